@@ -1,0 +1,152 @@
+/*
+ * oracle.h -- C interface of the CPU ORACLE (test infrastructure, NOT product).
+ *
+ * The oracle is a single-threaded CPU restatement of the reference hot path
+ * (ORBextractor / ORBmatcher / Optimizer::LocalBundleAdjustment + the g2o code
+ * it drives), written from reading the reference as text.  It exists to CHECK
+ * the HIP path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; nothing under orb_slam3-1_amd/ may.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
+ * for this path and cannot be compiled here (OpenCV / Eigen / Boost absent;
+ * see SURVEY.md 8(c)).  OpenCV-4.4.0 primitive semantics (FAST, resize,
+ * GaussianBlur, fastAtan2, cvRound) are restated from knowledge of the
+ * upstream algorithms; fidelity to a real OpenCV build is not verified.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same field layout as cv::KeyPoint (28 bytes). */
+typedef struct OracleKeyPoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} OracleKeyPoint;
+
+/* ---------------- extractor (reference src/ORBextractor.cc) ---------------- */
+void* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+void  orb_oracle_destroy(void* h);
+/* returns monoIndex (reference :1167) or -1 for an empty image (:1090). *n_out = number of keypoints. */
+int   orb_oracle_extract(void* h, const uint8_t* img, int w, int hgt, int stride, int lap0, int lap1,
+                         OracleKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+/* tables of the constructor (reference :409-469) */
+void  orb_oracle_tables(void* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                        int* nfeat_per_level, int* umax16);
+/* intermediates of the last extract call, for stage-wise parity */
+int   orb_oracle_level_size(void* h, int level, int* w, int* hgt);
+int   orb_oracle_level_image(void* h, int level, uint8_t* out /* w*h */);
+int   orb_oracle_level_blurred(void* h, int level, uint8_t* out /* w*h, only if level had keypoints */);
+int   orb_oracle_level_candidates(void* h, int level, OracleKeyPoint* out, int cap); /* vToDistributeKeys */
+int   orb_oracle_level_keypoints(void* h, int level, OracleKeyPoint* out, int cap);  /* after octree + angle, level coords */
+
+/* stand-alone primitives (OpenCV restatements), exposed for micro known-answer tests */
+int   orb_oracle_fast(const uint8_t* img, int w, int hgt, int stride, int threshold, int nonmax,
+                      OracleKeyPoint* out, int cap);
+void  orb_oracle_resize_linear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+void  orb_oracle_gaussian7(const uint8_t* src, int w, int hgt, int sstride, uint8_t* dst, int dstride);
+void  orb_oracle_gauss_taps(int ksize, double sigma, int* taps_q8);
+float orb_oracle_fast_atan2(float y, float x);
+void  orb_oracle_sincos(float angle_rad, float* c, float* s);
+int   orb_oracle_cvround(double v);
+/* std::sort with the reference's compareNodes ordering on (count, ULx) pairs; used to pin the device introsort */
+void  orb_oracle_sort_nodes(int* count, int* ulx, int* tag, int n);
+
+/* ---------------- matcher (reference src/ORBmatcher.cc) ---------------- */
+int   orbm_oracle_hamming(const uint8_t* a, const uint8_t* b);   /* :2058-2074 */
+
+/* FeatureVector as CSR: node ids ascending, offsets [n_nodes+1], feature indices. */
+typedef struct OracleFeatVec {
+    int32_t n_nodes;
+    const uint32_t* node_id;
+    const int32_t* offset;
+    const uint32_t* feat;
+} OracleFeatVec;
+
+/* SearchByBoW(KeyFrame*, Frame&, ...) mono branch (:223-425). match_f2kf[nF] = KF feature index or -1. */
+int   orbm_oracle_search_by_bow(const uint8_t* dKF, int nKF, const uint8_t* validKF, const float* angKF, const OracleFeatVec* fvKF,
+                                const uint8_t* dF, int nF, const float* angF, const OracleFeatVec* fvF,
+                                float nnratio, int checkOri, int32_t* match_f2kf);
+/* SearchByBoW(KeyFrame*, KeyFrame*, ...) (:765-905). match12[n1] = index in KF2 or -1. */
+int   orbm_oracle_search_by_bow_kfkf(const uint8_t* d1, int n1, const uint8_t* valid1, const float* ang1, const OracleFeatVec* fv1,
+                                     const uint8_t* d2, int n2, const uint8_t* valid2, const float* ang2, const OracleFeatVec* fv2,
+                                     float nnratio, int checkOri, int32_t* match12);
+
+/* Frame grid (reference src/Frame.cc:472-503, 744-822): 64x48 cells, CSR built by the oracle from keypoints. */
+typedef struct OracleFrameGrid {
+    int32_t n;                 /* number of features */
+    const float* x;            /* undistorted keypoint x */
+    const float* y;
+    const int32_t* octave;
+    float min_x, min_y, max_x, max_y;   /* mnMinX .. mnMaxY */
+    int32_t cols, rows;                 /* FRAME_GRID_COLS / ROWS (64, 48) */
+} OracleFrameGrid;
+
+/* SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFar, thFar) mono branch (:43-213).
+ * Per point: in_view, proj u/v, predicted level, view cos, track depth, 32B descriptor, has_obs (Observations()>0).
+ * occupied[nF]: in/out, 1 if F.mvpMapPoints[i] holds a MapPoint with Observations()>0.
+ * assign[nF]: in/out, index of map point held by feature i (-1 none). */
+int   orbm_oracle_search_by_projection(const OracleFrameGrid* g, const uint8_t* dF, const float* scale_factors, int nlevels,
+                                       int nMP, const uint8_t* in_view, const float* proj_u, const float* proj_v,
+                                       const int32_t* pred_level, const float* view_cos, const float* track_depth,
+                                       const uint8_t* dMP, const uint8_t* mp_has_obs, const uint8_t* mp_bad,
+                                       float th, int bFar, float thFar, float nnratio,
+                                       int32_t* assign, uint8_t* occupied);
+
+/* SearchByProjection(Frame& cur, const Frame& last, th, bMono) mono branch (:1676-1887).
+ * The caller projects (Tcw * x3Dw, Pinhole::project) and clears last_valid for invzc<0. */
+int   orbm_oracle_search_by_projection_last(const OracleFrameGrid* g, const uint8_t* dF, const float* angF,
+                                            const float* scale_factors, int nlevels,
+                                            int nLast, const uint8_t* last_valid /* has MP && !outlier && invzc>=0 */,
+                                            const float* proj_u, const float* proj_v,
+                                            const int32_t* last_octave, const float* last_angle,
+                                            const uint8_t* dMP, const uint8_t* mp_has_obs,
+                                            float th, int checkOri,
+                                            int32_t* assign, uint8_t* occupied);
+
+void  orbm_oracle_three_maxima(const int* hist_counts, int L, int* ind1, int* ind2, int* ind3); /* :2012-2053 */
+
+/* ---------------- local BA (reference src/Optimizer.cc:1116-1498 + g2o) ---------------- */
+typedef struct OracleLbaProblem {
+    int32_t n_poses;            /* optimisable + fixed */
+    const double* pose_q;       /* n_poses x 4: qx qy qz qw  (unit quaternion, world->camera) */
+    const double* pose_t;       /* n_poses x 3 */
+    const uint8_t* pose_fixed;  /* n_poses */
+    int32_t n_points;
+    const double* points;       /* n_points x 3 */
+    int32_t n_edges;
+    const int32_t* edge_point;  /* n_edges */
+    const int32_t* edge_pose;
+    const double* edge_obs;     /* n_edges x 3: u, v, u_right (u_right ignored for mono) */
+    const double* edge_inv_sigma2;
+    const uint8_t* edge_stereo; /* 0 mono (EdgeSE3ProjectXYZ), 1 stereo (EdgeStereoSE3ProjectXYZ) */
+    double fx, fy, cx, cy, bf;  /* camera parameters already promoted from float */
+    double huber_mono, huber_stereo;   /* delta (already through float) ; <=0 => no robust kernel */
+} OracleLbaProblem;
+
+typedef struct OracleLbaStats {
+    int32_t iterations;         /* outer iterations executed (calls of solve()) */
+    int32_t trials;             /* total LM trials */
+    int32_t stop_reason;        /* 0 max iters, 1 terminate(trials/rho==0), 2 nBad>=3, 3 stop flag, 4 solver fail */
+    double lambda;
+    double chi2_initial;
+    double chi2_final;
+    double chi2_trace[16];
+} OracleLbaStats;
+
+int   lba_oracle_solve(const OracleLbaProblem* p, const volatile uint8_t* stop_flag, int max_iters, double lambda_init,
+                       double* poses_q_out, double* poses_t_out, double* points_out,
+                       double* chi2_per_edge, uint8_t* depth_positive, OracleLbaStats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+"""Deterministic synthetic inputs for the hot path.
+
+No dataset ships with the reference (EuRoC images / ORBvoc.txt are listed in
+.MISSING_LARGE_BLOBS), so tests and bench.py use these seeded generators.
+Pure numpy; identical output on every machine (legacy RandomState streams).
+"""
+import numpy as np
+
+
+def _box3(a):
+    """3x3 box filter with edge replication, float32."""
+    p = np.pad(a, 1, mode="edge")
+    acc = np.zeros_like(a, dtype=np.float32)
+    for dy in range(3):
+        for dx in range(3):
+            acc += p[dy:dy + a.shape[0], dx:dx + a.shape[1]]
+    return acc / 9.0
+
+
+def make_frame(seed, w=640, h=480, n_rect=400, strip=64):
+    """640x480 u8 mono frame: band-limited noise + random grey rectangles + a flat strip.
+
+    The mix yields corners at both FAST thresholds (20 and 7) and some empty
+    cells (the flat strip forces the minThFAST fallback, reference
+    src/ORBextractor.cc:843-846)."""
+    rs = np.random.RandomState(1000003 * (seed + 1) % (2 ** 31 - 1))
+    noise = rs.randint(0, 256, size=(h, w)).astype(np.float32)
+    for _ in range(3):
+        noise = _box3(noise)
+    img = 128.0 + (noise - 127.5) * 1.6
+    n_rect = int(n_rect * (w * h) / (640.0 * 480.0)) if (w, h) != (640, 480) else n_rect
+    for _ in range(max(n_rect, 4)):
+        rw = int(rs.randint(6, max(8, w // 6)))
+        rh = int(rs.randint(6, max(8, h // 6)))
+        x0 = int(rs.randint(-rw // 2, w - rw // 2))
+        y0 = int(rs.randint(-rh // 2, h - rh // 2))
+        g = float(rs.randint(10, 246))
+        a = float(rs.uniform(0.35, 1.0))
+        xs, xe = max(x0, 0), min(x0 + rw, w)
+        ys, ye = max(y0, 0), min(y0 + rh, h)
+        img[ys:ye, xs:xe] = (1 - a) * img[ys:ye, xs:xe] + a * g
+    # low-contrast texture so that some cells only fire at minThFAST
+    img += rs.normal(0.0, 2.0, size=(h, w)).astype(np.float32)
+    if strip > 0 and w > 3 * strip:
+        sx = int(rs.randint(w // 4, w // 2))
+        img[:, sx:sx + strip] = 97.0
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_frames(batch, w=640, h=480, seed0=0):
+    return np.stack([make_frame(seed0 + i, w, h) for i in range(batch)])
+
+
+# ---------------------------------------------------------------- matcher inputs
+def _popcount8(a):
+    return np.unpackbits(a, axis=-1).sum(-1)
+
+
+def make_tree(seed, k=10):
+    """Synthetic 2-level k-ary vocabulary tree: (k level-1 centroids, k*k level-2 centroids).
+
+    Stand-in for Vocabulary/ORBvoc.txt (not shipped).  Level-2 node j*k+i is
+    child i of level-1 node j."""
+    rs = np.random.RandomState(7919 + seed)
+    l1 = rs.randint(0, 256, size=(k, 32)).astype(np.uint8)
+    l2 = rs.randint(0, 256, size=(k * k, 32)).astype(np.uint8)
+    return l1, l2
+
+
+def assign_nodes(desc, tree):
+    """Descend the tree with the DBoW2 rule (reference Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1232-1254):
+    at each level pick the child with the smallest Hamming distance, first minimum wins."""
+    l1, l2 = tree
+    k = l1.shape[0]
+    d1 = _popcount8(desc[:, None, :] ^ l1[None, :, :])
+    c1 = d1.argmin(1)
+    ch = l2.reshape(k, k, 32)[c1]
+    d2 = _popcount8(desc[:, None, :] ^ ch)
+    c2 = d2.argmin(1)
+    return (c1 * k + c2).astype(np.uint32)
+
+
+def feature_vector(node_of_feature):
+    """FeatureVector CSR (node ids ascending; inside a node feature indices ascending = insertion order,
+    reference Thirdparty/DBoW2/DBoW2/FeatureVector.cpp:31-47)."""
+    nodes = np.unique(node_of_feature)
+    offs = [0]
+    feats = []
+    for nd in nodes:
+        idx = np.nonzero(node_of_feature == nd)[0]
+        feats.append(idx)
+        offs.append(offs[-1] + len(idx))
+    feat = np.concatenate(feats).astype(np.uint32) if feats else np.zeros(0, np.uint32)
+    return nodes.astype(np.uint32), np.asarray(offs, np.int32), feat
+
+
+def make_match_set(seed, n=1000, p_true=0.7, k=10):
+    """Two descriptor sets (KF, F) of n x 32 B."""
+    rs = np.random.RandomState(4241 + seed)
+    dF = rs.randint(0, 256, size=(n, 32)).astype(np.uint8)
+    perm = rs.permutation(n)
+    is_true = rs.uniform(size=n) < p_true
+    flip_p = np.where(is_true, 0.02, 0.5)
+    bits = np.unpackbits(dF[perm], axis=1)
+    flips = rs.uniform(size=bits.shape) < flip_p[:, None]
+    dKF = np.packbits(bits ^ flips.astype(np.uint8), axis=1)
+    angF = rs.uniform(0, 360, size=n).astype(np.float32)
+    off = np.where(is_true, rs.normal(15.0, 3.0, size=n), rs.uniform(0, 360, size=n))
+    angKF = np.mod(angF[perm].astype(np.float64) + off, 360.0).astype(np.float32)
+    validKF = (rs.uniform(size=n) < 0.9).astype(np.uint8)
+    tree = make_tree(seed, k)
+    fvKF = feature_vector(assign_nodes(dKF, tree))
+    fvF = feature_vector(assign_nodes(dF, tree))
+    return dict(dKF=dKF, dF=dF, angKF=angKF, angF=angF, validKF=validKF, fvKF=fvKF, fvF=fvF, perm=perm, is_true=is_true)
+
+
+# ---------------------------------------------------------------- BA window
+def _quat_from_R(R):
+    """Rotation matrix -> (x, y, z, w), w >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        v = np.zeros(3)
+        v[i] = 0.25 * s
+        v[j] = (R[j, i] + R[i, j]) / s
+        v[k] = (R[k, i] + R[i, k]) / s
+        q = np.array([v[0], v[1], v[2], (R[k, j] - R[j, k]) / s])
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def make_ba_window(seed, n_opt=50, n_fixed=10, n_points=2000, obs_per_point=10, stereo_frac=0.0,
+                   outlier_frac=0.03):
+    """Synthetic LocalBA window: poses on a smooth arc looking at a point cloud in a
+    10x10x4 m box at 3-15 m depth, EuRoC pinhole intrinsics (reference Examples/Monocular/EuRoC.yaml:23-26),
+    pixel noise by octave, 3 % gross outliers, perturbed initial estimates.  All inputs are rounded through
+    float32 as the reference does (src/Optimizer.cc:1217-1218,1286,1309,1316)."""
+    rs = np.random.RandomState(9001 + seed)
+    fx, fy, cx, cy = [float(np.float32(v)) for v in (458.654, 457.296, 367.215, 248.375)]
+    bf = float(np.float32(47.90639384423901))
+    n_poses = n_opt + n_fixed
+    pts = np.stack([rs.uniform(-5, 5, n_points), rs.uniform(-2, 2, n_points), rs.uniform(3, 15, n_points)], 1)
+    Rs, ts = [], []
+    for i in range(n_poses):
+        a = (i / max(n_poses - 1, 1) - 0.5) * 0.6          # yaw sweep +-0.3 rad
+        c = np.array([3.0 * np.sin(a * 2), 0.2 * np.sin(i * 0.7), -1.0 + 0.5 * np.cos(a * 2)])   # camera centre
+        Rwc = _rodrigues(np.array([0.0, a, 0.0])) @ _rodrigues(np.array([0.02 * np.sin(i), 0, 0.01 * np.cos(i)]))
+        Rcw = Rwc.T
+        Rs.append(Rcw)
+        ts.append(-Rcw @ c)
+    Rs = np.array(Rs)
+    ts = np.array(ts)
+    scale2 = 1.2 ** (2 * np.arange(8))
+    e_pt, e_pose, e_obs, e_w, e_st = [], [], [], [], []
+    for l in range(n_points):
+        Xc = (Rs @ pts[l]) + ts                             # n_poses x 3
+        u = fx * Xc[:, 0] / Xc[:, 2] + cx
+        v = fy * Xc[:, 1] / Xc[:, 2] + cy
+        vis = np.nonzero((Xc[:, 2] > 0.5) & (u > 0) & (u < 752) & (v > 0) & (v < 480))[0]
+        if len(vis) == 0:
+            vis = np.array([int(np.argmax(Xc[:, 2]))])
+        sel = rs.permutation(vis)[:obs_per_point]
+        sel.sort()
+        for ip in sel:
+            octv = int(rs.randint(0, 8))
+            sig = np.sqrt(scale2[octv])
+            uu = u[ip] + rs.normal(0, sig)
+            vv = v[ip] + rs.normal(0, sig)
+            if rs.uniform() < outlier_frac:
+                uu += rs.choice([-30.0, 30.0])
+                vv += rs.choice([-30.0, 30.0])
+            st = rs.uniform() < stereo_frac
+            ur = uu - bf / Xc[ip, 2] + (rs.normal(0, sig) if st else 0.0)
+            e_pt.append(l); e_pose.append(int(ip))
+            e_obs.append([float(np.float32(uu)), float(np.float32(vv)), float(np.float32(ur)) if st else -1.0])
+            e_w.append(float(np.float32(1.0 / scale2[octv])))
+            e_st.append(1 if st else 0)
+    # perturbed initial estimates (1 deg / 2 cm poses, 3 cm points), through float32
+    q0 = np.zeros((n_poses, 4)); t0 = np.zeros((n_poses, 3))
+    fixed = np.zeros(n_poses, np.uint8)
+    fixed[n_opt:] = 1
+    for i in range(n_poses):
+        if fixed[i]:
+            R, t = Rs[i], ts[i]
+        else:
+            dR = _rodrigues(rs.normal(0, np.deg2rad(1.0) / np.sqrt(3), 3))
+            R = dR @ Rs[i]
+            t = dR @ ts[i] + rs.normal(0, 0.02 / np.sqrt(3), 3)
+        q = _quat_from_R(R).astype(np.float32).astype(np.float64)
+        q0[i] = q
+        t0[i] = t.astype(np.float32).astype(np.float64)
+    p0 = (pts + rs.normal(0, 0.03 / np.sqrt(3), pts.shape)).astype(np.float32).astype(np.float64)
+    th_mono = float(np.float32(np.sqrt(5.991)))
+    th_stereo = float(np.float32(np.sqrt(7.815)))
+    return dict(pose_q=q0, pose_t=t0, pose_fixed=fixed, points=p0,
+                edge_point=np.asarray(e_pt, np.int32), edge_pose=np.asarray(e_pose, np.int32),
+                edge_obs=np.asarray(e_obs, np.float64), edge_inv_sigma2=np.asarray(e_w, np.float64),
+                edge_stereo=np.asarray(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
+                huber_mono=th_mono, huber_stereo=th_stereo,
+                true_R=Rs, true_t=ts, true_points=pts)

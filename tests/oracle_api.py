@@ -1,0 +1,223 @@
+"""ctypes bindings for the CPU ORACLE (oracle/liborb_oracle.so).  Test infrastructure only:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                     ("octave", "i4"), ("class_id", "i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build_oracle(native=False):
+    out = "liborb_oracle_native.so" if native else "liborb_oracle.so"
+    args = ["make", "-C", ORACLE_DIR, "OUT=" + out]
+    if native:
+        args.append("ARCH=-march=native")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return os.path.join(ORACLE_DIR, out)
+
+
+class FeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("offset", C.c_void_p), ("feat", C.c_void_p)]
+
+
+class FrameGrid(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("cols", C.c_int32), ("rows", C.c_int32)]
+
+
+class LbaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("pose_q", C.c_void_p), ("pose_t", C.c_void_p), ("pose_fixed", C.c_void_p),
+                ("n_points", C.c_int32), ("points", C.c_void_p),
+                ("n_edges", C.c_int32), ("edge_point", C.c_void_p), ("edge_pose", C.c_void_p), ("edge_obs", C.c_void_p),
+                ("edge_inv_sigma2", C.c_void_p), ("edge_stereo", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+class LbaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("stop_reason", C.c_int32),
+                ("lambda_", C.c_double), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("chi2_trace", C.c_double * 16)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, path=None):
+        if path is None:
+            path = os.path.join(ORACLE_DIR, "liborb_oracle.so")
+            if not os.path.exists(path):
+                build_oracle()
+        self.lib = L = C.CDLL(path)
+        L.orb_oracle_create.restype = C.c_void_p
+        L.orb_oracle_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orb_oracle_destroy.argtypes = [C.c_void_p]
+        L.orb_oracle_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orb_oracle_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orb_oracle_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for f in (L.orb_oracle_level_image, L.orb_oracle_level_blurred):
+            f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        for f in (L.orb_oracle_level_candidates, L.orb_oracle_level_keypoints):
+            f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orb_oracle_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orb_oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orb_oracle_gaussian7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orb_oracle_gauss_taps.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.orb_oracle_fast_atan2.restype = C.c_float
+        L.orb_oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orb_oracle_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orb_oracle_cvround.argtypes = [C.c_double]
+        L.orb_oracle_sort_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orbm_oracle_hamming.argtypes = [C.c_void_p, C.c_void_p]
+        L.orbm_oracle_three_maxima.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 3
+        L.orbm_oracle_search_by_bow.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
+                                                C.c_void_p, C.c_int, C.c_void_p, C.POINTER(FeatVec),
+                                                C.c_float, C.c_int, C.c_void_p]
+        L.orbm_oracle_search_by_bow_kfkf.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
+                                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
+                                                     C.c_float, C.c_int, C.c_void_p]
+        L.orbm_oracle_search_by_projection.argtypes = [C.POINTER(FrameGrid), C.c_void_p, C.c_void_p, C.c_int,
+                                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orbm_oracle_search_by_projection_last.argtypes = [C.POINTER(FrameGrid), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                            C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.lba_oracle_solve.argtypes = [C.POINTER(LbaProblem), C.c_void_p, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LbaStats)]
+
+    # ---- extractor
+    def extractor(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7):
+        return OracleExtractor(self, nfeatures, scale, nlevels, ini, mn)
+
+    # ---- matcher
+    def hamming(self, a, b):
+        return self.lib.orbm_oracle_hamming(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)))
+
+    @staticmethod
+    def _fv(fv):
+        nodes, offs, feat = [np.ascontiguousarray(a) for a in fv]
+        s = FeatVec(len(nodes), _p(nodes), _p(offs), _p(feat))
+        s._keep = (nodes, offs, feat)
+        return s
+
+    def search_by_bow(self, dKF, validKF, angKF, fvKF, dF, angF, fvF, nnratio=0.7, check_ori=True):
+        dKF, dF = np.ascontiguousarray(dKF), np.ascontiguousarray(dF)
+        match = np.full(len(dF), -1, np.int32)
+        a, b = self._fv(fvKF), self._fv(fvF)
+        n = self.lib.orbm_oracle_search_by_bow(_p(dKF), len(dKF), _p(validKF), _p(angKF), C.byref(a),
+                                               _p(dF), len(dF), _p(angF), C.byref(b),
+                                               nnratio, int(check_ori), _p(match))
+        return n, match
+
+    def search_by_bow_kfkf(self, d1, valid1, ang1, fv1, d2, valid2, ang2, fv2, nnratio=0.7, check_ori=True):
+        match = np.full(len(d1), -1, np.int32)
+        a, b = self._fv(fv1), self._fv(fv2)
+        n = self.lib.orbm_oracle_search_by_bow_kfkf(_p(d1), len(d1), _p(valid1), _p(ang1), C.byref(a),
+                                                    _p(d2), len(d2), _p(valid2), _p(ang2), C.byref(b),
+                                                    nnratio, int(check_ori), _p(match))
+        return n, match
+
+    @staticmethod
+    def _grid(g):
+        s = FrameGrid(len(g["x"]), _p(g["x"]), _p(g["y"]), _p(g["octave"]),
+                      g["min_x"], g["min_y"], g["max_x"], g["max_y"], g.get("cols", 64), g.get("rows", 48))
+        return s
+
+    def search_by_projection(self, g, dF, scale_factors, mp, th, nnratio, assign, occupied, b_far=False, th_far=0.0):
+        s = self._grid(g)
+        return self.lib.orbm_oracle_search_by_projection(
+            C.byref(s), _p(dF), _p(scale_factors), len(scale_factors), len(mp["u"]),
+            _p(mp["in_view"]), _p(mp["u"]), _p(mp["v"]), _p(mp["level"]), _p(mp["view_cos"]), _p(mp["depth"]),
+            _p(mp["desc"]), _p(mp["has_obs"]), _p(mp["bad"]), th, int(b_far), th_far, nnratio, _p(assign), _p(occupied))
+
+    def search_by_projection_last(self, g, dF, angF, scale_factors, last, th, check_ori, assign, occupied):
+        s = self._grid(g)
+        return self.lib.orbm_oracle_search_by_projection_last(
+            C.byref(s), _p(dF), _p(angF), _p(scale_factors), len(scale_factors), len(last["u"]),
+            _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last["octave"]), _p(last["angle"]),
+            _p(last["desc"]), _p(last["has_obs"]), th, int(check_ori), _p(assign), _p(occupied))
+
+    # ---- LBA
+    def lba_solve(self, w, max_iters=10, lambda_init=0.0, stop_flag=None):
+        keep = {k: np.ascontiguousarray(w[k]) for k in ("pose_q", "pose_t", "pose_fixed", "points", "edge_point",
+                                                          "edge_pose", "edge_obs", "edge_inv_sigma2", "edge_stereo")}
+        pr = LbaProblem(len(keep["pose_q"]), _p(keep["pose_q"]), _p(keep["pose_t"]), _p(keep["pose_fixed"]),
+                        len(keep["points"]), _p(keep["points"]), len(keep["edge_point"]), _p(keep["edge_point"]),
+                        _p(keep["edge_pose"]), _p(keep["edge_obs"]), _p(keep["edge_inv_sigma2"]), _p(keep["edge_stereo"]),
+                        w["fx"], w["fy"], w["cx"], w["cy"], w["bf"], w["huber_mono"], w["huber_stereo"])
+        q = np.zeros_like(keep["pose_q"]); t = np.zeros_like(keep["pose_t"]); pts = np.zeros_like(keep["points"])
+        chi2 = np.zeros(len(keep["edge_point"])); dpos = np.zeros(len(keep["edge_point"]), np.uint8)
+        st = LbaStats()
+        sf = _p(stop_flag) if stop_flag is not None else None
+        self.lib.lba_oracle_solve(C.byref(pr), sf, max_iters, lambda_init, _p(q), _p(t), _p(pts), _p(chi2), _p(dpos), C.byref(st))
+        stats = dict(iterations=st.iterations, trials=st.trials, stop_reason=st.stop_reason, lambda_=st.lambda_,
+                     chi2_initial=st.chi2_initial, chi2_final=st.chi2_final, chi2_trace=list(st.chi2_trace))
+        return dict(pose_q=q, pose_t=t, points=pts, chi2=chi2, depth_positive=dpos, stats=stats)
+
+
+class OracleExtractor:
+    def __init__(self, orc, nfeatures, scale, nlevels, ini, mn):
+        self.o = orc
+        self.L = orc.lib
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = C.c_void_p(self.L.orb_oracle_create(nfeatures, scale, nlevels, ini, mn))
+
+    def __del__(self):
+        try:
+            self.L.orb_oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32); um = np.zeros(16, np.int32)
+        self.L.orb_oracle_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(nf), _p(um))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, nfeat=nf, umax=um)
+
+    def extract(self, img, lap=(0, 1000)):
+        img = np.ascontiguousarray(img)
+        h, w = img.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+        r = self.L.orb_oracle_extract(self.h, _p(img), w, h, w, lap[0], lap[1], _p(kps), _p(desc), cap, C.byref(n))
+        return r, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_size(self, l):
+        w, h = C.c_int(), C.c_int()
+        self.L.orb_oracle_level_size(self.h, l, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_image(self, l):
+        w, h = self.level_size(l)
+        out = np.zeros((h, w), np.uint8)
+        self.L.orb_oracle_level_image(self.h, l, _p(out))
+        return out
+
+    def level_blurred(self, l):
+        w, h = self.level_size(l)
+        out = np.zeros((h, w), np.uint8)
+        r = self.L.orb_oracle_level_blurred(self.h, l, _p(out))
+        return out if r == 0 else None
+
+    def level_candidates(self, l, cap=100000):
+        out = np.zeros(cap, KP_DTYPE)
+        n = self.L.orb_oracle_level_candidates(self.h, l, _p(out), cap)
+        return out[:n].copy()
+
+    def level_keypoints(self, l, cap=20000):
+        out = np.zeros(cap, KP_DTYPE)
+        n = self.L.orb_oracle_level_keypoints(self.h, l, _p(out), cap)
+        return out[:n].copy()
