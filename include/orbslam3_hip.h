@@ -1,0 +1,244 @@
+/*
+ * orbslam3_hip.h -- C ABI of the MI355X (gfx950) implementation of ORB-SLAM3's per-frame hot path.
+ *
+ * The reference has no FFI layer: the boundary is three C++ signatures inside libORB_SLAM3.so
+ * (SURVEY.md 8(b)).  This header is what a binding for that path links against; every entry
+ * point cites the reference interface it replaces.  POD only: no cv::Mat / Eigen / torch types.
+ * include/orbslam3_shim.hpp adapts these to the reference's own C++ signatures.
+ *
+ * Conventions: int status returns (0 ok, <0 error); caller-allocated outputs with capacity + count;
+ * handles are NOT thread-safe (same as one reference ORBextractor instance); no global state.
+ * All kernels are hand-written HIP for gfx950; there is no CPU fallback -- if no HIP device is
+ * usable every compute entry point returns ORBX_ERR_NO_DEVICE.
+ */
+#ifndef ORBSLAM3_HIP_H
+#define ORBSLAM3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_OK 0
+#define ORBX_ERR_EMPTY (-1)        /* empty image: reference returns -1 (src/ORBextractor.cc:1090-1091) */
+#define ORBX_ERR_CAPACITY (-2)     /* caller-provided capacity too small; *n holds the required count */
+#define ORBX_ERR_ARG (-3)
+#define ORBX_ERR_NO_DEVICE (-4)
+#define ORBX_ERR_HIP (-5)
+#define ORBX_ERR_INTERNAL (-6)     /* device-side guard tripped (scratch capacity); never a silent wrong result */
+
+const char* orbx_last_error(void);         /* thread-local message of the last failing call */
+int orbx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Extractor -- replaces ORB_SLAM3::ORBextractor (include/ORBextractor.h:44-109)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Field layout of cv::KeyPoint (28 bytes), so std::vector<cv::KeyPoint> can be filled with memcpy. */
+typedef struct OrbxKeyPoint {
+    float x, y;        /* pt, level-0 coordinates (scaled as src/ORBextractor.cc:1149-1151) */
+    float size;        /* int(31 * scale[level])          (:880) */
+    float angle;       /* degrees [0,360), IC_Angle        (:76-103) */
+    float response;    /* FAST corner score */
+    int32_t octave;
+    int32_t class_id;  /* -1 */
+} OrbxKeyPoint;
+
+typedef struct orbx_extractor orbx_extractor;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) (src/ORBextractor.cc:409-469). */
+int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast,
+                int device, orbx_extractor** out);
+void orbx_destroy(orbx_extractor* h);
+
+/* ORBextractor::operator()(image, mask [ignored], keypoints, descriptors, vLappingArea) (src/ORBextractor.cc:1086-1168).
+ * Host buffers in, host buffers out.  kps/desc have room for `cap` keypoints (orbx_max_keypoints() is always enough).
+ * *n = number of keypoints, *mono_index = the reference's return value.  Returns ORBX_ERR_EMPTY for an empty image. */
+int orbx_extract(orbx_extractor* h, const uint8_t* img, int width, int height, int stride,
+                 int lap0, int lap1, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
+
+/* Throughput path: `batch` independent frames of identical geometry per call (one reference operator() each).
+ * Host variant: imgs[b] are host pointers; outputs are [batch][cap] host arrays. */
+int orbx_extract_batch(orbx_extractor* h, const uint8_t* const* imgs, int batch, int width, int height, int stride,
+                       int lap0, int lap1, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n, int* mono_index);
+
+/* Device-resident variant: d_imgs, d_kps, d_desc, d_n, d_mono are DEVICE pointers (frame b at d_imgs + b*frame_stride);
+ * the call only enqueues work on `stream` (a hipStream_t, NULL = default stream) and returns.
+ * d_status[batch] (device, int32) receives ORBX_OK / ORBX_ERR_CAPACITY / ORBX_ERR_INTERNAL per frame. */
+int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int batch, int width, int height,
+                              int row_stride, size_t frame_stride, int lap0, int lap1,
+                              OrbxKeyPoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n, int32_t* d_mono,
+                              int32_t* d_status, void* stream);
+
+/* Upper bound on keypoints per frame: sum over levels of (mnFeaturesPerLevel + 3) (octree overshoot). */
+int orbx_max_keypoints(const orbx_extractor* h);
+
+/* Getters (include/ORBextractor.h:61-81).  Arrays of nlevels floats; NULL pointers are skipped. */
+int orbx_levels(const orbx_extractor* h);
+float orbx_scale_factor(const orbx_extractor* h);
+int orbx_scale_tables(const orbx_extractor* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
+int orbx_features_per_level(const orbx_extractor* h, int* n_per_level);
+
+/* Replaces the public member mvImagePyramid (include/ORBextractor.h:83; read by Frame::ComputeStereoMatches,
+ * src/Frame.cc:938,1028,1043).  Copies level `level` of frame `frame` of the LAST extract call to host memory.
+ * border=0: the WxH level image; border=19: with the EDGE_THRESHOLD reflect-101 border of ComputePyramid (:1170-1195). */
+int orbx_pyramid_level_size(const orbx_extractor* h, int level, int* width, int* height);
+int orbx_pyramid_level(orbx_extractor* h, int frame, int level, int border, uint8_t* dst, int dst_stride);
+
+/* Stage-wise introspection for parity tests (results of the LAST extract call, frame `frame`). */
+int orbx_debug_blurred_level(orbx_extractor* h, int frame, int level, uint8_t* dst, int dst_stride);
+/* FAST candidates of a level in vToDistributeKeys order (src/ORBextractor.cc:787-872): x,y relative to minBorder, response. */
+int orbx_debug_candidates(orbx_extractor* h, int frame, int level, OrbxKeyPoint* out, int cap, int* n);
+/* per-level keypoints after DistributeOctTree + orientation, level coordinates, list order (:874-895). */
+int orbx_debug_level_keypoints(orbx_extractor* h, int frame, int level, OrbxKeyPoint* out, int cap, int* n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Matcher -- replaces ORB_SLAM3::ORBmatcher (include/ORBmatcher.h:40-106)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2058-2074).  Pure host helper (32-byte operands). */
+int orbm_hamming(const uint8_t a[32], const uint8_t b[32]);
+
+/* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened to CSR, node ids ascending. */
+typedef struct OrbmFeatVec {
+    int32_t n_nodes;
+    const uint32_t* node_id;   /* [n_nodes] ascending */
+    const int32_t* offset;     /* [n_nodes+1] */
+    const uint32_t* feat;      /* [offset[n_nodes]] feature indices, insertion order inside a node */
+} OrbmFeatVec;
+
+typedef struct orbm_matcher orbm_matcher;
+int orbm_create(int device, orbm_matcher** out);
+void orbm_destroy(orbm_matcher* m);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:223-425),
+ * mono branch.  valid_kf[i] = (vpMapPointsKF[i] && !isBad()).  match_f2kf[nF] receives the KF feature index whose
+ * MapPoint the shim stores in vpMapPointMatches[f], or -1.  Returns the reference's return value (>=0) or <0 on error. */
+int orbm_search_by_bow(orbm_matcher* m,
+                       const uint8_t* desc_kf, int n_kf, const uint8_t* valid_kf, const float* angle_kf, const OrbmFeatVec* fv_kf,
+                       const uint8_t* desc_f, int n_f, const float* angle_f, const OrbmFeatVec* fv_f,
+                       float nnratio, int check_orientation, int32_t* match_f2kf);
+
+/* Batched variant: P independent (KF, F) pairs per launch, everything host-side SoA of per-pair pointers. */
+typedef struct OrbmBowPair {
+    const uint8_t* desc_kf; int32_t n_kf; const uint8_t* valid_kf; const float* angle_kf; OrbmFeatVec fv_kf;
+    const uint8_t* desc_f;  int32_t n_f;  const float* angle_f;  OrbmFeatVec fv_f;
+    int32_t* match_f2kf;    /* out [n_f] */
+    int32_t n_matches;      /* out */
+} OrbmBowPair;
+int orbm_search_by_bow_batch(orbm_matcher* m, OrbmBowPair* pairs, int n_pairs, float nnratio, int check_orientation);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:765-905).
+ * match12[n1] = feature index in KF2 or -1.  Strict `< TH_LOW` as the reference (:848). */
+int orbm_search_by_bow_kfkf(orbm_matcher* m,
+                            const uint8_t* desc1, int n1, const uint8_t* valid1, const float* angle1, const OrbmFeatVec* fv1,
+                            const uint8_t* desc2, int n2, const uint8_t* valid2, const float* angle2, const OrbmFeatVec* fv2,
+                            float nnratio, int check_orientation, int32_t* match12);
+
+/* Frame keypoint grid inputs (Frame::AssignFeaturesToGrid / GetFeaturesInArea, src/Frame.cc:472-503,744-822). */
+typedef struct OrbmFrame {
+    int32_t n;                         /* F.N */
+    const float* x; const float* y;    /* mvKeysUn[i].pt */
+    const int32_t* octave;             /* mvKeysUn[i].octave */
+    const float* angle;                /* mvKeysUn[i].angle (may be NULL when orientation is not checked) */
+    const uint8_t* desc;               /* mDescriptors, n x 32 */
+    float min_x, min_y, max_x, max_y;  /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    int32_t grid_cols, grid_rows;      /* FRAME_GRID_COLS, FRAME_GRID_ROWS (64, 48: include/Frame.h:44-45) */
+    const float* scale_factors;        /* mvScaleFactors */
+    int32_t n_levels;
+} OrbmFrame;
+
+/* int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, float th, bool bFarPoints,
+ *                                    float thFarPoints) (src/ORBmatcher.cc:43-213), mono branch.
+ * Per map point i: in_view = mbTrackInView, proj_u/v = mTrackProjX/Y, pred_level = mnTrackScaleLevel,
+ * view_cos = mTrackViewCos, track_depth = mTrackDepth, bad = isBad(), has_obs = Observations()>0, desc = GetDescriptor().
+ * occupied[n] (in/out): F.mvpMapPoints[i] != NULL && Observations()>0.  assign[n] (in/out): map point index now held by
+ * feature i (unchanged where the call made no assignment).  Returns nmatches. */
+int orbm_search_by_projection(orbm_matcher* m, const OrbmFrame* f,
+                              int n_mp, const uint8_t* in_view, const float* proj_u, const float* proj_v,
+                              const int32_t* pred_level, const float* view_cos, const float* track_depth,
+                              const uint8_t* desc_mp, const uint8_t* mp_has_obs, const uint8_t* mp_bad,
+                              float th, int far_points, float th_far, float nnratio,
+                              int32_t* assign, uint8_t* occupied);
+
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th, bool bMono)
+ * (src/ORBmatcher.cc:1676-1887), mono branch.  The caller projects the last frame's map points (Tcw*x3Dw,
+ * Pinhole::project) with the reference's own float expressions and clears last_valid where invzc<0, the point is
+ * NULL or an outlier.  last_octave/last_angle = LastFrame.mvKeys[i].octave / mvKeysUn[i].angle. */
+int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
+                                   int n_last, const uint8_t* last_valid, const float* proj_u, const float* proj_v,
+                                   const int32_t* last_octave, const float* last_angle,
+                                   const uint8_t* desc_mp, const uint8_t* mp_has_obs,
+                                   float th, int check_orientation,
+                                   int32_t* assign, uint8_t* occupied);
+
+/* ------------------------------------------------------------------------------------------------
+ * Local bundle adjustment -- replaces the numerical core of
+ * Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&)
+ * (include/Optimizer.h:58, src/Optimizer.cc:1116-1498) and, with robust=0 / other Huber deltas, of
+ * Optimizer::BundleAdjustment (:60-390).  The pointer-graph walk (:1118-1186) and the map write-back
+ * (:1464-1497) stay in the host shim.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct LbaProblem {
+    int32_t n_poses;              /* local (optimisable) + fixed keyframes, in ascending vertex id */
+    const double* pose_q;         /* [n_poses][4] qx qy qz qw of Tcw (SE3Quat ctor normalises, se3quat.h:59-61) */
+    const double* pose_t;         /* [n_poses][3] */
+    const uint8_t* pose_fixed;    /* [n_poses] setFixed() */
+    int32_t n_points;
+    const double* points;         /* [n_points][3] world positions, ascending vertex id */
+    int32_t n_edges;              /* in optimizer.addEdge() order */
+    const int32_t* edge_point;    /* [n_edges] */
+    const int32_t* edge_pose;     /* [n_edges] */
+    const double* edge_obs;       /* [n_edges][3] u, v, u_right (ignored for mono edges) */
+    const double* edge_inv_sigma2;/* [n_edges] mvInvLevelSigma2[octave] promoted to double */
+    const uint8_t* edge_stereo;   /* [n_edges] 0: EdgeSE3ProjectXYZ, 1: g2o::EdgeStereoSE3ProjectXYZ */
+    double fx, fy, cx, cy, bf;    /* float camera parameters promoted to double */
+    double huber_mono;            /* (double)(float)sqrt(5.991) for LocalBA; <= 0 disables the robust kernel */
+    double huber_stereo;          /* (double)(float)sqrt(7.815) */
+} LbaProblem;
+
+typedef struct LbaStats {
+    int32_t iterations;           /* outer iterations (OptimizationAlgorithmLevenberg::solve calls) */
+    int32_t trials;               /* total LM trials */
+    int32_t stop_reason;          /* 0 max iters, 1 trials exhausted / rho==0, 2 Raul's nBad>=3 rule, 3 stop flag, 4 solver failure */
+    double lambda;
+    double chi2_initial;
+    double chi2_final;
+    double chi2_trace[16];
+} LbaStats;
+
+typedef struct lba_solver lba_solver;
+int lba_create(int device, lba_solver** out);
+void lba_destroy(lba_solver* s);
+
+/* optimizer.initializeOptimization(); optimizer.optimize(max_iters) (src/Optimizer.cc:1410-1411).
+ * stop_flag: the caller's bool* pbStopFlag, polled (never written) between outer iterations and LM trials.
+ * lambda_init: 0 => tau*max(diag) (g2o computeLambdaInit), >0 => setUserLambdaInit (src/Optimizer.cc:1197-1198).
+ * Outputs: optimised poses/points (all n_poses / n_points entries; fixed ones unchanged up to normalisation),
+ * chi2_per_edge = e->chi2() and depth_positive = e->isDepthPositive() as the epilogue (:1417-1460) reads them. */
+int lba_solve(lba_solver* s, const LbaProblem* problem, const volatile uint8_t* stop_flag, int max_iters, double lambda_init,
+              double* pose_q_out, double* pose_t_out, double* points_out,
+              double* chi2_per_edge, uint8_t* depth_positive, LbaStats* stats);
+
+/* Sharded global BA: landmarks (with all their edges) are partitioned over ranks, poses replicated.
+ * One LM trial = lba_shard_reduce() on every rank -> all-reduce(sum) of the returned buffer across ranks (RCCL,
+ * done by the caller on the DEVICE buffer) -> lba_shard_finish() on every rank.  See INTEGRATION.md. */
+typedef struct lba_shard lba_shard;
+int lba_shard_create(int device, const LbaProblem* local_problem, lba_shard** out);
+void lba_shard_destroy(lba_shard* s);
+/* number of doubles in the reduce buffer: (6P)^2 + 6P + 4, P = number of non-fixed poses */
+int64_t lba_shard_reduce_len(const lba_shard* s);
+/* device pointer of the reduce buffer [S | b_schur | chi2, max_diag, scale_partial, spare] */
+double* lba_shard_reduce_buffer(lba_shard* s);
+int lba_shard_linearize(lba_shard* s, double* chi2_local);                 /* errors + build system (once per outer iteration) */
+int lba_shard_reduce(lba_shard* s, double lambda);                         /* partial Schur complement into the reduce buffer */
+int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double* scale_local);  /* solve + back-subst + trial update */
+int lba_shard_accept(lba_shard* s, int accept);                            /* discardTop() / pop() */
+int lba_shard_download(lba_shard* s, double* pose_q, double* pose_t, double* points, double* chi2_per_edge, uint8_t* depth_positive);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBSLAM3_HIP_H */

@@ -1,0 +1,439 @@
+"""ctypes mirror of include/orbslam3_hip.h.  Names, argument meaning and error behaviour follow the C ABI,
+which in turn follows the reference's ORBextractor / ORBmatcher / Optimizer signatures."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG_DIR, "liborbslam3_hip.so")
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                     ("octave", "i4"), ("class_id", "i4")])
+assert KP_DTYPE.itemsize == 28
+
+ORBX_OK, ORBX_ERR_EMPTY, ORBX_ERR_CAPACITY, ORBX_ERR_ARG, ORBX_ERR_NO_DEVICE, ORBX_ERR_HIP, ORBX_ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbslam3_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class FeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("offset", C.c_void_p), ("feat", C.c_void_p)]
+
+
+class BowPair(C.Structure):
+    _fields_ = [("desc_kf", C.c_void_p), ("n_kf", C.c_int32), ("valid_kf", C.c_void_p), ("angle_kf", C.c_void_p), ("fv_kf", FeatVec),
+                ("desc_f", C.c_void_p), ("n_f", C.c_int32), ("angle_f", C.c_void_p), ("fv_f", FeatVec),
+                ("match_f2kf", C.c_void_p), ("n_matches", C.c_int32)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p),
+                ("desc", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("scale_factors", C.c_void_p), ("n_levels", C.c_int32)]
+
+
+class LbaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("pose_q", C.c_void_p), ("pose_t", C.c_void_p), ("pose_fixed", C.c_void_p),
+                ("n_points", C.c_int32), ("points", C.c_void_p),
+                ("n_edges", C.c_int32), ("edge_point", C.c_void_p), ("edge_pose", C.c_void_p), ("edge_obs", C.c_void_p),
+                ("edge_inv_sigma2", C.c_void_p), ("edge_stereo", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+class LbaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("stop_reason", C.c_int32),
+                ("lambda_", C.c_double), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("chi2_trace", C.c_double * 16)]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("%s not found: build it with __graft_entry__.build() (hipcc, gfx950). "
+                          "There is no CPU fallback." % _LIB_PATH)
+    return C.CDLL(_LIB_PATH)
+
+
+lib = _load()
+lib.orbx_last_error.restype = C.c_char_p
+lib.orbx_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+lib.orbx_destroy.argtypes = [C.c_void_p]
+lib.orbx_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.orbx_extract_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+lib.orbx_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.orbx_max_keypoints.argtypes = [C.c_void_p]
+lib.orbx_levels.argtypes = [C.c_void_p]
+lib.orbx_scale_factor.argtypes = [C.c_void_p]
+lib.orbx_scale_factor.restype = C.c_float
+lib.orbx_scale_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+lib.orbx_features_per_level.argtypes = [C.c_void_p, C.c_void_p]
+lib.orbx_pyramid_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.orbx_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+lib.orbx_debug_blurred_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+lib.orbx_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+lib.orbx_debug_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+lib.orbx_debug_introsort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.orbx_debug_fast_atan2.restype = C.c_float
+lib.orbx_debug_fast_atan2.argtypes = [C.c_float, C.c_float]
+lib.orbx_debug_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(code):
+    if code < 0:
+        raise OrbxError(code, (lib.orbx_last_error() or b"").decode())
+    return code
+
+
+def device_count():
+    return lib.orbx_device_count()
+
+
+class Extractor:
+    """ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:44-109)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, device=0):
+        h = C.c_void_p()
+        _check(lib.orbx_create(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, device, C.byref(h)))
+        self._h = h
+        self.nlevels = nlevels
+        self.max_keypoints = lib.orbx_max_keypoints(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.orbx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # getters (include/ORBextractor.h:61-81)
+    def GetLevels(self):
+        return lib.orbx_levels(self._h)
+
+    def GetScaleFactor(self):
+        return lib.orbx_scale_factor(self._h)
+
+    def _tables(self):
+        n = self.nlevels
+        t = [np.zeros(n, np.float32) for _ in range(4)]
+        _check(lib.orbx_scale_tables(self._h, *[_p(a) for a in t]))
+        return t
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels, np.int32)
+        _check(lib.orbx_features_per_level(self._h, _p(out)))
+        return out
+
+    def __call__(self, image, lapping_area=(0, 1000)):
+        """operator(): returns (monoIndex, keypoints[KP_DTYPE], descriptors[n,32]); monoIndex == -1 for an empty image."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2       # assert(image.type() == CV_8UC1)
+        img = image if image.strides[1] == 1 else np.ascontiguousarray(image)
+        h, w = img.shape
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int(), C.c_int()
+        _check(lib.orbx_extract(self._h, _p(img), w, h, img.strides[0], lapping_area[0], lapping_area[1],
+                                _p(kps), _p(desc), cap, C.byref(n), C.byref(mono)))
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images, lapping_area=(0, 1000)):
+        """images: uint8 array [B, H, W] (host).  Returns (mono[B], n[B], kps[B,cap], desc[B,cap,32])."""
+        imgs = np.ascontiguousarray(images)
+        B, h, w = imgs.shape
+        cap = self.max_keypoints
+        kps = np.zeros((B, cap), KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        mono = np.zeros(B, np.int32)
+        ptrs = (C.c_void_p * B)(*[imgs[b].ctypes.data for b in range(B)])
+        _check(lib.orbx_extract_batch(self._h, ptrs, B, w, h, imgs.strides[1], lapping_area[0], lapping_area[1],
+                                      _p(kps), _p(desc), cap, _p(n), _p(mono)))
+        return mono, n, kps, desc
+
+    def extract_batch_device(self, d_imgs_ptr, batch, w, h, row_stride, frame_stride, d_kps_ptr, d_desc_ptr, cap,
+                             d_n_ptr, d_mono_ptr, d_status_ptr, lapping_area=(0, 1000), stream=None):
+        """Raw device-pointer variant (pointers as ints, e.g. torch.Tensor.data_ptr()); asynchronous."""
+        _check(lib.orbx_extract_batch_device(self._h, d_imgs_ptr, batch, w, h, row_stride, frame_stride,
+                                             lapping_area[0], lapping_area[1], d_kps_ptr, d_desc_ptr, cap,
+                                             d_n_ptr, d_mono_ptr, d_status_ptr, stream))
+
+    # mvImagePyramid replacement + stage introspection
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _check(lib.orbx_pyramid_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def pyramid_level(self, level, frame=0, border=0):
+        w, h = self.level_size(level)
+        out = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+        _check(lib.orbx_pyramid_level(self._h, frame, level, border, _p(out), out.strides[0]))
+        return out
+
+    def blurred_level(self, level, frame=0):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        _check(lib.orbx_debug_blurred_level(self._h, frame, level, _p(out), out.strides[0]))
+        return out
+
+    def candidates(self, level, frame=0, cap=200000):
+        out = np.zeros(cap, KP_DTYPE)
+        n = C.c_int()
+        _check(lib.orbx_debug_candidates(self._h, frame, level, _p(out), cap, C.byref(n)))
+        return out[:min(n.value, cap)].copy()
+
+    def level_keypoints(self, level, frame=0, cap=20000):
+        out = np.zeros(cap, KP_DTYPE)
+        n = C.c_int()
+        _check(lib.orbx_debug_level_keypoints(self._h, frame, level, _p(out), cap, C.byref(n)))
+        return out[:min(n.value, cap)].copy()
+
+
+def hamming(a, b):
+    """ORBmatcher::DescriptorDistance."""
+    lib.orbm_hamming.argtypes = [C.c_void_p, C.c_void_p]
+    return lib.orbm_hamming(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)))
+
+
+def _fv(fv):
+    nodes, offs, feat = [np.ascontiguousarray(a) for a in fv]
+    s = FeatVec(len(nodes), nodes.ctypes.data, offs.ctypes.data, feat.ctypes.data)
+    s._keep = (nodes, offs, feat)
+    return s
+
+
+class Matcher:
+    """ORB_SLAM3::ORBmatcher (reference include/ORBmatcher.h:40-106): ORBmatcher(nnratio=0.6, checkOri=true)."""
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, check_orientation=True, device=0):
+        self.nnratio = float(nnratio)
+        self.check_ori = bool(check_orientation)
+        lib.orbm_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.orbm_destroy.argtypes = [C.c_void_p]
+        lib.orbm_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
+                                           C.c_void_p, C.c_int, C.c_void_p, C.POINTER(FeatVec), C.c_float, C.c_int, C.c_void_p]
+        lib.orbm_search_by_bow_batch.argtypes = [C.c_void_p, C.POINTER(BowPair), C.c_int, C.c_float, C.c_int]
+        lib.orbm_search_by_bow_kfkf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
+                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
+                                                C.c_float, C.c_int, C.c_void_p]
+        lib.orbm_search_by_projection.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int] + [C.c_void_p] * 9 + \
+            [C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        lib.orbm_search_by_projection_last.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int] + [C.c_void_p] * 7 + \
+            [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        h = C.c_void_p()
+        _check(lib.orbm_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.orbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        return hamming(a, b)
+
+    def SearchByBoW(self, dKF, validKF, angKF, fvKF, dF, angF, fvF):
+        """SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&): returns (nmatches, match_f2kf[nF])."""
+        dKF, dF = np.ascontiguousarray(dKF), np.ascontiguousarray(dF)
+        match = np.full(len(dF), -1, np.int32)
+        a, b = _fv(fvKF), _fv(fvF)
+        n = _check(lib.orbm_search_by_bow(self._h, _p(dKF), len(dKF), _p(validKF), _p(angKF), C.byref(a),
+                                          _p(dF), len(dF), _p(angF), C.byref(b), self.nnratio, int(self.check_ori), _p(match)))
+        return n, match
+
+    def SearchByBoW_batch(self, sets):
+        """sets: list of dicts as synth.make_match_set.  Returns list of (nmatches, match)."""
+        P = len(sets)
+        arr = (BowPair * P)()
+        keep = []
+        outs = []
+        for i, s in enumerate(sets):
+            dKF, dF = np.ascontiguousarray(s["dKF"]), np.ascontiguousarray(s["dF"])
+            a, b = _fv(s["fvKF"]), _fv(s["fvF"])
+            m = np.full(len(dF), -1, np.int32)
+            keep.append((dKF, dF, a, b, m))
+            outs.append(m)
+            arr[i] = BowPair(dKF.ctypes.data, len(dKF), s["validKF"].ctypes.data, s["angKF"].ctypes.data, a,
+                             dF.ctypes.data, len(dF), s["angF"].ctypes.data, b, m.ctypes.data, 0)
+        _check(lib.orbm_search_by_bow_batch(self._h, arr, P, self.nnratio, int(self.check_ori)))
+        return [(arr[i].n_matches, outs[i]) for i in range(P)]
+
+    def SearchByBoW_KFKF(self, d1, valid1, ang1, fv1, d2, valid2, ang2, fv2):
+        match = np.full(len(d1), -1, np.int32)
+        a, b = _fv(fv1), _fv(fv2)
+        n = _check(lib.orbm_search_by_bow_kfkf(self._h, _p(d1), len(d1), _p(valid1), _p(ang1), C.byref(a),
+                                               _p(d2), len(d2), _p(valid2), _p(ang2), C.byref(b),
+                                               self.nnratio, int(self.check_ori), _p(match)))
+        return n, match
+
+    @staticmethod
+    def _frame(g, desc, scale_factors, angle=None):
+        f = Frame(len(g["x"]), g["x"].ctypes.data, g["y"].ctypes.data, g["octave"].ctypes.data,
+                  angle.ctypes.data if angle is not None else None, desc.ctypes.data,
+                  g["min_x"], g["min_y"], g["max_x"], g["max_y"], g.get("cols", 64), g.get("rows", 48),
+                  scale_factors.ctypes.data, len(scale_factors))
+        return f
+
+    def SearchByProjection(self, g, dF, scale_factors, mp, th, assign, occupied, far_points=False, th_far=0.0):
+        """SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)."""
+        f = self._frame(g, dF, scale_factors)
+        return _check(lib.orbm_search_by_projection(
+            self._h, C.byref(f), len(mp["u"]), _p(mp["in_view"]), _p(mp["u"]), _p(mp["v"]), _p(mp["level"]),
+            _p(mp["view_cos"]), _p(mp["depth"]), _p(mp["desc"]), _p(mp["has_obs"]), _p(mp["bad"]),
+            th, int(far_points), th_far, self.nnratio, _p(assign), _p(occupied)))
+
+    def SearchByProjection_last(self, g, dF, angF, scale_factors, last, th, assign, occupied):
+        """SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono=true)."""
+        f = self._frame(g, dF, scale_factors, angF)
+        return _check(lib.orbm_search_by_projection_last(
+            self._h, C.byref(f), len(last["u"]), _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last["octave"]),
+            _p(last["angle"]), _p(last["desc"]), _p(last["has_obs"]), th, int(self.check_ori), _p(assign), _p(occupied)))
+
+
+def _lba_problem(w):
+    keep = {k: np.ascontiguousarray(w[k]) for k in ("pose_q", "pose_t", "pose_fixed", "points", "edge_point",
+                                                      "edge_pose", "edge_obs", "edge_inv_sigma2", "edge_stereo")}
+    pr = LbaProblem(len(keep["pose_q"]), keep["pose_q"].ctypes.data, keep["pose_t"].ctypes.data, keep["pose_fixed"].ctypes.data,
+                    len(keep["points"]), keep["points"].ctypes.data, len(keep["edge_point"]), keep["edge_point"].ctypes.data,
+                    keep["edge_pose"].ctypes.data, keep["edge_obs"].ctypes.data, keep["edge_inv_sigma2"].ctypes.data,
+                    keep["edge_stereo"].ctypes.data, w["fx"], w["fy"], w["cx"], w["cy"], w["bf"], w["huber_mono"], w["huber_stereo"])
+    pr._keep = keep
+    return pr
+
+
+def _stats_dict(st):
+    return dict(iterations=st.iterations, trials=st.trials, stop_reason=st.stop_reason, lambda_=st.lambda_,
+                chi2_initial=st.chi2_initial, chi2_final=st.chi2_final, chi2_trace=list(st.chi2_trace))
+
+
+class LbaSolver:
+    """Numerical core of Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:1116-1498)."""
+
+    def __init__(self, device=0):
+        lib.lba_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.lba_destroy.argtypes = [C.c_void_p]
+        lib.lba_solve.argtypes = [C.c_void_p, C.POINTER(LbaProblem), C.c_void_p, C.c_int, C.c_double,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LbaStats)]
+        h = C.c_void_p()
+        _check(lib.lba_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.lba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, w, max_iters=10, lambda_init=0.0, stop_flag=None):
+        pr = _lba_problem(w)
+        k = pr._keep
+        q = np.zeros_like(k["pose_q"]); t = np.zeros_like(k["pose_t"]); pts = np.zeros_like(k["points"])
+        chi2 = np.zeros(len(k["edge_point"])); dpos = np.zeros(len(k["edge_point"]), np.uint8)
+        st = LbaStats()
+        _check(lib.lba_solve(self._h, C.byref(pr), _p(stop_flag), max_iters, lambda_init,
+                             _p(q), _p(t), _p(pts), _p(chi2), _p(dpos), C.byref(st)))
+        return dict(pose_q=q, pose_t=t, points=pts, chi2=chi2, depth_positive=dpos, stats=_stats_dict(st))
+
+
+class LbaShard:
+    """One rank's share of a landmark-sharded global BA; see INTEGRATION.md."""
+
+    def __init__(self, w, device=0):
+        lib.lba_shard_create.argtypes = [C.c_int, C.POINTER(LbaProblem), C.POINTER(C.c_void_p)]
+        lib.lba_shard_destroy.argtypes = [C.c_void_p]
+        lib.lba_shard_reduce_len.argtypes = [C.c_void_p]
+        lib.lba_shard_reduce_len.restype = C.c_int64
+        lib.lba_shard_reduce_buffer.argtypes = [C.c_void_p]
+        lib.lba_shard_reduce_buffer.restype = C.c_void_p
+        lib.lba_shard_linearize.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.lba_shard_reduce.argtypes = [C.c_void_p, C.c_double]
+        lib.lba_shard_finish.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.lba_shard_accept.argtypes = [C.c_void_p, C.c_int]
+        lib.lba_shard_download.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        self._pr = _lba_problem(w)
+        h = C.c_void_p()
+        _check(lib.lba_shard_create(device, C.byref(self._pr), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.lba_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reduce_len(self):
+        return lib.lba_shard_reduce_len(self._h)
+
+    def reduce_buffer_ptr(self):
+        return lib.lba_shard_reduce_buffer(self._h)
+
+    def linearize(self):
+        chi = C.c_double()
+        _check(lib.lba_shard_linearize(self._h, C.byref(chi)))
+        return chi.value
+
+    def reduce(self, lam):
+        _check(lib.lba_shard_reduce(self._h, lam))
+
+    def finish(self, lam):
+        chi, sc = C.c_double(), C.c_double()
+        r = lib.lba_shard_finish(self._h, lam, C.byref(chi), C.byref(sc))
+        _check(min(r, 0))
+        return r, chi.value, sc.value
+
+    def accept(self, ok):
+        _check(lib.lba_shard_accept(self._h, int(ok)))
+
+    def download(self):
+        k = self._pr._keep
+        q = np.zeros_like(k["pose_q"]); t = np.zeros_like(k["pose_t"]); pts = np.zeros_like(k["points"])
+        chi2 = np.zeros(len(k["edge_point"])); dpos = np.zeros(len(k["edge_point"]), np.uint8)
+        _check(lib.lba_shard_download(self._h, _p(q), _p(t), _p(pts), _p(chi2), _p(dpos)))
+        return dict(pose_q=q, pose_t=t, points=pts, chi2=chi2, depth_positive=dpos)

@@ -1,0 +1,588 @@
+// orbx_extractor.hip -- host driver + C ABI of the gfx950 ORB extractor.
+//
+// Mirrors ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:44-109, src/ORBextractor.cc):
+// constructor tables on the host (E0), then one fixed sequence of kernel launches per batch of
+// frames (orbx_kernels.hip).  No CPU compute path exists: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "orbx_kernels.hip"
+
+namespace orbx {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define ORBX_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(ORBX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int cv_round_host(double v) { return (int)std::nearbyint(v); }
+static inline int cv_floor_host(double v) { int i = (int)v; return i - (i > v); }
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// getGaussianKernelFixedPoint_ED (OpenCV 4.x): Q8.8 taps, error diffusion, centre = 256 - 2*sum(others)
+static void gauss_taps_q8(int n, double sigma, int* taps)
+{
+    std::vector<double> k(n);
+    const double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; i++) { const double x = i - (n - 1) * 0.5; k[i] = std::exp(scale2x * x * x); sum += k[i]; }
+    sum = 1. / sum;
+    double err = 0;
+    long long acc = 0;
+    for (int i = 0; i < n / 2; i++) {
+        const double adj = k[i] * sum * 256.0 + err;
+        const long long v0 = cv_round_host(adj);
+        err = adj - (double)v0;
+        taps[i] = taps[n - 1 - i] = (int)v0;
+        acc += v0;
+    }
+    taps[n / 2] = (int)(256 - 2 * acc);
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count)
+    {
+        if (count <= n) return ORBX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        ORBX_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return ORBX_OK;
+    }
+    int upload(const std::vector<T>& v)
+    {
+        int r = ensure(v.size() ? v.size() : 1);
+        if (r) return r;
+        if (!v.empty()) ORBX_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return ORBX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace orbx
+
+using namespace orbx;
+
+struct orbx_extractor {
+    int device = 0;
+    int nfeatures = 0, nlevels = 0, ini_th = 0, min_th = 0;
+    float scale_factor_f = 0;
+    double scale_factor_d = 0;           // the reference member is a double (include/ORBextractor.h:92)
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> nfeat;
+    int taps[7];
+    int max_kp = 0;
+
+    // geometry for the current image size
+    int geo_w = 0, geo_h = 0;
+    std::vector<LevelDesc> levels;
+    std::vector<CellDesc> cells;
+    std::vector<TileDesc> tiles;
+    size_t pyr_frame_bytes = 0;
+    int cand_frame_entries = 0, sel_frame_entries = 0;
+    int tile_pitch = 0, tile_rows = 0, m_pitch = 0, m_rows = 0;
+    size_t fast_lds = 0, oct_lds = 0;
+    int oct_pool = 0, oct_lds_keys = 0;
+
+    DevBuf<LevelDesc> d_levels;
+    DevBuf<CellDesc> d_cells;
+    DevBuf<TileDesc> d_tiles;
+    std::vector<DevBuf<int> > d_xofs, d_yofs;
+    std::vector<DevBuf<short> > d_ialpha, d_ibeta;
+
+    // per-batch scratch
+    int batch_cap = 0, last_batch = 0;
+    DevBuf<uint8_t> d_pyr, d_blur;
+    DevBuf<uint32_t> d_cand, d_scratch, d_sel;
+    DevBuf<int> d_cell_count, d_sel_count, d_kp_dst;
+    DevBuf<OrbxKeyPoint> d_lvl_kps;
+    // staging for the host-pointer API
+    DevBuf<OrbxKeyPoint> d_kps;
+    DevBuf<uint8_t> d_desc;
+    DevBuf<int> d_n, d_mono, d_status;
+    int out_cap = 0;
+    hipStream_t stream = nullptr;
+
+    int setup_geometry(int w, int h);
+    int ensure_batch(int batch);
+    int enqueue(const uint8_t* d_imgs, bool level0_ready, int batch, int row_stride, size_t frame_stride,
+                int lap0, int lap1, OrbxKeyPoint* o_kps, uint8_t* o_desc, int cap, int* o_n, int* o_mono, int* o_status,
+                hipStream_t st);
+};
+
+// E0: constructor tables (reference src/ORBextractor.cc:409-445)
+static void build_tables(orbx_extractor* e)
+{
+    const int nl = e->nlevels;
+    e->scale.assign(nl, 1.0f); e->sigma2.assign(nl, 1.0f); e->inv_scale.resize(nl); e->inv_sigma2.resize(nl);
+    for (int i = 1; i < nl; i++) {
+        e->scale[i] = (float)(e->scale[i - 1] * e->scale_factor_d);
+        e->sigma2[i] = e->scale[i] * e->scale[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        e->inv_scale[i] = 1.0f / e->scale[i];
+        e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+    }
+    e->nfeat.resize(nl);
+    const float factor = (float)(1.0f / e->scale_factor_d);
+    float per_scale = e->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        e->nfeat[l] = (int)std::nearbyintf(per_scale);
+        sum += e->nfeat[l];
+        per_scale *= factor;
+    }
+    e->nfeat[nl - 1] = std::max(e->nfeatures - sum, 0);
+    e->max_kp = 0;
+    for (int l = 0; l < nl; l++) e->max_kp += e->nfeat[l] + 3;
+    gauss_taps_q8(7, 2.0, e->taps);
+}
+
+int orbx_extractor::setup_geometry(int w, int h)
+{
+    if (w == geo_w && h == geo_h) return ORBX_OK;
+    levels.assign(nlevels, LevelDesc());
+    cells.clear();
+    tiles.clear();
+    size_t off = 0;
+    int cand_off = 0, sel_off = 0, max_tw = 0, max_th = 0, max_nfeat = 0;
+    d_xofs.resize(nlevels); d_yofs.resize(nlevels); d_ialpha.resize(nlevels); d_ibeta.resize(nlevels);
+    for (int l = 0; l < nlevels; l++) {
+        LevelDesc& L = levels[l];
+        L.w = (int)std::nearbyintf((float)w * inv_scale[l]);      // ComputePyramid :1175
+        L.h = (int)std::nearbyintf((float)h * inv_scale[l]);
+        if (L.w < 1 || L.h < 1) return fail(ORBX_ERR_ARG, "pyramid level %d of a %dx%d image is empty", l, w, h);
+        if (L.w > 4096 + 32 || L.h > 4096 + 32) return fail(ORBX_ERR_ARG, "image %dx%d too large (keys are 12-bit)", w, h);
+        L.stride = round_up(L.w, 64);
+        L.off = (int64_t)off;
+        off += (size_t)L.stride * L.h;
+        off = (off + 255) & ~(size_t)255;
+        L.nfeat = nfeat[l];
+        L.scale = scale[l];
+        L.patch_size = (int)(kPatch * scale[l]);
+        L.sel_off = sel_off; L.sel_cap = nfeat[l] + 3;
+        sel_off += L.sel_cap;
+        max_nfeat = std::max(max_nfeat, nfeat[l]);
+        // FAST cells (ComputeKeyPointsOctTree :787-822)
+        L.cell_begin = (int)cells.size();
+        L.cand_off = cand_off;
+        const int minBX = kEdge - 3, minBY = minBX, maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+        const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+        const int nCols = (int)(width / 35.f), nRows = (int)(height / 35.f);
+        if (nCols > 0 && nRows > 0) {
+            const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+            for (int i = 0; i < nRows; i++) {
+                const float iniY = (float)(minBY + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= maxBY - 3) continue;
+                if (maxY > maxBY) maxY = (float)maxBY;
+                for (int j = 0; j < nCols; j++) {
+                    const float iniX = (float)(minBX + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBX - 6) continue;
+                    if (maxX > maxBX) maxX = (float)maxBX;
+                    CellDesc c;
+                    c.level = (int16_t)l;
+                    c.x0 = (int16_t)iniX; c.x1 = (int16_t)maxX; c.y0 = (int16_t)iniY; c.y1 = (int16_t)maxY;
+                    const int iw = c.x1 - c.x0 - 6, ih = c.y1 - c.y0 - 6;
+                    if (iw <= 0 || ih <= 0) continue;       // cv::FAST finds nothing in a sub-image thinner than 7 px
+                    c.slot_off = cand_off;
+                    c.slot_cap = ((iw + 1) / 2) * ((ih + 1) / 2);     // 3x3 NMS: no two 8-adjacent survivors
+                    cand_off += c.slot_cap;
+                    max_tw = std::max(max_tw, c.x1 - c.x0);
+                    max_th = std::max(max_th, c.y1 - c.y0);
+                    cells.push_back(c);
+                }
+            }
+        }
+        L.cell_count = (int)cells.size() - L.cell_begin;
+        L.cand_cap = cand_off - L.cand_off;
+        // blur tiles
+        for (int y0 = 0; y0 < L.h; y0 += kBlurTH)
+            for (int x0 = 0; x0 < L.w; x0 += kBlurTW) {
+                TileDesc t; t.level = (int16_t)l; t.x0 = (int16_t)x0; t.y0 = (int16_t)y0; t.pad = 0;
+                tiles.push_back(t);
+            }
+        // resize tables (cv::resize INTER_LINEAR 8UC1); level l is made from level l-1
+        if (l > 0) {
+            const LevelDesc& P = levels[l - 1];
+            const double scale_x = 1. / ((double)L.w / P.w), scale_y = 1. / ((double)L.h / P.h);
+            std::vector<int> xofs(L.w), yofs(L.h);
+            std::vector<short> ia((size_t)L.w * 2), ib((size_t)L.h * 2);
+            auto sat = [](float v) { int iv = (int)std::nearbyintf(v); return (short)std::min(std::max(iv, -32768), 32767); };
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor_host(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= P.w - 1) { fx = 0; sx = P.w - 1; }
+                xofs[dx] = sx;
+                ia[2 * dx] = sat((1.f - fx) * 2048);
+                ia[2 * dx + 1] = sat(fx * 2048);
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = cv_floor_host(fy);
+                fy -= sy;
+                yofs[dy] = sy;
+                ib[2 * dy] = sat((1.f - fy) * 2048);
+                ib[2 * dy + 1] = sat(fy * 2048);
+            }
+            int r;
+            if ((r = d_xofs[l].upload(xofs)) || (r = d_yofs[l].upload(yofs)) || (r = d_ialpha[l].upload(ia)) || (r = d_ibeta[l].upload(ib))) return r;
+        }
+    }
+    pyr_frame_bytes = off;
+    cand_frame_entries = std::max(cand_off, 1);
+    sel_frame_entries = sel_off;
+    // FAST kernel LDS
+    tile_pitch = round_up(max_tw + 3, 4) + 4;
+    tile_rows = std::max(max_th, 1);
+    m_pitch = round_up(std::max(max_tw - 6, 1) + 2, 4);
+    m_rows = std::max(max_th - 6, 1) + 2;
+    fast_lds = (size_t)tile_rows * tile_pitch + (size_t)m_rows * m_pitch + 64;
+    fast_lds = (fast_lds + 15) & ~(size_t)15;
+    if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST cell of %dx%d px does not fit LDS", max_tw, max_th);
+    // octree kernel LDS
+    oct_pool = max_nfeat + 16;
+    if (oct_pool > 16000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree", max_nfeat);
+    const char* env = getenv("ORBX_OCT_LDS_KEYS");
+    oct_lds_keys = env ? atoi(env) : 6144;
+    const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 16) + (size_t)((oct_pool + 15) & ~15);
+    if (node_bytes + 8 * (size_t)oct_lds_keys > 150 * 1024) oct_lds_keys = (int)((150 * 1024 - node_bytes) / 8);
+    if (oct_lds_keys < 0) oct_lds_keys = 0;
+    oct_lds = node_bytes + 8 * (size_t)oct_lds_keys + 16;
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds));
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_fast_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
+    int r;
+    if ((r = d_levels.upload(levels)) || (r = d_cells.upload(cells)) || (r = d_tiles.upload(tiles))) return r;
+    geo_w = w; geo_h = h;
+    batch_cap = 0;      // scratch must be re-sized for the new geometry
+    return ORBX_OK;
+}
+
+int orbx_extractor::ensure_batch(int batch)
+{
+    if (batch <= batch_cap) return ORBX_OK;
+    int r;
+    const size_t B = (size_t)batch;
+    if ((r = d_pyr.ensure(B * pyr_frame_bytes)) || (r = d_blur.ensure(B * pyr_frame_bytes)) ||
+        (r = d_cand.ensure(B * cand_frame_entries)) || (r = d_scratch.ensure(B * 2 * cand_frame_entries)) ||
+        (r = d_sel.ensure(B * sel_frame_entries)) || (r = d_cell_count.ensure(B * std::max<size_t>(cells.size(), 1))) ||
+        (r = d_sel_count.ensure(B * nlevels)) || (r = d_kp_dst.ensure(B * sel_frame_entries)) ||
+        (r = d_lvl_kps.ensure(B * sel_frame_entries)) || (r = d_n.ensure(B)) || (r = d_mono.ensure(B)) || (r = d_status.ensure(B)))
+        return r;
+    // the pyramid row padding is read by dword loads at row ends; keep it defined
+    ORBX_HIP(hipMemset(d_pyr.p, 0, B * pyr_frame_bytes));
+    ORBX_HIP(hipMemset(d_blur.p, 0, B * pyr_frame_bytes));
+    batch_cap = batch;
+    return ORBX_OK;
+}
+
+namespace orbx {
+// copies B frames of arbitrary row stride into pyramid level 0 (dword stores, byte loads)
+__global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__ src, int row_stride, size_t src_frame_stride,
+                                                     uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc L)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x4 >= L.w) return;
+    const uint8_t* s = src + (size_t)blockIdx.z * src_frame_stride + (size_t)y * row_stride + x4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (x4 + k < L.w) v |= (uint32_t)s[k] << (8 * k);
+    *(uint32_t*)(pyr + (size_t)blockIdx.z * frame_stride + L.off + (size_t)y * L.stride + x4) = v;
+}
+}  // namespace orbx
+
+int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch, int row_stride, size_t frame_stride,
+                            int lap0, int lap1, OrbxKeyPoint* o_kps, uint8_t* o_desc, int cap, int* o_n, int* o_mono, int* o_status,
+                            hipStream_t st)
+{
+    const int B = batch;
+    ORBX_HIP(hipMemsetAsync(o_status, 0, sizeof(int) * B, st));
+    if (!level0_ready) {
+        const LevelDesc& L0 = levels[0];
+        dim3 g((L0.w / 4 + 255) / 256, L0.h, B);
+        hipLaunchKernelGGL(k_copy_level0, g, dim3(256), 0, st, d_imgs, row_stride, frame_stride, d_pyr.p, pyr_frame_bytes, L0);
+    }
+    for (int l = 1; l < nlevels; l++) {
+        const LevelDesc& D = levels[l];
+        dim3 g(((D.w + 3) / 4 + 255) / 256, D.h, B);
+        hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, d_pyr.p, pyr_frame_bytes, levels[l - 1], D,
+                           d_xofs[l].p, d_ialpha[l].p, d_yofs[l].p, d_ibeta[l].p);
+    }
+    const int n_cells = (int)cells.size();
+    if (n_cells > 0)
+        hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
+                           ini_th, min_th, tile_pitch, tile_rows, m_pitch, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
+    hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), oct_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
+                       d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, oct_lds_keys,
+                       d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status);
+    hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,
+                       lap0, lap1, cap, d_kp_dst.p, sel_frame_entries, o_n, o_mono, o_status);
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)tiles.size(), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
+                       taps[0], taps[1], taps[2], taps[3]);
+    hipLaunchKernelGGL(k_orient_desc, dim3((sel_frame_entries + 3) / 4, B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
+                       d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p, d_kp_dst.p, sel_frame_entries,
+                       o_kps, o_desc, cap, d_lvl_kps.p);
+    ORBX_HIP(hipGetLastError());
+    last_batch = B;
+    return ORBX_OK;
+}
+
+extern "C" {
+
+const char* orbx_last_error(void) { return g_last_error.c_str(); }
+
+int orbx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device, orbx_extractor** out)
+{
+    if (!out) return fail(ORBX_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (nlevels < 1 || nlevels > kMaxLevels || nfeatures < 1 || !(scale_factor > 1.0f))
+        return fail(ORBX_ERR_ARG, "bad extractor parameters (nfeatures=%d scale=%f nlevels=%d)", nfeatures, scale_factor, nlevels);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ORBX_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(ORBX_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+    ORBX_HIP(hipSetDevice(device));
+    orbx_extractor* e = new orbx_extractor();
+    e->device = device;
+    e->nfeatures = nfeatures; e->nlevels = nlevels; e->ini_th = ini_th_fast; e->min_th = min_th_fast;
+    e->scale_factor_f = scale_factor; e->scale_factor_d = (double)scale_factor;
+    build_tables(e);
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(ORBX_ERR_HIP, "stream create failed"); }
+    *out = e;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_extractor* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    e->d_levels.release(); e->d_cells.release(); e->d_tiles.release();
+    for (auto& b : e->d_xofs) b.release();
+    for (auto& b : e->d_yofs) b.release();
+    for (auto& b : e->d_ialpha) b.release();
+    for (auto& b : e->d_ibeta) b.release();
+    e->d_pyr.release(); e->d_blur.release(); e->d_cand.release(); e->d_scratch.release(); e->d_sel.release();
+    e->d_cell_count.release(); e->d_sel_count.release(); e->d_kp_dst.release(); e->d_lvl_kps.release();
+    e->d_kps.release(); e->d_desc.release(); e->d_n.release(); e->d_mono.release(); e->d_status.release();
+    delete e;
+}
+
+int orbx_max_keypoints(const orbx_extractor* e) { return e ? e->max_kp : 0; }
+int orbx_levels(const orbx_extractor* e) { return e ? e->nlevels : 0; }
+float orbx_scale_factor(const orbx_extractor* e) { return e ? e->scale_factor_f : 0.f; }
+
+int orbx_scale_tables(const orbx_extractor* e, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2)
+{
+    if (!e) return fail(ORBX_ERR_ARG, "NULL handle");
+    for (int i = 0; i < e->nlevels; i++) {
+        if (scale) scale[i] = e->scale[i];
+        if (inv_scale) inv_scale[i] = e->inv_scale[i];
+        if (sigma2) sigma2[i] = e->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = e->inv_sigma2[i];
+    }
+    return ORBX_OK;
+}
+
+int orbx_features_per_level(const orbx_extractor* e, int* n_per_level)
+{
+    if (!e || !n_per_level) return fail(ORBX_ERR_ARG, "NULL argument");
+    for (int i = 0; i < e->nlevels; i++) n_per_level[i] = e->nfeat[i];
+    return ORBX_OK;
+}
+
+int orbx_extract_batch_device(orbx_extractor* e, const uint8_t* d_imgs, int batch, int width, int height,
+                              int row_stride, size_t frame_stride, int lap0, int lap1,
+                              OrbxKeyPoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n, int32_t* d_mono,
+                              int32_t* d_status, void* stream)
+{
+    if (!e || !d_imgs || !d_kps || !d_desc || !d_n || !d_mono || !d_status) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (batch < 1 || width < 1 || height < 1 || row_stride < width || cap < 1) return fail(ORBX_ERR_ARG, "bad batch/geometry");
+    ORBX_HIP(hipSetDevice(e->device));
+    int r;
+    if ((r = e->setup_geometry(width, height)) || (r = e->ensure_batch(batch))) return r;
+    return e->enqueue(d_imgs, false, batch, row_stride, frame_stride, lap0, lap1, d_kps, d_desc, cap, d_n, d_mono, d_status,
+                      (hipStream_t)stream);
+}
+
+int orbx_extract_batch(orbx_extractor* e, const uint8_t* const* imgs, int batch, int width, int height, int stride,
+                       int lap0, int lap1, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n, int* mono_index)
+{
+    if (!e || !imgs || !kps || !desc || !n || !mono_index) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (batch < 1 || cap < 1) return fail(ORBX_ERR_ARG, "bad batch/capacity");
+    if (width < 1 || height < 1) { for (int b = 0; b < batch; b++) { n[b] = 0; mono_index[b] = -1; } return ORBX_ERR_EMPTY; }
+    if (stride < width) return fail(ORBX_ERR_ARG, "stride < width");
+    ORBX_HIP(hipSetDevice(e->device));
+    int r;
+    if ((r = e->setup_geometry(width, height)) || (r = e->ensure_batch(batch))) return r;
+    const size_t B = (size_t)batch;
+    if ((r = e->d_kps.ensure(B * cap)) || (r = e->d_desc.ensure(B * cap * 32))) return r;
+    const LevelDesc& L0 = e->levels[0];
+    for (int b = 0; b < batch; b++) {
+        if (!imgs[b]) return fail(ORBX_ERR_ARG, "imgs[%d] is NULL", b);
+        ORBX_HIP(hipMemcpy2DAsync(e->d_pyr.p + b * e->pyr_frame_bytes + L0.off, L0.stride, imgs[b], stride, width, height,
+                                  hipMemcpyHostToDevice, e->stream));
+    }
+    if ((r = e->enqueue(nullptr, true, batch, 0, 0, lap0, lap1, e->d_kps.p, e->d_desc.p, cap, e->d_n.p, e->d_mono.p, e->d_status.p, e->stream)))
+        return r;
+    std::vector<int> st(batch);
+    ORBX_HIP(hipMemcpyAsync(n, e->d_n.p, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(mono_index, e->d_mono.p, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(st.data(), e->d_status.p, sizeof(int) * B, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(kps, e->d_kps.p, sizeof(OrbxKeyPoint) * B * cap, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipMemcpyAsync(desc, e->d_desc.p, B * cap * 32, hipMemcpyDeviceToHost, e->stream));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < batch; b++)
+        if (st[b] != ORBX_OK) return fail(st[b], "frame %d: device status %d (n=%d, cap=%d)", b, st[b], n[b], cap);
+    return ORBX_OK;
+}
+
+int orbx_extract(orbx_extractor* e, const uint8_t* img, int width, int height, int stride,
+                 int lap0, int lap1, OrbxKeyPoint* kps, uint8_t* desc, int cap, int* n, int* mono_index)
+{
+    if (!img || width < 1 || height < 1) {      // _image.empty() (:1090-1091)
+        if (n) *n = 0;
+        if (mono_index) *mono_index = -1;
+        return ORBX_ERR_EMPTY;
+    }
+    const uint8_t* imgs[1] = {img};
+    return orbx_extract_batch(e, imgs, 1, width, height, stride, lap0, lap1, kps, desc, cap, n, mono_index);
+}
+
+int orbx_pyramid_level_size(const orbx_extractor* e, int level, int* width, int* height)
+{
+    if (!e || level < 0 || level >= e->nlevels || e->geo_w == 0) return fail(ORBX_ERR_ARG, "no pyramid (level %d)", level);
+    if (width) *width = e->levels[level].w;
+    if (height) *height = e->levels[level].h;
+    return ORBX_OK;
+}
+
+static int download_level(orbx_extractor* e, const uint8_t* base, int frame, int level, int border, uint8_t* dst, int dst_stride)
+{
+    if (!e || !dst || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch || border < 0)
+        return fail(ORBX_ERR_ARG, "bad frame/level");
+    const LevelDesc& L = e->levels[level];
+    if (dst_stride < L.w + 2 * border) return fail(ORBX_ERR_ARG, "dst_stride too small");
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    ORBX_HIP(hipMemcpy2D(dst + (size_t)border * dst_stride + border, dst_stride, base + (size_t)frame * e->pyr_frame_bytes + L.off,
+                         L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+    if (border > 0) {       // copyMakeBorder(..., BORDER_REFLECT_101) (:1185,:1190)
+        auto refl = [](int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p; return p; };
+        for (int y = 0; y < L.h + 2 * border; y++) {
+            const int sy = refl(y - border, L.h) + border;
+            uint8_t* row = dst + (size_t)y * dst_stride;
+            const uint8_t* srow = dst + (size_t)sy * dst_stride;
+            if (sy != y) std::memcpy(row + border, srow + border, L.w);
+            for (int x = 0; x < border; x++) {
+                row[x] = row[border + refl(x - border, L.w)];
+                row[border + L.w + x] = row[border + refl(L.w + x, L.w)];
+            }
+        }
+    }
+    return ORBX_OK;
+}
+
+int orbx_pyramid_level(orbx_extractor* e, int frame, int level, int border, uint8_t* dst, int dst_stride)
+{
+    return download_level(e, e ? e->d_pyr.p : nullptr, frame, level, border, dst, dst_stride);
+}
+
+int orbx_debug_blurred_level(orbx_extractor* e, int frame, int level, uint8_t* dst, int dst_stride)
+{
+    return download_level(e, e ? e->d_blur.p : nullptr, frame, level, 0, dst, dst_stride);
+}
+
+int orbx_debug_candidates(orbx_extractor* e, int frame, int level, OrbxKeyPoint* out, int cap, int* n)
+{
+    if (!e || !out || !n || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch) return fail(ORBX_ERR_ARG, "bad frame/level");
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    const LevelDesc& L = e->levels[level];
+    std::vector<int> cnt(std::max(L.cell_count, 1));
+    std::vector<uint32_t> ent(std::max(L.cand_cap, 1));
+    if (L.cell_count > 0) {
+        ORBX_HIP(hipMemcpy(cnt.data(), e->d_cell_count.p + (size_t)frame * e->cells.size() + L.cell_begin, sizeof(int) * L.cell_count, hipMemcpyDeviceToHost));
+        ORBX_HIP(hipMemcpy(ent.data(), e->d_cand.p + (size_t)frame * e->cand_frame_entries + L.cand_off, sizeof(uint32_t) * L.cand_cap, hipMemcpyDeviceToHost));
+    }
+    int k = 0;
+    for (int c = 0; c < L.cell_count; c++) {
+        const CellDesc& cd = e->cells[L.cell_begin + c];
+        for (int i = 0; i < cnt[c]; i++, k++) {
+            if (k >= cap) continue;
+            const uint32_t en = ent[cd.slot_off - L.cand_off + i];
+            OrbxKeyPoint kp;
+            kp.x = (float)key_x(en); kp.y = (float)key_y(en); kp.size = 7.f; kp.angle = -1.f; kp.response = (float)key_resp(en);
+            kp.octave = 0; kp.class_id = -1;
+            out[k] = kp;
+        }
+    }
+    *n = k;
+    return ORBX_OK;
+}
+
+int orbx_debug_level_keypoints(orbx_extractor* e, int frame, int level, OrbxKeyPoint* out, int cap, int* n)
+{
+    if (!e || !out || !n || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch) return fail(ORBX_ERR_ARG, "bad frame/level");
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->stream));
+    const LevelDesc& L = e->levels[level];
+    int cnt = 0;
+    ORBX_HIP(hipMemcpy(&cnt, e->d_sel_count.p + (size_t)frame * e->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n = cnt;
+    const int m = std::min(cnt, cap);
+    if (m > 0)
+        ORBX_HIP(hipMemcpy(out, e->d_lvl_kps.p + (size_t)frame * e->sel_frame_entries + L.sel_off, sizeof(OrbxKeyPoint) * m, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// host-side run of the device introsort restatement (pins it against std::sort in the CPU tests)
+int orbx_debug_introsort(int32_t* count, int32_t* ulx, int32_t* node, int n)
+{
+    if (n < 0) return ORBX_ERR_ARG;
+    std::vector<SortNode> v(n);
+    for (int i = 0; i < n; i++) { v[i].count = count[i]; v[i].ulx = ulx[i]; v[i].node = node[i]; }
+    introsort_nodes(v.data(), n);
+    for (int i = 0; i < n; i++) { count[i] = v[i].count; ulx[i] = v[i].ulx; node[i] = v[i].node; }
+    return ORBX_OK;
+}
+
+// host-side evaluation of the shared float helpers (pins them against the oracle in the CPU tests)
+float orbx_debug_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+void orbx_debug_sincos(float a, float* c, float* s) { sincos_f32(a, c, s); }
+
+}  // extern "C"

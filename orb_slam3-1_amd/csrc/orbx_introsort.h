@@ -1,0 +1,184 @@
+// orbx_introsort.h -- reproduces, element move for element move, what libstdc++'s std::sort does, so
+// that the device-side octree expands nodes in exactly the order the reference does.
+//
+// Why: DistributeOctTree sorts (keyCount, node*) pairs with std::sort and a comparator that ties on
+// (count, UL.x) (reference src/ORBextractor.cc:538-553,700).  std::sort is not stable, so the order of
+// tied elements -- and therefore which nodes get split before the feature budget is hit and the final
+// keypoint order -- is defined by the libstdc++ algorithm: introsort (median-of-3 quicksort with an
+// unguarded Hoare partition, depth limit 2*floor(log2 n), heapsort fallback) followed by a final
+// insertion sort with threshold 16.  This file restates that published algorithm (GCC bits/stl_algo.h,
+// bits/stl_heap.h) iteratively (explicit stack instead of recursion) for host and device.
+// tests/test_introsort.py checks it against std::sort itself on tie-heavy and adversarial inputs.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ORBX_SORT_HD __host__ __device__
+#else
+#define ORBX_SORT_HD
+#endif
+
+namespace orbx {
+
+struct SortNode {
+    int32_t count;   // pair.first  (number of keys in the node)
+    int32_t ulx;     // pair.second->UL.x
+    int32_t node;    // pair.second (node slot)
+};
+
+// compareNodes (reference src/ORBextractor.cc:538-553)
+ORBX_SORT_HD inline bool node_less(const SortNode& a, const SortNode& b)
+{
+    if (a.count < b.count) return true;
+    if (a.count > b.count) return false;
+    return a.ulx < b.ulx;
+}
+
+namespace detail {
+
+ORBX_SORT_HD inline void swap_nodes(SortNode* v, int a, int b)
+{
+    SortNode t = v[a]; v[a] = v[b]; v[b] = t;
+}
+
+ORBX_SORT_HD inline int floor_log2(int n)
+{
+    int r = 0;
+    while (n > 1) { n >>= 1; ++r; }
+    return r;
+}
+
+// __push_heap on v[first..], hole/top indices relative to first
+ORBX_SORT_HD inline void push_heap(SortNode* v, int first, int hole, int top, SortNode value)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top && node_less(v[first + parent], value)) {
+        v[first + hole] = v[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    v[first + hole] = value;
+}
+
+// __adjust_heap
+ORBX_SORT_HD inline void adjust_heap(SortNode* v, int first, int hole, int len, SortNode value)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (node_less(v[first + child], v[first + child - 1])) child--;
+        v[first + hole] = v[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        v[first + hole] = v[first + child - 1];
+        hole = child - 1;
+    }
+    push_heap(v, first, hole, top, value);
+}
+
+// __partial_sort(first, last, last) == make_heap + sort_heap on [first, last)
+ORBX_SORT_HD inline void heap_sort(SortNode* v, int first, int last)
+{
+    const int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            SortNode value = v[first + parent];
+            adjust_heap(v, first, parent, len, value);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    while (last - first > 1) {
+        --last;
+        SortNode value = v[last];
+        v[last] = v[first];
+        adjust_heap(v, first, 0, last - first, value);
+    }
+}
+
+// __unguarded_linear_insert
+ORBX_SORT_HD inline void unguarded_linear_insert(SortNode* v, int last)
+{
+    SortNode val = v[last];
+    int next = last - 1;
+    while (node_less(val, v[next])) {
+        v[last] = v[next];
+        last = next;
+        --next;
+    }
+    v[last] = val;
+}
+
+// __insertion_sort
+ORBX_SORT_HD inline void insertion_sort(SortNode* v, int first, int last)
+{
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (node_less(v[i], v[first])) {
+            SortNode val = v[i];
+            for (int k = i; k > first; --k) v[k] = v[k - 1];
+            v[first] = val;
+        } else {
+            unguarded_linear_insert(v, i);
+        }
+    }
+}
+
+}  // namespace detail
+
+// std::sort(v, v+n, compareNodes)
+ORBX_SORT_HD inline void introsort_nodes(SortNode* v, int n)
+{
+    using namespace detail;
+    if (n <= 0) return;
+    // __introsort_loop with an explicit stack of (first, last, depth) for the recursive right halves
+    int stack_first[64], stack_last[64], stack_depth[64];
+    int sp = 0;
+    stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = floor_log2(n) * 2; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+        // the recursion visits the RIGHT part first (call), then loops on the left part; the two parts are
+        // disjoint so the visiting order does not change the result -- process left now, push right.
+        while (last - first > 16) {
+            if (depth == 0) { heap_sort(v, first, last); break; }
+            --depth;
+            // __unguarded_partition_pivot
+            const int mid = first + (last - first) / 2;
+            const int a = first + 1, b = mid, c = last - 1;
+            if (node_less(v[a], v[b])) {
+                if (node_less(v[b], v[c])) swap_nodes(v, first, b);
+                else if (node_less(v[a], v[c])) swap_nodes(v, first, c);
+                else swap_nodes(v, first, a);
+            } else if (node_less(v[a], v[c])) swap_nodes(v, first, a);
+            else if (node_less(v[b], v[c])) swap_nodes(v, first, c);
+            else swap_nodes(v, first, b);
+            int lo = first + 1, hi = last;
+            while (true) {
+                while (node_less(v[lo], v[first])) ++lo;
+                --hi;
+                while (node_less(v[first], v[hi])) --hi;
+                if (!(lo < hi)) break;
+                swap_nodes(v, lo, hi);
+                ++lo;
+            }
+            const int cut = lo;
+            if (sp < 64) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
+            last = cut;
+        }
+    }
+    // __final_insertion_sort
+    if (n > 16) {
+        insertion_sort(v, 0, 16);
+        for (int i = 16; i != n; ++i) unguarded_linear_insert(v, i);
+    } else {
+        insertion_sort(v, 0, n);
+    }
+}
+
+}  // namespace orbx

@@ -1,0 +1,633 @@
+// orbx_kernels.hip -- gfx950 kernels of the ORB extractor (reference src/ORBextractor.cc).
+//
+// Pipeline per batch of B frames (all launches cover the whole batch; blockIdx.y / .z = frame):
+//   k_resize        level l-1 -> l, fixed-point bilinear            (E1, ComputePyramid :1170-1195)
+//   k_fast_cells    FAST-9/16 score + per-cell NMS / threshold fallback / ordered compaction
+//                                                                    (E2, ComputeKeyPointsOctTree :787-872)
+//   k_octree        quadtree keypoint selection, one wave per (frame, level)
+//                                                                    (E3, DistributeOctTree :555-779)
+//   k_index         output slot of every keypoint (lapping-area split) (E8, operator() :1140-1167)
+//   k_blur          7x7 sigma-2 Gaussian, Q8.8 fixed point             (E6, :1132-1133)
+//   k_orient_desc   intensity-centroid angle + steered BRIEF-256       (E5 :76-103, E7 :107-146)
+//
+// Integer stages are exact by construction; float stages use orbx_math.h (no FMA, no libm).
+// HBM layout: one pyramid buffer per frame, levels back to back, row stride rounded up to 64 B so that
+// every row starts on a 64-B boundary (coalesced dword loads); blurred pyramid has the same layout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orbx_device.h"
+#include "orbx_introsort.h"
+#include "orbx_math.h"
+
+namespace orbx {
+
+__device__ const signed char d_pattern[1024] = {
+#include "orb_pattern_31.inc"
+};
+
+// umax of the radius-15 disc (reference :453-468); fixed because HALF_PATCH_SIZE is a constant.
+__device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// ------------------------------------------------------------------------------------------------
+// E1: bilinear resize, OpenCV fixed-point scheme.  One thread -> 4 horizontally adjacent output
+// pixels (one aligned dword store).  Tables (xofs, ialpha, yofs, ibeta) are built on the host.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t frame_stride,
+                                                LevelDesc src, LevelDesc dst,
+                                                const int* __restrict__ xofs, const short* __restrict__ ialpha,
+                                                const int* __restrict__ yofs, const short* __restrict__ ibeta)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int dy = blockIdx.y;
+    if (x4 >= dst.w) return;
+    const uint8_t* sbase = pyr + (size_t)blockIdx.z * frame_stride + src.off;
+    uint8_t* dbase = pyr + (size_t)blockIdx.z * frame_stride + dst.off;
+    int sy0 = yofs[dy], sy1 = sy0 + 1;
+    sy0 = min(max(sy0, 0), src.h - 1);
+    sy1 = min(max(sy1, 0), src.h - 1);
+    const uint8_t* S0 = sbase + (size_t)sy0 * src.stride;
+    const uint8_t* S1 = sbase + (size_t)sy1 * src.stride;
+    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = x4 + k;
+        if (dx < dst.w) {
+            const int sx = xofs[dx];
+            const int sx1 = min(sx + 1, src.w - 1);
+            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (uint32_t)v << (8 * k);
+        }
+    }
+    *(uint32_t*)(dbase + (size_t)dy * dst.stride + x4) = packed;    // stride is a multiple of 64: in-row padding exists
+}
+
+// ------------------------------------------------------------------------------------------------
+// E2: FAST-9/16.  M(p) = max over the 16 arcs of 9 contiguous ring pixels of min(+-(v - ring)).
+// OpenCV's corner test at threshold t is  M > t  and its score (response) is  M - 1  (SURVEY App. A.1).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_m(const uint8_t* __restrict__ t, int pitch)
+{
+    // t points at the pixel inside the LDS tile
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * pitch];       d[1] = v - t[3 * pitch + 1];   d[2] = v - t[2 * pitch + 2];   d[3] = v - t[pitch + 3];
+    d[4] = v - t[3];               d[5] = v - t[-pitch + 3];      d[6] = v - t[-2 * pitch + 2];  d[7] = v - t[-3 * pitch + 1];
+    d[8] = v - t[-3 * pitch];      d[9] = v - t[-3 * pitch - 1];  d[10] = v - t[-2 * pitch - 2]; d[11] = v - t[-pitch - 3];
+    d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int best_dark = -256, best_bright = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // min of d[k..k+8]
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);   // max of d[k..k+8]
+        best_dark = max(best_dark, lo9);
+        best_bright = min(best_bright, hi9);
+    }
+    const int m = max(best_dark, -best_bright);
+    return max(m, 0);
+}
+
+// One 256-thread workgroup per FAST cell.  LDS: image tile (cell + 3 px ring halo), M tile with a
+// 1-px zero halo (NMS must treat everything outside the cell's own interior as 0), 2-bit pass flags.
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t frame_stride,
+                                                    const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
+                                                    int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch,
+                                                    uint32_t* __restrict__ cand, size_t cand_frame_stride,
+                                                    int* __restrict__ cell_count, int n_cells)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* tile = smem;                                   // tile_rows x tile_pitch
+    uint8_t* mt = smem + (size_t)tile_rows * tile_pitch;    // (ih+2) x m_pitch
+    __shared__ int s_wave_cnt[4];
+    __shared__ int s_ini_total;
+
+    const CellDesc c = cells[blockIdx.x];
+    const LevelDesc L = levels[c.level];
+    const int frame = blockIdx.y;
+    const uint8_t* img = pyr + (size_t)frame * frame_stride + L.off;
+    const int tid = threadIdx.x;
+    const int tw = c.x1 - c.x0, th = c.y1 - c.y0;       // tile (cell sub-image) size
+    const int iw = tw - 6, ih = th - 6;                 // interior (detection area)
+    const int xa = c.x0 & ~3;                           // dword-aligned tile origin
+    const int shift = c.x0 - xa;
+    const int row_dw = (shift + tw + 3) >> 2;           // dwords per tile row
+
+    if (tid == 0) s_ini_total = 0;
+    // load tile: coalesced dword loads, rows are 64-B aligned in HBM
+    for (int i = tid; i < th * row_dw; i += 256) {
+        const int r = i / row_dw, q = i - r * row_dw;
+        const uint32_t v = *(const uint32_t*)(img + (size_t)(c.y0 + r) * L.stride + xa + 4 * q);
+        *(uint32_t*)(tile + r * tile_pitch + 4 * q) = v;
+    }
+    // zero the M tile (halo included)
+    for (int i = tid; i < (ih + 2) * m_pitch / 4; i += 256) ((uint32_t*)mt)[i] = 0;
+    __syncthreads();
+    // scores
+    const int n_int = iw * ih;
+    for (int q = tid; q < n_int; q += 256) {
+        const int y = q / iw, x = q - y * iw;
+        const int m = fast_m(tile + (y + 3) * tile_pitch + shift + x + 3, tile_pitch);
+        mt[(y + 1) * m_pitch + x + 1] = (uint8_t)m;
+    }
+    __syncthreads();
+    // NMS at both thresholds -> flags (bit0: keypoint at iniTh, bit1: at minTh), kept in the (now free) image tile
+    uint8_t* flags = tile;
+    int local_ini = 0;
+    for (int q = tid; q < n_int; q += 256) {
+        const int y = q / iw, x = q - y * iw;
+        const uint8_t* p = mt + (y + 1) * m_pitch + x + 1;
+        const int m = p[0];
+        int f = 0;
+        if (m > min_th) {
+            const int n0 = p[-m_pitch - 1], n1 = p[-m_pitch], n2 = p[-m_pitch + 1], n3 = p[-1], n4 = p[1],
+                      n5 = p[m_pitch - 1], n6 = p[m_pitch], n7 = p[m_pitch + 1];
+            const int s = m - 1;
+#define ORBX_NB(n, t) (((n) > (t)) ? (n)-1 : 0)
+#define ORBX_PASS(t) (s > ORBX_NB(n0, t) && s > ORBX_NB(n1, t) && s > ORBX_NB(n2, t) && s > ORBX_NB(n3, t) && \
+                      s > ORBX_NB(n4, t) && s > ORBX_NB(n5, t) && s > ORBX_NB(n6, t) && s > ORBX_NB(n7, t))
+            if (m > ini_th && ORBX_PASS(ini_th)) f |= 1;
+            if (ORBX_PASS(min_th)) f |= 2;
+#undef ORBX_PASS
+#undef ORBX_NB
+        }
+        local_ini += f & 1;
+        flags[q] = (uint8_t)f;      // q < iw*ih <= tile bytes
+    }
+    // the flags alias the image tile: all score reads finished at the barrier above
+    if (local_ini) atomicAdd(&s_ini_total, local_ini);
+    __syncthreads();
+    const int bit = (s_ini_total > 0) ? 1 : 2;      // per-cell fallback to minThFAST only when iniThFAST found nothing (:843)
+    // ordered (row-major) compaction
+    uint32_t* out = cand + (size_t)frame * cand_frame_stride + c.slot_off;
+    const int lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int q0 = 0; q0 < n_int; q0 += 256) {
+        const int q = q0 + tid;
+        const bool on = (q < n_int) && (flags[q] & bit);
+        const unsigned long long mask = __ballot(on);
+        if (lane == 0) s_wave_cnt[wave] = __popcll(mask);
+        __syncthreads();
+        int wave_base = base;
+        for (int w = 0; w < wave; w++) wave_base += s_wave_cnt[w];
+        const int total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        if (on) {
+            const int rank = wave_base + __popcll(mask & ((1ull << lane) - 1ull));
+            const int y = q / iw, x = q - y * iw;
+            const int m = mt[(y + 1) * m_pitch + x + 1];
+            // coordinates relative to minBorder (= level coordinates - 16), as vToDistributeKeys holds them (:865-866)
+            const uint32_t px = (uint32_t)(c.x0 + 3 + x - 16), py = (uint32_t)(c.y0 + 3 + y - 16);
+            if (rank < c.slot_cap) out[rank] = pack_key(px, py, (uint32_t)(m - 1));
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) cell_count[(size_t)frame * n_cells + blockIdx.x] = min(base, c.slot_cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// E3: DistributeOctTree.  One wave per (frame, level).  The std::list of nodes is an index-linked list
+// in LDS; a node's keys are a contiguous, order-preserving segment of a ping-pong key array (LDS when
+// the level's candidates fit, HBM scratch otherwise).  Node bookkeeping is wave-uniform scalar work;
+// the stable 4-way key partition of DivideNode is wave-parallel (ballot + prefix popcount).
+// ------------------------------------------------------------------------------------------------
+struct OctLds {
+    short* ulx; short* uly; short* brx; short* bry;
+    int* beg; int* cnt;
+    short* prev; short* next; short* freelist; short* order;
+    uint8_t* flg;           // bit0: bNoMore, bit1: keys live in buffer 1
+    SortNode* ex[2];
+};
+
+__global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
+                                               const uint32_t* __restrict__ cand, size_t cand_frame_stride,
+                                               const int* __restrict__ cell_count, int n_cells,
+                                               uint32_t* __restrict__ scratch, size_t scratch_frame_stride,
+                                               int pool, int lds_keys_cap,
+                                               uint32_t* __restrict__ sel, int sel_frame_stride,
+                                               int* __restrict__ sel_count, int n_levels, int* __restrict__ status)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const int lane = threadIdx.x;
+    const LevelDesc L = levels[level];
+    const int N = L.nfeat;
+
+    // carve LDS
+    OctLds S;
+    {
+        uint8_t* p = smem;
+        S.ex[0] = (SortNode*)p; p += sizeof(SortNode) * pool;
+        S.ex[1] = (SortNode*)p; p += sizeof(SortNode) * pool;
+        S.beg = (int*)p; p += 4 * pool;
+        S.cnt = (int*)p; p += 4 * pool;
+        S.ulx = (short*)p; p += 2 * pool;  S.uly = (short*)p; p += 2 * pool;
+        S.brx = (short*)p; p += 2 * pool;  S.bry = (short*)p; p += 2 * pool;
+        S.prev = (short*)p; p += 2 * pool; S.next = (short*)p; p += 2 * pool;
+        S.freelist = (short*)p; p += 2 * pool; S.order = (short*)p; p += 2 * pool;
+        S.flg = p; p += (pool + 15) & ~15;
+        // keys follow
+        uint32_t* lds_keys = (uint32_t*)p;
+        // ---- gather the level's candidates in vToDistributeKeys order (cell row-major, row-major inside a cell)
+        const uint32_t* fc = cand + (size_t)frame * cand_frame_stride;
+        const int* cc = cell_count + (size_t)frame * n_cells;
+        int total = 0;
+        for (int c0 = 0; c0 < L.cell_count; c0 += 64) {
+            const int ci = c0 + lane;
+            int v = (ci < L.cell_count) ? cc[L.cell_begin + ci] : 0;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            total += v;
+        }
+        uint32_t* keys[2];
+        if (total <= lds_keys_cap) { keys[0] = lds_keys; keys[1] = lds_keys + lds_keys_cap; }
+        else {
+            uint32_t* g = scratch + (size_t)frame * scratch_frame_stride + 2 * (size_t)L.cand_off;
+            keys[0] = g; keys[1] = g + L.cand_cap;
+        }
+        int run = 0;
+        for (int ci = 0; ci < L.cell_count; ci++) {
+            const CellDesc c = cells[L.cell_begin + ci];
+            const int n = cc[L.cell_begin + ci];
+            for (int k = lane; k < n; k += 64) keys[0][run + k] = fc[c.slot_off + k];
+            run += n;
+        }
+        __syncthreads();
+
+        int* out_count = sel_count + (size_t)frame * n_levels + level;
+        uint32_t* out = sel + (size_t)frame * sel_frame_stride + L.sel_off;
+        const int width = (L.w - kEdge + 3) - (kEdge - 3), height = (L.h - kEdge + 3) - (kEdge - 3);
+        const int nIni = (height > 0) ? (int)roundf((float)width / (float)height) : 0;      // :559
+        if (total == 0 || nIni <= 0 || nIni > pool / 2) {
+            if (lane == 0) {
+                *out_count = 0;
+                if (total != 0 && nIni > pool / 2) atomicExch(status + frame, ORBX_ERR_INTERNAL);
+            }
+            return;
+        }
+
+        // ---- list primitives (wave-uniform: every lane runs them on identical values) ----
+        int head = -1, tail = -1, size = 0, nfree = pool;
+        for (int i = lane; i < pool; i += 64) S.freelist[i] = (short)(pool - 1 - i);
+        __syncthreads();
+        bool overflow = false;
+        auto alloc = [&]() -> int { if (nfree <= 0) { overflow = true; return 0; } return S.freelist[--nfree]; };
+        auto release = [&](int i) { S.freelist[nfree++] = (short)i; };
+        auto push_front = [&](int i) {
+            S.prev[i] = -1; S.next[i] = (short)head;
+            if (head >= 0) S.prev[head] = (short)i; else tail = i;
+            head = i; size++;
+        };
+        auto push_back = [&](int i) {
+            S.next[i] = -1; S.prev[i] = (short)tail;
+            if (tail >= 0) S.next[tail] = (short)i; else head = i;
+            tail = i; size++;
+        };
+        auto erase = [&](int i) {
+            const int p0 = S.prev[i], n0 = S.next[i];
+            if (p0 >= 0) S.next[p0] = (short)n0; else head = n0;
+            if (n0 >= 0) S.prev[n0] = (short)p0; else tail = p0;
+            size--;
+            release(i);
+        };
+
+        // ---- root nodes (:564-586): nIni vertical strips of width hX
+        const float hX = (float)width / (float)nIni;
+        {
+            // assign keys to strips, stable (keys are already in order; strips partition by x)
+            // count per strip with a wave pass, then scatter (nIni is 1 for 4:3 images: plain copy)
+            int strip_beg = 0;
+            for (int s = 0; s < nIni; s++) {
+                int cnt = 0;
+                for (int k0 = 0; k0 < total; k0 += 64) {
+                    const int k = k0 + lane;
+                    bool in = false;
+                    uint32_t e = 0;
+                    if (k < total) { e = keys[0][k]; in = ((int)((float)key_x(e) / hX) == s); }
+                    const unsigned long long m = __ballot(in);
+                    if (in) keys[1][strip_beg + cnt + __popcll(m & ((1ull << lane) - 1ull))] = e;
+                    cnt += __popcll(m);
+                }
+                if (cnt > 0) {      // empty roots are erased (:595-596)
+                    const int id = alloc();
+                    S.ulx[id] = (short)(int)(hX * (float)s);       S.uly[id] = 0;
+                    S.brx[id] = (short)(int)(hX * (float)(s + 1)); S.bry[id] = (short)height;
+                    S.beg[id] = strip_beg; S.cnt[id] = cnt;
+                    S.flg[id] = (uint8_t)(2 | (cnt == 1 ? 1 : 0));
+                    push_back(id);
+                }
+                strip_beg += cnt;
+            }
+            __syncthreads();
+        }
+
+        int cur_ex = 0, n_ex = 0;
+        // DivideNode + push children to the FRONT in order n1..n4 (:480-536, :639-676); then erase the parent
+        auto divide = [&](int id, int& n_to_expand) {
+            const int ulx = S.ulx[id], uly = S.uly[id], brx = S.brx[id], bry = S.bry[id];
+            const int beg = S.beg[id], cnt = S.cnt[id];
+            const int src = (S.flg[id] >> 1) & 1;
+            const int halfX = (brx - ulx + 1) >> 1;     // ceil(float(w)/2), w >= 0
+            const int halfY = (bry - uly + 1) >> 1;
+            const int midx = ulx + halfX, midy = uly + halfY;
+            const uint32_t* kin = keys[src];
+            uint32_t* kout = keys[src ^ 1];
+            // pass 1: child sizes
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int k0 = 0; k0 < cnt; k0 += 64) {
+                const int k = k0 + lane;
+                int cls = -1;
+                if (k < cnt) { const uint32_t e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
+                c0 += __popcll(__ballot(cls == 0)); c1 += __popcll(__ballot(cls == 1));
+                c2 += __popcll(__ballot(cls == 2)); c3 += __popcll(__ballot(cls == 3));
+            }
+            const int b0 = beg, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2;
+            // pass 2: stable scatter into the other buffer
+            int w0 = b0, w1 = b1, w2 = b2, w3 = b3;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            for (int k0 = 0; k0 < cnt; k0 += 64) {
+                const int k = k0 + lane;
+                int cls = -1;
+                uint32_t e = 0;
+                if (k < cnt) { e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
+                const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+                if (cls == 0) kout[w0 + __popcll(m0 & lt)] = e;
+                else if (cls == 1) kout[w1 + __popcll(m1 & lt)] = e;
+                else if (cls == 2) kout[w2 + __popcll(m2 & lt)] = e;
+                else if (cls == 3) kout[w3 + __popcll(m3 & lt)] = e;
+                w0 += __popcll(m0); w1 += __popcll(m1); w2 += __popcll(m2); w3 += __popcll(m3);
+            }
+            const int cb[4] = {b0, b1, b2, b3}, cn[4] = {c0, c1, c2, c3};
+            const int cux[4] = {ulx, midx, ulx, midx}, cuy[4] = {uly, uly, midy, midy};
+            const int cbx[4] = {midx, brx, midx, brx}, cby[4] = {midy, midy, bry, bry};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (cn[c] > 0) {
+                    const int ch = alloc();
+                    S.ulx[ch] = (short)cux[c]; S.uly[ch] = (short)cuy[c]; S.brx[ch] = (short)cbx[c]; S.bry[ch] = (short)cby[c];
+                    S.beg[ch] = cb[c]; S.cnt[ch] = cn[c];
+                    S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn[c] == 1 ? 1 : 0));
+                    push_front(ch);
+                    if (cn[c] > 1) {
+                        n_to_expand++;
+                        SortNode sn; sn.count = cn[c]; sn.ulx = cux[c]; sn.node = ch;
+                        if (n_ex < pool) S.ex[cur_ex][n_ex] = sn;
+                        n_ex++;
+                    }
+                }
+            }
+            erase(id);
+            __syncthreads();        // key scatter visible to every lane before the children are read
+        };
+
+        bool finish = false;
+        int guard = 0;
+        while (!finish && !overflow && guard++ < 64) {
+            const int prev_size = size;
+            int n_to_expand = 0;
+            n_ex = 0;
+            int cur = head;
+            while (cur >= 0 && !overflow) {
+                const int nxt = S.next[cur];
+                if (!(S.flg[cur] & 1)) divide(cur, n_to_expand);
+                cur = nxt;
+            }
+            if (size >= N || size == prev_size) {
+                finish = true;
+            } else if (size + n_to_expand * 3 > N) {
+                int guard2 = 0;
+                while (!finish && !overflow && guard2++ < 4096) {
+                    const int prev_size2 = size;
+                    const int n_prev = min(n_ex, pool);
+                    SortNode* pv = S.ex[cur_ex];
+                    if (lane == 0) introsort_nodes(pv, n_prev);     // std::sort(..., compareNodes) (:700)
+                    __syncthreads();
+                    cur_ex ^= 1;
+                    n_ex = 0;
+                    int dummy = 0;
+                    for (int j = n_prev - 1; j >= 0; j--) {
+                        divide(pv[j].node, dummy);
+                        if (size >= N || overflow) break;
+                    }
+                    if (size >= N || size == prev_size2) finish = true;
+                }
+            }
+        }
+        if (overflow || n_ex > pool) {
+            if (lane == 0) { atomicExch(status + frame, ORBX_ERR_INTERNAL); *out_count = 0; }
+            return;
+        }
+
+        // ---- final list order, then the best-response key of every node, first wins ties (:758-776)
+        {
+            int cur = head, k = 0;
+            while (cur >= 0 && k < pool) { S.order[k++] = (short)cur; cur = S.next[cur]; }
+        }
+        __syncthreads();
+        const int n_out = min(size, L.sel_cap);
+        for (int k = lane; k < n_out; k += 64) {
+            const int id = S.order[k];
+            const uint32_t* kb = keys[(S.flg[id] >> 1) & 1] + S.beg[id];
+            const int cnt = S.cnt[id];
+            uint32_t best = kb[0];
+            for (int i = 1; i < cnt; i++) {
+                const uint32_t e = kb[i];
+                if (key_resp(e) > key_resp(best)) best = e;
+            }
+            out[k] = best;
+        }
+        if (lane == 0) {
+            *out_count = n_out;
+            if (size > L.sel_cap) atomicExch(status + frame, ORBX_ERR_INTERNAL);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// E8 (index part): slot of every selected keypoint in the output arrays.  Level-major order; keypoints
+// whose scaled x lies in [lap0, lap1] are written from the back (stereoIndex--), the rest from the front.
+// One wave per frame.  meta[k] = (level << 24 | rank within level), dst[k] = output row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_index(const LevelDesc* __restrict__ levels, int n_levels,
+                                              const uint32_t* __restrict__ sel, int sel_frame_stride,
+                                              const int* __restrict__ sel_count, int lap0, int lap1, int cap,
+                                              int* __restrict__ kp_dst, int kp_frame_stride,
+                                              int* __restrict__ n_out, int* __restrict__ mono_out, int* __restrict__ status)
+{
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int* sc = sel_count + (size_t)frame * n_levels;
+    int total = 0;
+    for (int l = 0; l < n_levels; l++) total += sc[l];
+    int* dst = kp_dst + (size_t)frame * kp_frame_stride;
+    int mono = 0, stereo = total - 1;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int l = 0; l < n_levels; l++) {
+        const LevelDesc L = levels[l];
+        const uint32_t* s = sel + (size_t)frame * sel_frame_stride + L.sel_off;
+        const int n = sc[l];
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            bool valid = k < n, lap = false;
+            if (valid) {
+                float x = (float)(key_x(s[k]) + 16);
+                if (l != 0) x = x * L.scale;
+                lap = (x >= (float)lap0) && (x <= (float)lap1);
+            }
+            const unsigned long long ml = __ballot(valid && lap), mm = __ballot(valid && !lap);
+            if (valid) dst[L.sel_off + k] = lap ? stereo - __popcll(ml & lt) : mono + __popcll(mm & lt);
+            stereo -= __popcll(ml);
+            mono += __popcll(mm);
+        }
+    }
+    if (lane == 0) {
+        n_out[frame] = total;
+        mono_out[frame] = mono;
+        if (total > cap) atomicExch(status + frame, ORBX_ERR_CAPACITY);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// E6: GaussianBlur 7x7, sigma 2, BORDER_REFLECT_101 -- OpenCV 4.x fixed-point path:
+// horizontal u8 x Q8.8 taps -> Q8.8 (u16), vertical Q8.8 x Q8.8 -> Q16.16, (v + 0x8000) >> 16.
+// 256 threads per 64x32 output tile; the (64+6) x (32+6) source window is staged in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+constexpr int kBlurTW = 64, kBlurTH = 32;
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t frame_stride,
+                                              const LevelDesc* __restrict__ levels, const TileDesc* __restrict__ tiles,
+                                              int t0, int t1, int t2, int t3)
+{
+    __shared__ uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
+    __shared__ uint16_t s_h[(kBlurTH + 6) * kBlurTW];
+    const TileDesc T = tiles[blockIdx.x];
+    const LevelDesc L = levels[T.level];
+    const uint8_t* img = pyr + (size_t)blockIdx.y * frame_stride + L.off;
+    uint8_t* dst = blur + (size_t)blockIdx.y * frame_stride + L.off;
+    const int tid = threadIdx.x;
+    const int x0 = T.x0, y0 = T.y0;
+    constexpr int SP = kBlurTW + 8;
+    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
+        const int r = i / (kBlurTW + 6), c = i - r * (kBlurTW + 6);
+        const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 + c - 3, L.w);
+        s_src[r * SP + c] = img[(size_t)sy * L.stride + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        const int r = i / kBlurTW, c = i - r * kBlurTW;
+        const uint8_t* p = s_src + r * SP + c;
+        const uint32_t acc = (uint32_t)t0 * (p[0] + p[6]) + (uint32_t)t1 * (p[1] + p[5]) + (uint32_t)t2 * (p[2] + p[4]) + (uint32_t)t3 * p[3];
+        s_h[i] = (uint16_t)min(acc, 65535u);
+    }
+    __syncthreads();
+    // 4 output pixels per thread (one dword store)
+    for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
+        const int r = i / (kBlurTW / 4), c4 = (i - r * (kBlurTW / 4)) * 4;
+        const int oy = y0 + r;
+        if (oy >= L.h || x0 + c4 >= L.w) continue;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint16_t* h = s_h + r * kBlurTW + c4 + k;
+            const uint32_t acc = (uint32_t)t0 * ((uint32_t)h[0] + h[6 * kBlurTW]) + (uint32_t)t1 * ((uint32_t)h[kBlurTW] + h[5 * kBlurTW]) +
+                                 (uint32_t)t2 * ((uint32_t)h[2 * kBlurTW] + h[4 * kBlurTW]) + (uint32_t)t3 * h[3 * kBlurTW];
+            packed |= min((acc + 0x8000u) >> 16, 255u) << (8 * k);
+        }
+        *(uint32_t*)(dst + (size_t)oy * L.stride + x0 + c4) = packed;   // row padding absorbs the tail of the last dword
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// E5 + E7 + E8: one wave per keypoint.  IC_Angle on the unblurred level, steered BRIEF on the blurred
+// level, then the cv::KeyPoint record and the 32-byte descriptor are written to their output row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t frame_stride,
+                                                     const LevelDesc* __restrict__ levels, int n_levels,
+                                                     const uint32_t* __restrict__ sel, int sel_frame_stride,
+                                                     const int* __restrict__ sel_count,
+                                                     const int* __restrict__ kp_dst, int kp_frame_stride,
+                                                     OrbxKeyPoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap,
+                                                     OrbxKeyPoint* __restrict__ lvl_kps /* optional: per-level keypoints, level coords */)
+{
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);       // index into the per-frame sel buffer (level-major slots)
+    if (slot >= sel_frame_stride) return;
+    // which level does this slot belong to?
+    int level = -1;
+    LevelDesc L;
+    for (int l = 0; l < n_levels; l++) {
+        const LevelDesc t = levels[l];
+        if (slot >= t.sel_off && slot < t.sel_off + t.sel_cap) { level = l; L = t; }
+    }
+    if (level < 0) return;
+    const int k = slot - L.sel_off;
+    if (k >= sel_count[(size_t)frame * n_levels + level]) return;
+    const uint32_t e = sel[(size_t)frame * sel_frame_stride + slot];
+    const int px = (int)key_x(e) + 16, py = (int)key_y(e) + 16;     // level coordinates (:885-886)
+
+    // ---- IC_Angle: lanes 0..30 take column u = lane-15 of row +v, lanes 32..62 the same column of row -v... two rows per step
+    const uint8_t* img = pyr + (size_t)frame * frame_stride + L.off + (size_t)py * L.stride + px;
+    const int half = lane >> 5;             // 0: rows v = 0..15 stepping, 1: rows v = -1..-15
+    const int u = (lane & 31) - 15;
+    int m10 = 0, m01 = 0;
+    if ((lane & 31) < 31) {
+        for (int vi = 0; vi < 16; vi++) {
+            const int v = half ? -(vi + 1) : vi;
+            if (half && vi == 15) break;    // rows -1..-15 only
+            const int av = v < 0 ? -v : v;
+            if (u >= -d_umax[av] && u <= d_umax[av]) {
+                const int val = img[v * L.stride + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- steered BRIEF: lane handles pairs lane, lane+64, lane+128, lane+192; ballot k = descriptor bytes 8k..8k+7
+    const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
+    float a, b;
+    sincos_f32(angle * factorPI, &a, &b);
+    const uint8_t* bimg = blur + (size_t)frame * frame_stride + L.off + (size_t)py * L.stride + px;
+    unsigned long long w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const signed char* pt = d_pattern + 4 * (lane + 64 * q);
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int t0 = bimg[cv_round_f(x0 * b + y0 * a) * L.stride + cv_round_f(x0 * a - y0 * b)];
+        const int t1 = bimg[cv_round_f(x1 * b + y1 * a) * L.stride + cv_round_f(x1 * a - y1 * b)];
+        w[q] = __ballot(t0 < t1);
+    }
+    const int row = kp_dst[(size_t)frame * kp_frame_stride + slot];
+    if (lane == 0) {
+        OrbxKeyPoint kp;
+        kp.x = (float)px; kp.y = (float)py;
+        kp.size = (float)L.patch_size; kp.angle = angle; kp.response = (float)key_resp(e);
+        kp.octave = level; kp.class_id = -1;
+        if (lvl_kps) lvl_kps[(size_t)frame * sel_frame_stride + slot] = kp;
+        if (level != 0) { kp.x = kp.x * L.scale; kp.y = kp.y * L.scale; }      // :1149-1151
+        if (row >= 0 && row < cap) kps[(size_t)frame * cap + row] = kp;
+    }
+    if (lane < 4 && row >= 0 && row < cap) {
+        const unsigned long long mine = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
+        ((unsigned long long*)(desc + ((size_t)frame * cap + row) * 32))[lane] = mine;
+    }
+}
+
+}  // namespace orbx

@@ -1,0 +1,106 @@
+"""Parity of the HIP extractor (through the C ABI) against the CPU oracle: bit-exact keypoints
+(x, y, octave, angle, response, size), descriptor bytes and output order, stage by stage and end to end."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+def _assert_kps_equal(a, b, what):
+    assert len(a) == len(b), "%s: count %d vs %d" % (what, len(a), len(b))
+    for f in FIELDS:
+        if not np.array_equal(a[f], b[f]):
+            bad = np.nonzero(a[f] != b[f])[0]
+            raise AssertionError("%s: field %s differs at %d rows, first %d: %r vs %r" %
+                                 (what, f, len(bad), bad[0], a[f][bad[0]], b[f][bad[0]]))
+
+
+@pytest.fixture(scope="module")
+def gpu_ex(pkg):
+    ex = pkg.Extractor(1000, 1.2, 8, 20, 7)
+    yield ex
+    ex.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_stagewise_640x480(pkg, oracle, synth, gpu_ex, seed):
+    img = synth.make_frame(seed)
+    oex = oracle.extractor(1000, 1.2, 8, 20, 7)
+    r0, okps, odesc = oex.extract(img, (0, 1000))
+    mono, kps, desc = gpu_ex(img, (0, 1000))
+    for l in range(8):
+        assert gpu_ex.level_size(l) == oex.level_size(l)
+        np.testing.assert_array_equal(gpu_ex.pyramid_level(l), oex.level_image(l), err_msg="pyramid level %d" % l)
+    for l in range(8):
+        oc = oex.level_candidates(l)
+        gc = gpu_ex.candidates(l)
+        assert len(gc) == len(oc), "level %d candidates %d vs %d" % (l, len(gc), len(oc))
+        for f in ("x", "y", "response"):
+            np.testing.assert_array_equal(gc[f], oc[f], err_msg="FAST candidates level %d field %s" % (l, f))
+    for l in range(8):
+        ob = oex.level_blurred(l)
+        if ob is not None:
+            np.testing.assert_array_equal(gpu_ex.blurred_level(l), ob, err_msg="blur level %d" % l)
+    for l in range(8):
+        _assert_kps_equal(gpu_ex.level_keypoints(l), oex.level_keypoints(l), "octree+angle level %d" % l)
+    assert mono == r0
+    _assert_kps_equal(kps, okps, "final keypoints")
+    np.testing.assert_array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("shape,params,lap", [
+    ((120, 160), (300, 1.2, 4, 20, 7), (0, 1000)),
+    ((240, 376), (500, 1.2, 8, 20, 7), (0, 0)),          # rectified-stereo style lapping: forward order
+    ((480, 752), (1200, 1.2, 8, 20, 7), (100, 400)),     # fisheye style overlap bounds
+    ((97, 131), (150, 1.5, 3, 15, 5), (0, 1000)),
+    ((480, 640), (5000, 1.2, 8, 20, 7), (0, 1000)),      # mono initialisation extractor (5 x nFeatures)
+])
+def test_end_to_end_shapes(pkg, oracle, synth, shape, params, lap):
+    h, w = shape
+    img = synth.make_frame(11, w, h)
+    oex = oracle.extractor(*params)
+    r0, okps, odesc = oex.extract(img, lap)
+    ex = pkg.Extractor(*params)
+    try:
+        mono, kps, desc = ex(img, lap)
+    finally:
+        ex.close()
+    assert mono == r0
+    _assert_kps_equal(kps, okps, "final keypoints %r" % (shape,))
+    np.testing.assert_array_equal(desc, odesc)
+
+
+def test_flat_and_empty(pkg, oracle, gpu_ex):
+    flat = np.full((480, 640), 90, np.uint8)
+    mono, kps, desc = gpu_ex(flat)
+    assert mono == 0 and len(kps) == 0 and desc.shape == (0, 32)
+    mono, kps, desc = gpu_ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1                       # reference returns -1 for an empty image
+    n = pkg.capi.C.c_int(); m = pkg.capi.C.c_int()
+    r = pkg.lib.orbx_extract(gpu_ex._h, None, 0, 0, 0, 0, 1000, None, None, 0, pkg.capi.C.byref(n), pkg.capi.C.byref(m))
+    assert r == -1 and m.value == -1
+
+
+def test_batch_matches_single(pkg, oracle, synth):
+    imgs = synth.make_frames(6, seed0=20)
+    ex = pkg.Extractor(1000, 1.2, 8, 20, 7)
+    try:
+        mono, n, kps, desc = ex.extract_batch(imgs)
+        oex = oracle.extractor(1000, 1.2, 8, 20, 7)
+        for b in range(len(imgs)):
+            r0, okps, odesc = oex.extract(imgs[b])
+            assert mono[b] == r0 and n[b] == len(okps)
+            _assert_kps_equal(kps[b, :n[b]], okps, "batch frame %d" % b)
+            np.testing.assert_array_equal(desc[b, :n[b]], odesc)
+    finally:
+        ex.close()
+
+
+def test_pyramid_border(pkg, oracle, synth, gpu_ex):
+    img = synth.make_frame(3)
+    gpu_ex(img)
+    lvl = gpu_ex.pyramid_level(2, border=19)
+    inner = gpu_ex.pyramid_level(2)
+    np.testing.assert_array_equal(lvl, np.pad(inner, 19, mode="reflect"))     # numpy 'reflect' == BORDER_REFLECT_101
