@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X (BASELINE.json: "tracking frames/s (ORB extract+match)
+and LocalBA iters/s, 1/2/4/8 MI355X vs CPU ref").
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  ORBextractor::operator() on B 640x480 mono frames (8 levels, 1000 features, BASELINE configs[1]) followed by
+  ORBmatcher::SearchByBoW on B (1000 x 1000)-descriptor pairs (configs[2]), all through the C ABI on one HIP stream.
+Frames shard over ranks with no collective (weak scaling: B frames per GPU).  value = frames of all ranks / time of
+the slowest rank.  PyTorch only provides device buffers, the stream and torch.distributed.
+
+Extra legs reported in the same JSON line:
+  roofline      dominant extractor kernel, duration measured live with HIP events on the launch stream
+  cpu_baseline  the CPU oracle (this repo's restatement of the reference algorithms) on the box's host cores, 1 thread
+  lba           LocalBundleAdjustment 50 KF / 2000 MP / 20 k edges (configs[3]): outer LM iterations per second
+  gba           (N>1 only) landmark-sharded global BA whose reduced camera system is summed with one RCCL all-reduce
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+ALGO_BYTES_PER_FRAME = 4934396  # algorithmic HBM traffic of one 640x480 extraction
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def stage_algorithmic_bytes(level_sizes, n_kp, n_cand):
+    """Algorithmic bytes per frame of every extractor stage."""
+    px = [w * h for (w, h) in level_sizes]
+    return {
+        "resize": sum(px[:-1]) + sum(px[1:]),               # read levels 0..L-2, write levels 1..L-1
+        "fast_cells": sum(px) + 4 * n_cand,                 # every level read once + candidate records
+        "octree": 2 * 4 * n_cand + 4 * n_kp,                # candidate keys in/out (latency-bound stage)
+        "index": 8 * n_kp,
+        "blur": 2 * sum(px),                                # read + write every level
+        "orient_desc": n_kp * (31 * 31 + 37 * 37) + n_kp * 60,   # patch reads + 28 B keypoint + 32 B descriptor
+        "copy_level0": 2 * px[0],
+    }
+
+
+def cpu_baseline(synth, imgs, match_sets, budget_s=12.0):
+    """Oracle (kind 'port': the reference cannot be built here) timed on ONE host core, extract + SearchByBoW per frame."""
+    from oracle_api import Oracle, build_oracle
+    try:
+        path = build_oracle(native=True)        # -O3 -march=native like the reference's CMakeLists.txt:10-13
+    except Exception:
+        path = None
+    o = Oracle(path)
+    ex = o.extractor(1000, 1.2, 8, 20, 7)
+    ms = match_sets[0]
+
+    def one(i):
+        ex.extract(imgs[i % len(imgs)], (0, 1000))
+        o.search_by_bow(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], ms["angF"], ms["fvF"], 0.7, True)
+    one(0)
+    t0 = time.perf_counter()
+    for i in range(10):
+        one(i)
+    per = (time.perf_counter() - t0) / 10
+    n = int(max(30, min(5000, budget_s / per)))
+    t0 = time.perf_counter()
+    for i in range(n):
+        one(i)
+    dt = time.perf_counter() - t0
+    return o, {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d frames 640x480 (extract 1000 features + SearchByBoW 1000x1000), single thread, %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("ORBX_BENCH_BATCH", "256")))
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-lba", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+
+    pkg = importlib.import_module("orb_slam3-1_amd")
+    synth = importlib.import_module("orb_slam3-1_amd.synth")
+    dmod = importlib.import_module("orb_slam3-1_amd.distributed")
+
+    B, K, W = args.batch, args.steps, args.warmup
+    Hh, Ww = 480, 640
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    n_distinct = 8
+    host_imgs = synth.make_frames(n_distinct, seed0=100 * rank)
+    reps = (B + n_distinct - 1) // n_distinct
+    d_imgs = torch.from_numpy(np.concatenate([host_imgs] * reps)[:B].copy()).to(dev)
+    ex = pkg.Extractor(1000, 1.2, 8, 20, 7, device=local_rank)
+    cap = ex.max_keypoints
+    d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
+    match_sets = [synth.make_match_set(50 + i) for i in range(4)]
+    matcher = pkg.Matcher(0.7, True, device=local_rank)
+    plan = matcher.bow_plan([match_sets[i % 4] for i in range(B)])
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ex.extract_batch_device(d_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                d_n.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
+        plan.run(stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = world * B * K
+    value = frames / elapsed
+
+    # sanity of what was computed (not timed)
+    st = d_status.cpu().numpy()
+    nk = d_n.cpu().numpy()
+    if (st != 0).any():
+        raise SystemExit("extractor reported device status %r" % st[st != 0][:4])
+    bow = plan.fetch(stream)
+    n_kp = float(nk.mean())
+
+    out = {
+        "metric": "tracking frames/s (ORB extract+match)", "value": value, "unit": "frames/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "ORBextractor::operator() 640x480 mono, 8 levels, 1000 features (BASELINE configs[1]) + "
+                               "ORBmatcher::SearchByBoW 1000x1000 descriptors per frame (configs[2])",
+                   "batch_per_gpu": B, "frames_per_step": world * B, "keypoints_per_frame": n_kp,
+                   "bow_matches_per_pair": float(np.mean([b[0] for b in bow])), "sharding": "frames, no collective"},
+        "pipeline_gbs": ALGO_BYTES_PER_FRAME * value / 1e9,
+    }
+
+    if rank == 0:
+        # ---- roofline leg: per-stage device time with HIP events on the launch stream ----
+        ex.profile_enable(True)
+        acc = {}
+        reps_p = 5
+        for _ in range(reps_p):
+            ex.extract_batch_device(d_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                    d_n.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
+            torch.cuda.synchronize()
+            for k, v in ex.profile_read().items():
+                acc[k] = acc.get(k, 0.0) + v / reps_p
+        ex.profile_enable(False)
+        n_cand = float(sum(len(ex.candidates(l, frame=0)) for l in range(8)))
+        sizes = [ex.level_size(l) for l in range(8)]
+        sb = stage_algorithmic_bytes(sizes, n_kp, n_cand)
+        dom = max(acc, key=acc.get)
+        achieved = sb[dom] * B / (acc[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from a separate rocprofv3 --pmc run
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "launch_ms": acc[dom], "algorithmic_bytes_per_launch": sb[dom] * B,
+                           "stage_ms": acc, "stage_gbs": {k: sb[k] * B / (max(acc[k], 1e-6) * 1e-3) / 1e9 for k in acc}}
+
+        # ---- LocalBA leg (configs[3]) ----
+        if not args.no_lba:
+            w = synth.make_ba_window(0)
+            sh = pkg.LbaShard(w, device=local_rank)
+            ad = dmod.LocalHipShard(sh)
+            stats = dmod.sharded_bundle_adjustment(ad, None, None, max_iters=10)      # warm-up + reference stats
+            n_runs, iters, trials = 5, 0, 0
+            t0 = time.perf_counter()
+            for _ in range(n_runs):
+                sh.reset()
+                s2 = dmod.sharded_bundle_adjustment(ad, None, None, max_iters=10)
+                iters += s2["iterations"]; trials += s2["trials"]
+            dt = time.perf_counter() - t0
+            solver = pkg.LbaSolver(device=local_rank)
+            t1 = time.perf_counter()
+            r = solver.solve(w, 10)
+            dt_call = time.perf_counter() - t1
+            out["lba"] = {"metric": "LocalBA outer iterations/s", "value": iters / dt, "unit": "iters/s", "dtype": "f64",
+                          "workload": "50 opt + 10 fixed KF, 2000 MP, %d mono edges, optimize(10)" % len(w["edge_point"]),
+                          "iterations_per_solve": stats["iterations"], "trials_per_solve": stats["trials"],
+                          "ms_per_iteration": 1e3 * dt / max(iters, 1), "algorithmic_mflop_per_iteration": 47.0,
+                          "achieved_gflops": 47e-3 * iters / dt,
+                          "lba_solve_call_ms_incl_upload": 1e3 * dt_call, "chi2_initial": stats["chi2_initial"], "chi2_final": stats["chi2_final"]}
+            sh.close(); solver.close()
+
+        # ---- CPU baseline leg (N=1 only, rank 0) ----
+        if not args.no_cpu and world == 1:
+            o, cb = cpu_baseline(synth, host_imgs, match_sets)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_1core"] = value / cb["value"]
+            if "lba" in out:
+                w = synth.make_ba_window(0)
+                t0 = time.perf_counter(); it = 0
+                for _ in range(3):
+                    it += o.lba_solve(w, 10)["stats"]["iterations"]
+                dtc = time.perf_counter() - t0
+                out["lba"]["cpu_baseline"] = {"value": it / dtc, "unit": "iters/s", "cores": 1, "kind": "port",
+                                              "sample": "3 solves of the same window, %d iterations" % it}
+                out["lba"]["speedup_vs_cpu_1core"] = out["lba"]["value"] / (it / dtc)
+
+    # ---- sharded global BA with one RCCL all-reduce per LM trial (N>1) ----
+    if world > 1 and not args.no_lba:
+        try:
+            wg = synth.make_ba_window(3, n_opt=190, n_fixed=10, n_points=8000, obs_per_point=10)
+            loc, _, _ = dmod.partition_landmarks(wg, rank, world)
+            sh = pkg.LbaShard(loc, device=local_rank)
+            ad = dmod.HipShard(sh, torch, dev)
+            comm = dmod.TorchDist(dist, dev)
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gs = dmod.sharded_bundle_adjustment(ad, ad.tensor, comm, max_iters=5)
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - t0
+            if rank == 0:
+                out["gba"] = {"workload": "200 KF / 8000 MP / %d edges, landmarks sharded over %d GPUs" % (len(wg["edge_point"]), world),
+                              "allreduce_bytes_per_trial": int(ad.n_red * 8), "iterations": gs["iterations"], "trials": gs["trials"],
+                              "seconds": dtg, "iters_per_s": gs["iterations"] / dtg, "chi2_initial": gs["chi2_initial"], "chi2_final": gs["chi2_final"]}
+            sh.close()
+        except Exception as e:     # the frame-sharded headline number stands on its own
+            if rank == 0:
+                out["gba"] = {"error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    plan.close(); matcher.close(); ex.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

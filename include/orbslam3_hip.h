@@ -87,6 +87,12 @@ int orbx_features_per_level(const orbx_extractor* h, int* n_per_level);
 int orbx_pyramid_level_size(const orbx_extractor* h, int level, int* width, int* height);
 int orbx_pyramid_level(orbx_extractor* h, int frame, int level, int border, uint8_t* dst, int dst_stride);
 
+/* Per-stage device time of the LAST extract call, measured with HIP events recorded on the launch stream
+ * (used by bench.py for the roofline figure).  Stages: 0 level-0 copy, 1 pyramid resize, 2 FAST cells, 3 octree,
+ * 4 output index, 5 blur, 6 orientation + descriptors.  Times in milliseconds. */
+int orbx_profile_enable(orbx_extractor* h, int on);
+int orbx_profile_read(orbx_extractor* h, float* stage_ms, int n_stages);
+
 /* Stage-wise introspection for parity tests (results of the LAST extract call, frame `frame`). */
 int orbx_debug_blurred_level(orbx_extractor* h, int frame, int level, uint8_t* dst, int dst_stride);
 /* FAST candidates of a level in vToDistributeKeys order (src/ORBextractor.cc:787-872): x,y relative to minBorder, response. */
@@ -129,6 +135,14 @@ typedef struct OrbmBowPair {
     int32_t n_matches;      /* out */
 } OrbmBowPair;
 int orbm_search_by_bow_batch(orbm_matcher* m, OrbmBowPair* pairs, int n_pairs, float nnratio, int check_orientation);
+
+/* Device-resident batched SearchByBoW: the plan uploads the pairs once; run() only launches the kernel on `stream`
+ * (hipStream_t, NULL = default stream); fetch() copies match_f2kf / n_matches back into the pairs. */
+typedef struct orbm_bow_plan orbm_bow_plan;
+int orbm_bow_plan_create(orbm_matcher* m, const OrbmBowPair* pairs, int n_pairs, orbm_bow_plan** out);
+int orbm_bow_plan_run(orbm_bow_plan* plan, float nnratio, int check_orientation, void* stream);
+int orbm_bow_plan_fetch(orbm_bow_plan* plan, OrbmBowPair* pairs, void* stream);
+void orbm_bow_plan_destroy(orbm_bow_plan* plan);
 
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:765-905).
  * match12[n1] = feature index in KF2 or -1.  Strict `< TH_LOW` as the reference (:848). */
@@ -223,19 +237,34 @@ int lba_solve(lba_solver* s, const LbaProblem* problem, const volatile uint8_t* 
               double* chi2_per_edge, uint8_t* depth_positive, LbaStats* stats);
 
 /* Sharded global BA: landmarks (with all their edges) are partitioned over ranks, poses replicated.
- * One LM trial = lba_shard_reduce() on every rank -> all-reduce(sum) of the returned buffer across ranks (RCCL,
- * done by the caller on the DEVICE buffer) -> lba_shard_finish() on every rank.  See INTEGRATION.md. */
+ * The same entry points also drive the single-GPU lba_solve().  One outer LM iteration on every rank:
+ *   lba_shard_linearize()                      errors + buildSystem on the accepted state; chi2 and max diagonals
+ *      -> caller: all-reduce SUM chi2, all-reduce MAX the diagonals (iteration 0: lambda = tau * max)
+ *   repeat (LM trial):
+ *     lba_shard_reduce(lambda)                 this rank's partial reduced camera system into the reduce buffer
+ *        -> caller: all-reduce SUM of lba_shard_reduce_buffer() (a DEVICE pointer; RCCL over xGMI)
+ *     lba_shard_finish(lambda, ...)            += lambda I, Cholesky, back-substitution of the local landmarks,
+ *                                              trial state, errors -> chi2_local_new, scale terms
+ *        -> caller: all-reduce SUM (chi2_local_new, scale_landmarks_local); rho test (levenberg.cpp:129-147)
+ *     lba_shard_accept(accept)                 discardTop() / pop()
+ * See INTEGRATION.md for the torch.distributed / RCCL side. */
 typedef struct lba_shard lba_shard;
 int lba_shard_create(int device, const LbaProblem* local_problem, lba_shard** out);
 void lba_shard_destroy(lba_shard* s);
-/* number of doubles in the reduce buffer: (6P)^2 + 6P + 4, P = number of non-fixed poses */
+/* number of doubles in the reduce buffer: n*n + 3n with n = 6 * (number of non-fixed poses):
+ * [ S (n x n, row-major) | b_schur (n) | b_p (n) | diag(Hpp) (n) ] -- every section is additive over shards. */
 int64_t lba_shard_reduce_len(const lba_shard* s);
-/* device pointer of the reduce buffer [S | b_schur | chi2, max_diag, scale_partial, spare] */
 double* lba_shard_reduce_buffer(lba_shard* s);
-int lba_shard_linearize(lba_shard* s, double* chi2_local);                 /* errors + build system (once per outer iteration) */
-int lba_shard_reduce(lba_shard* s, double lambda);                         /* partial Schur complement into the reduce buffer */
-int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double* scale_local);  /* solve + back-subst + trial update */
-int lba_shard_accept(lba_shard* s, int accept);                            /* discardTop() / pop() */
+/* optional: use a caller-owned device buffer of lba_shard_reduce_len() doubles (e.g. a torch CUDA tensor) instead */
+int lba_shard_set_reduce_buffer(lba_shard* s, double* device_buffer);
+int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses_local, double* max_diag_landmarks_local);
+int lba_shard_reduce(lba_shard* s, double lambda);
+/* returns 1 if the reduced system was solved, 0 if it was not positive definite (step is rejected), <0 on error.
+ * scale_poses is identical on every rank (count it once); scale_landmarks_local must be summed over ranks. */
+int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double* scale_poses, double* scale_landmarks_local);
+int lba_shard_accept(lba_shard* s, int accept);
+int lba_shard_reset(lba_shard* s);     /* back to the initial estimates (benchmarks re-run without re-uploading) */
+/* estimates of the accepted state; chi2_per_edge = e->chi2() of the last computed errors, depth_positive = isDepthPositive() */
 int lba_shard_download(lba_shard* s, double* pose_q, double* pose_t, double* points, double* chi2_per_edge, uint8_t* depth_positive);
 
 #ifdef __cplusplus

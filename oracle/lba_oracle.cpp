@@ -541,3 +541,180 @@ extern "C" int lba_oracle_solve(const OracleLbaProblem* pr, const volatile uint8
     if (st) *st = stats;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sharded form of the same algorithm (landmarks partitioned over ranks, poses replicated).
+// Used by the world_size-2 gloo tests to check the distributed LM driver against the single-rank oracle.
+// Reduce buffer layout = the product's: [ S (n x n) | b_schur (n) | b_p (n) | diag(Hpp) (n) ], all additive.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct OracleShard {
+    Lba s;
+    OracleLbaProblem prob;
+    std::vector<double> q, t, pts, obs, w;
+    std::vector<uint8_t> fixed, stereo;
+    std::vector<int32_t> ep, eo;
+    std::vector<double> reduce;
+    std::vector<double> Dinv;
+    std::vector<std::vector<int> > by_l;
+    std::vector<Pose> trial_poses;
+    std::vector<double> trial_pts;
+    int n;
+};
+
+}  // namespace
+
+extern "C" {
+
+void* lba_oracle_shard_create(const OracleLbaProblem* p)
+{
+    OracleShard* o = new OracleShard();
+    o->q.assign(p->pose_q, p->pose_q + 4 * (size_t)p->n_poses);
+    o->t.assign(p->pose_t, p->pose_t + 3 * (size_t)p->n_poses);
+    o->fixed.assign(p->pose_fixed, p->pose_fixed + p->n_poses);
+    o->pts.assign(p->points, p->points + 3 * (size_t)p->n_points);
+    o->ep.assign(p->edge_point, p->edge_point + p->n_edges);
+    o->eo.assign(p->edge_pose, p->edge_pose + p->n_edges);
+    o->obs.assign(p->edge_obs, p->edge_obs + 3 * (size_t)p->n_edges);
+    o->w.assign(p->edge_inv_sigma2, p->edge_inv_sigma2 + p->n_edges);
+    o->stereo.assign(p->edge_stereo, p->edge_stereo + p->n_edges);
+    o->prob = *p;
+    o->prob.pose_q = o->q.data(); o->prob.pose_t = o->t.data(); o->prob.pose_fixed = o->fixed.data();
+    o->prob.points = o->pts.data(); o->prob.edge_point = o->ep.data(); o->prob.edge_pose = o->eo.data();
+    o->prob.edge_obs = o->obs.data(); o->prob.edge_inv_sigma2 = o->w.data(); o->prob.edge_stereo = o->stereo.data();
+    o->s.init(&o->prob);
+    o->n = 6 * o->s.nP;
+    o->reduce.assign((size_t)o->n * o->n + 3 * (size_t)o->n, 0.0);
+    o->Dinv.assign(9 * (size_t)o->s.nL, 0.0);
+    o->by_l.resize(o->s.nL);
+    for (int e = 0; e < o->s.nE; e++)
+        if (o->s.pose_col[o->prob.edge_pose[e]] >= 0) o->by_l[o->prob.edge_point[e]].push_back(e);
+    return o;
+}
+
+void lba_oracle_shard_destroy(void* h) { delete (OracleShard*)h; }
+int64_t lba_oracle_shard_reduce_len(void* h) { return (int64_t)((OracleShard*)h)->reduce.size(); }
+double* lba_oracle_shard_reduce_buffer(void* h) { return ((OracleShard*)h)->reduce.data(); }
+
+void lba_oracle_shard_linearize(void* h, double* chi2, double* max_diag_poses, double* max_diag_landmarks)
+{
+    OracleShard* o = (OracleShard*)h;
+    o->s.compute_errors();
+    *chi2 = o->s.robust_chi2();
+    o->s.build_system();
+    double mp = 0, ml = 0;
+    for (int i = 0; i < o->s.nP; i++) for (int j = 0; j < 6; j++) mp = std::max(std::fabs(o->s.Hpp[(size_t)i * 36 + j * 7]), mp);
+    for (int i = 0; i < o->s.nL; i++) for (int j = 0; j < 3; j++) ml = std::max(std::fabs(o->s.Hll[(size_t)i * 9 + j * 4]), ml);
+    *max_diag_poses = mp; *max_diag_landmarks = ml;
+}
+
+void lba_oracle_shard_reduce(void* h, double lambda)
+{
+    OracleShard* o = (OracleShard*)h;
+    Lba& s = o->s;
+    const int n = o->n;
+    std::fill(o->reduce.begin(), o->reduce.end(), 0.0);
+    double* S = o->reduce.data();
+    double* bs = S + (size_t)n * n;
+    double* bpf = bs + n;
+    double* dg = bpf + n;
+    for (int i = 0; i < s.nP; i++)
+        for (int a = 0; a < 6; a++) {
+            for (int b = 0; b < 6; b++) S[(size_t)(6 * i + a) * n + 6 * i + b] = s.Hpp[(size_t)i * 36 + a * 6 + b];
+            bs[6 * i + a] = s.bp[6 * i + a];
+            bpf[6 * i + a] = s.bp[6 * i + a];
+            dg[6 * i + a] = s.Hpp[(size_t)i * 36 + a * 7];
+        }
+    for (int l = 0; l < s.nL; l++) {
+        double Dm[9];
+        for (int k = 0; k < 9; k++) Dm[k] = s.Hll[(size_t)l * 9 + k] + (k % 4 == 0 ? lambda : 0.0);
+        double* Di = &o->Dinv[(size_t)l * 9];
+        inv3(Dm, Di);
+        double db[3];
+        for (int a = 0; a < 3; a++) db[a] = Di[a * 3] * s.bl[3 * l] + Di[a * 3 + 1] * s.bl[3 * l + 1] + Di[a * 3 + 2] * s.bl[3 * l + 2];
+        const std::vector<int>& es = o->by_l[l];
+        for (size_t a = 0; a < es.size(); a++) {
+            const double* Bi = &s.Hpl[(size_t)es[a] * 18];
+            const int i1 = s.pose_col[o->prob.edge_pose[es[a]]];
+            double BD[18];
+            for (int r = 0; r < 6; r++)
+                for (int c = 0; c < 3; c++) BD[r * 3 + c] = Bi[r * 3] * Di[c] + Bi[r * 3 + 1] * Di[3 + c] + Bi[r * 3 + 2] * Di[6 + c];
+            for (int r = 0; r < 6; r++) bs[6 * i1 + r] -= Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+            for (size_t b = 0; b < es.size(); b++) {
+                const double* Bj = &s.Hpl[(size_t)es[b] * 18];
+                const int i2 = s.pose_col[o->prob.edge_pose[es[b]]];
+                for (int r = 0; r < 6; r++)
+                    for (int c = 0; c < 6; c++)
+                        S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] -= BD[r * 3] * Bj[c * 3] + BD[r * 3 + 1] * Bj[c * 3 + 1] + BD[r * 3 + 2] * Bj[c * 3 + 2];
+            }
+        }
+    }
+}
+
+int lba_oracle_shard_finish(void* h, double lambda, double* chi2_new, double* scale_poses, double* scale_landmarks)
+{
+    OracleShard* o = (OracleShard*)h;
+    Lba& s = o->s;
+    const int n = o->n;
+    std::vector<double> S(o->reduce.begin(), o->reduce.begin() + (size_t)n * n);
+    const double* bs = o->reduce.data() + (size_t)n * n;
+    const double* bpf = bs + n;
+    for (int i = 0; i < n; i++) S[(size_t)i * n + i] += lambda;
+    bool ok = true;
+    if (n > 0) ok = ldlt_solve(S, n, bs, s.x.data());
+    double sp = 0, sl = 0;
+    if (ok) {
+        for (int l = 0; l < s.nL; l++) {
+            double c[3] = {s.bl[3 * l], s.bl[3 * l + 1], s.bl[3 * l + 2]};
+            const std::vector<int>& es = o->by_l[l];
+            for (size_t a = 0; a < es.size(); a++) {
+                const double* B = &s.Hpl[(size_t)es[a] * 18];
+                const double* xp = &s.x[6 * (size_t)s.pose_col[o->prob.edge_pose[es[a]]]];
+                for (int k = 0; k < 3; k++) { double v = 0; for (int r = 0; r < 6; r++) v += B[r * 3 + k] * xp[r]; c[k] -= v; }
+            }
+            const double* Di = &o->Dinv[(size_t)l * 9];
+            for (int a = 0; a < 3; a++) {
+                const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
+                s.x[(size_t)n + 3 * l + a] = xl;
+                sl += xl * (lambda * xl + s.bl[3 * l + a]);
+            }
+        }
+        for (int j = 0; j < n; j++) sp += s.x[j] * (lambda * s.x[j] + bpf[j]);
+    }
+    // trial state
+    std::vector<Pose> keep_poses = s.poses;
+    std::vector<double> keep_pts = s.pts;
+    if (ok) s.update();
+    s.compute_errors();
+    *chi2_new = s.robust_chi2();
+    o->trial_poses = s.poses; o->trial_pts = s.pts;
+    s.poses = keep_poses; s.pts = keep_pts;
+    *scale_poses = sp; *scale_landmarks = sl;
+    return ok ? 1 : 0;
+}
+
+void lba_oracle_shard_accept(void* h, int accept)
+{
+    OracleShard* o = (OracleShard*)h;
+    if (accept) { o->s.poses = o->trial_poses; o->s.pts = o->trial_pts; }
+}
+
+void lba_oracle_shard_download(void* h, double* q, double* t, double* pts, double* chi2, uint8_t* depth)
+{
+    OracleShard* o = (OracleShard*)h;
+    Lba& s = o->s;
+    for (int i = 0; i < o->prob.n_poses; i++) {
+        q[4 * i] = s.poses[i].q.x; q[4 * i + 1] = s.poses[i].q.y; q[4 * i + 2] = s.poses[i].q.z; q[4 * i + 3] = s.poses[i].q.w;
+        for (int k = 0; k < 3; k++) t[3 * i + k] = s.poses[i].t[k];
+    }
+    std::memcpy(pts, s.pts.data(), sizeof(double) * 3 * (size_t)s.nL);
+    for (int e = 0; e < s.nE; e++) {
+        chi2[e] = s.edge_chi2(e);
+        double Xc[3];
+        pose_map(s.poses[o->prob.edge_pose[e]], &s.pts[3 * (size_t)o->prob.edge_point[e]], Xc);
+        depth[e] = Xc[2] > 0.0;
+    }
+}
+
+}  // extern "C"

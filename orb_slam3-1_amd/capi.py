@@ -187,6 +187,19 @@ class Extractor:
                                              lapping_area[0], lapping_area[1], d_kps_ptr, d_desc_ptr, cap,
                                              d_n_ptr, d_mono_ptr, d_status_ptr, stream))
 
+    def profile_enable(self, on=True):
+        lib.orbx_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.orbx_profile_enable(self._h, int(on)))
+
+    STAGES = ("copy_level0", "resize", "fast_cells", "octree", "index", "blur", "orient_desc")
+
+    def profile_read(self):
+        """per-stage device milliseconds of the last call (HIP events on the launch stream)"""
+        lib.orbx_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        ms = np.zeros(7, np.float32)
+        _check(lib.orbx_profile_read(self._h, _p(ms), 7))
+        return dict(zip(self.STAGES, ms.tolist()))
+
     # mvImagePyramid replacement + stage introspection
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
@@ -295,6 +308,10 @@ class Matcher:
         _check(lib.orbm_search_by_bow_batch(self._h, arr, P, self.nnratio, int(self.check_ori)))
         return [(arr[i].n_matches, outs[i]) for i in range(P)]
 
+    def bow_plan(self, sets):
+        """Uploads the pairs once; returns a BowPlan whose run() only launches the kernel."""
+        return BowPlan(self, sets)
+
     def SearchByBoW_KFKF(self, d1, valid1, ang1, fv1, d2, valid2, ang2, fv2):
         match = np.full(len(d1), -1, np.int32)
         a, b = _fv(fv1), _fv(fv2)
@@ -325,6 +342,47 @@ class Matcher:
         return _check(lib.orbm_search_by_projection_last(
             self._h, C.byref(f), len(last["u"]), _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last["octave"]),
             _p(last["angle"]), _p(last["desc"]), _p(last["has_obs"]), th, int(self.check_ori), _p(assign), _p(occupied)))
+
+
+class BowPlan:
+    def __init__(self, matcher, sets):
+        lib.orbm_bow_plan_create.argtypes = [C.c_void_p, C.POINTER(BowPair), C.c_int, C.POINTER(C.c_void_p)]
+        lib.orbm_bow_plan_run.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        lib.orbm_bow_plan_fetch.argtypes = [C.c_void_p, C.POINTER(BowPair), C.c_void_p]
+        lib.orbm_bow_plan_destroy.argtypes = [C.c_void_p]
+        self.m = matcher
+        P = self.P = len(sets)
+        self.arr = (BowPair * P)()
+        self.keep, self.outs = [], []
+        for i, s in enumerate(sets):
+            dKF, dF = np.ascontiguousarray(s["dKF"]), np.ascontiguousarray(s["dF"])
+            a, b = _fv(s["fvKF"]), _fv(s["fvF"])
+            m = np.full(len(dF), -1, np.int32)
+            self.keep.append((dKF, dF, a, b, s["validKF"], s["angKF"], s["angF"]))
+            self.outs.append(m)
+            self.arr[i] = BowPair(dKF.ctypes.data, len(dKF), s["validKF"].ctypes.data, s["angKF"].ctypes.data, a,
+                                  dF.ctypes.data, len(dF), s["angF"].ctypes.data, b, m.ctypes.data, 0)
+        h = C.c_void_p()
+        _check(lib.orbm_bow_plan_create(matcher._h, self.arr, P, C.byref(h)))
+        self._h = h
+
+    def run(self, stream=None):
+        _check(lib.orbm_bow_plan_run(self._h, self.m.nnratio, int(self.m.check_ori), stream))
+
+    def fetch(self, stream=None):
+        _check(lib.orbm_bow_plan_fetch(self._h, self.arr, stream))
+        return [(self.arr[i].n_matches, self.outs[i]) for i in range(self.P)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.orbm_bow_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _lba_problem(w):
@@ -387,9 +445,9 @@ class LbaShard:
         lib.lba_shard_reduce_len.restype = C.c_int64
         lib.lba_shard_reduce_buffer.argtypes = [C.c_void_p]
         lib.lba_shard_reduce_buffer.restype = C.c_void_p
-        lib.lba_shard_linearize.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        lib.lba_shard_linearize.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 3
         lib.lba_shard_reduce.argtypes = [C.c_void_p, C.c_double]
-        lib.lba_shard_finish.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        lib.lba_shard_finish.argtypes = [C.c_void_p, C.c_double] + [C.POINTER(C.c_double)] * 3
         lib.lba_shard_accept.argtypes = [C.c_void_p, C.c_int]
         lib.lba_shard_download.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         self._pr = _lba_problem(w)
@@ -414,22 +472,32 @@ class LbaShard:
     def reduce_buffer_ptr(self):
         return lib.lba_shard_reduce_buffer(self._h)
 
+    def set_reduce_buffer(self, device_ptr):
+        lib.lba_shard_set_reduce_buffer.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib.lba_shard_set_reduce_buffer(self._h, device_ptr))
+
     def linearize(self):
-        chi = C.c_double()
-        _check(lib.lba_shard_linearize(self._h, C.byref(chi)))
-        return chi.value
+        """returns (chi2_local, max_diag_poses_local, max_diag_landmarks_local)"""
+        chi, mp, ml = C.c_double(), C.c_double(), C.c_double()
+        _check(lib.lba_shard_linearize(self._h, C.byref(chi), C.byref(mp), C.byref(ml)))
+        return chi.value, mp.value, ml.value
 
     def reduce(self, lam):
         _check(lib.lba_shard_reduce(self._h, lam))
 
     def finish(self, lam):
-        chi, sc = C.c_double(), C.c_double()
-        r = lib.lba_shard_finish(self._h, lam, C.byref(chi), C.byref(sc))
+        """returns (solved, chi2_local_new, scale_poses, scale_landmarks_local)"""
+        chi, sp, sl = C.c_double(), C.c_double(), C.c_double()
+        r = lib.lba_shard_finish(self._h, lam, C.byref(chi), C.byref(sp), C.byref(sl))
         _check(min(r, 0))
-        return r, chi.value, sc.value
+        return r, chi.value, sp.value, sl.value
 
     def accept(self, ok):
         _check(lib.lba_shard_accept(self._h, int(ok)))
+
+    def reset(self):
+        lib.lba_shard_reset.argtypes = [C.c_void_p]
+        _check(lib.lba_shard_reset(self._h))
 
     def download(self):
         k = self._pr._keep

@@ -1,0 +1,1020 @@
+// lba_solver.hip -- gfx950 kernels + C ABI for the numerical core of Optimizer::LocalBundleAdjustment
+// (reference src/Optimizer.cc:1116-1498) = g2o Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:61-194)
+// over EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ edges with Huber kernels and BlockSolver_6_3 with Schur
+// complement (block_solver.hpp:354-604).  All arithmetic is f64 like g2o.
+//
+// Device data (SoA, HBM): poses [P][7] (qx qy qz qw tx ty tz), points [L][3], edges in caller order, CSR of the
+// edges of every landmark and of every non-fixed pose, and a CSR "pair list": for every non-zero 6x6 block (i<=j)
+// of the reduced camera system, the (edge_a, edge_b) pairs of landmarks seen by both poses.
+//
+// One LM trial:
+//   k_schur_landmarks  D^-1 = (Hll + lambda I)^-1, db = D^-1 b_l, Z_e = W_e D^-1          (1 thread / landmark)
+//   k_schur_blocks     S_ij = [Hpp_ii] - sum_pairs Z_a W_b^T ,  b_s = b_p - sum W_e db        (1 wave / block)
+//   (multi-GPU: the caller all-reduces [S | b_s | b_p | diag Hpp] here -- RCCL over xGMI)
+//   k_add_lambda, blocked Cholesky (k_chol_panel / k_chol_update per 60-column step), k_chol_solve
+//   k_backsub_update   x_l = D^-1 (b_l - W^T x_p), trial state = oplus(state, x), scale partials
+//   k_errors           residuals + Huber rho of the trial state; k_reduce sums chi2 / scale deterministically
+// Every reduction is ordered (CSR gather or fixed tree), so results are reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/orbslam3_hip.h"
+
+namespace orbx {
+int fail(int code, const char* fmt, ...);
+}
+using orbx::fail;
+
+#define LBA_HIP(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(ORBX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace lba {
+
+constexpr int NB = 60;      // Cholesky block size (10 poses)
+
+struct Cam { double fx, fy, cx, cy, bf, huber_mono, huber_stereo, dsqr_mono, dsqr_stereo; };
+
+struct Dev {        // device pointers of one problem (passed by value to kernels)
+    int nPoses, nP, nL, nE, n;      // n = 6 nP
+    const int* pose_col;            // [nPoses] column among non-fixed poses or -1
+    const int* col_pose;            // [nP] pose index of column
+    const int* e_point; const int* e_pose; const double* e_obs; const double* e_w; const uint8_t* e_stereo;
+    const int* l_off; const int* l_edge;        // edges of a landmark (caller order)
+    const int* p_off; const int* p_edge;        // edges of a non-fixed pose (by column)
+    const int* b_i; const int* b_j; const int* b_off; const int2* b_pair; int nBlocks;
+    double* Hll; double* bl; double* Hpp; double* bp; double* W; double* Z; double* Dinv; double* db;
+    double* err; double* rho0;      // [nE][3], [nE]
+    double* x;                      // [n + 3 nL]
+    double* part;                   // scale partials [nL + nP]
+    double* scal;                   // [16] scalars: 0 chi2, 1 max diag (poses), 2 max diag (landmarks), 3 scale poses, 4 scale landmarks, 5 chol fail flag
+    Cam cam;
+};
+
+// ---- small SE3 / quaternion helpers (g2o types/se3quat.h, Eigen quaternion formulas) ----
+__device__ __forceinline__ void quat_rotate(const double* q, const double* v, double* out)
+{
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux; uy += uy; uz += uz;
+    out[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+    out[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    out[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+}
+
+__device__ __forceinline__ void pose_map(const double* T, const double* X, double* out)
+{
+    quat_rotate(T, X, out);
+    out[0] += T[4]; out[1] += T[5]; out[2] += T[6];
+}
+
+__device__ __forceinline__ void quat_to_R(const double* q, double* R)
+{
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+__device__ __forceinline__ void quat_normalize(double* q)       // SE3Quat::normalizeRotation
+{
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+__device__ inline void quat_from_R(const double* R, double* q)   // Eigen Quaternion(Matrix3d)
+{
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        double v[3];
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+    }
+}
+
+// VertexSE3Expmap::oplusImpl: est <- SE3Quat::exp(update) * est, update = (omega, upsilon)
+__device__ inline void pose_oplus(const double* T, const double* u, double* out)
+{
+    const double om[3] = {u[0], u[1], u[2]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    double O2[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }   // se3quat.h:237-243 quirk
+    } else {
+        const double a = sin(theta) / theta;
+        const double b = (1 - cos(theta)) / (theta * theta);
+        const double c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 9; i++) {
+            const double I = (i % 4 == 0) ? 1.0 : 0.0;
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    double dq[4], dt[3];
+    quat_from_R(R, dq);
+    quat_normalize(dq);
+    for (int i = 0; i < 3; i++) dt[i] = V[i * 3] * u[3] + V[i * 3 + 1] * u[4] + V[i * 3 + 2] * u[5];
+    // result = exp * T
+    double rt[3];
+    quat_rotate(dq, T + 4, rt);
+    out[4] = dt[0] + rt[0]; out[5] = dt[1] + rt[1]; out[6] = dt[2] + rt[2];
+    out[3] = dq[3] * T[3] - dq[0] * T[0] - dq[1] * T[1] - dq[2] * T[2];
+    out[0] = dq[3] * T[0] + dq[0] * T[3] + dq[1] * T[2] - dq[2] * T[1];
+    out[1] = dq[3] * T[1] + dq[1] * T[3] + dq[2] * T[0] - dq[0] * T[2];
+    out[2] = dq[3] * T[2] + dq[2] * T[3] + dq[0] * T[1] - dq[1] * T[0];
+    quat_normalize(out);
+}
+
+// residual of one edge (EdgeSE3ProjectXYZ::computeError / EdgeStereoSE3ProjectXYZ::computeError)
+__device__ __forceinline__ void edge_residual(const Cam& c, const double* Xc, const double* obs, int stereo, double* r)
+{
+    if (!stereo) {
+        r[0] = obs[0] - (c.fx * Xc[0] / Xc[2] + c.cx);
+        r[1] = obs[1] - (c.fy * Xc[1] / Xc[2] + c.cy);
+        r[2] = 0;
+    } else {
+        const float invz = 1.0f / (float)Xc[2];          // float quirk (types_six_dof_expmap.cpp:191)
+        const double u = Xc[0] * (double)invz * c.fx + c.cx;
+        const double v = Xc[1] * (double)invz * c.fy + c.cy;
+        const double ur = u - (double)((float)c.bf * invz);
+        r[0] = obs[0] - u; r[1] = obs[1] - v; r[2] = obs[2] - ur;
+    }
+}
+
+__device__ __forceinline__ void huber(const Cam& c, int stereo, double chi, double& rho0, double& rho1)
+{
+    const double delta = stereo ? c.huber_stereo : c.huber_mono;
+    const double dsqr = stereo ? c.dsqr_stereo : c.dsqr_mono;
+    if (delta <= 0 || chi <= dsqr) { rho0 = chi; rho1 = 1.0; }
+    else { const double s = sqrt(chi); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+// Jacobians of one edge: Ji (D x 3, point) and Jj (D x 6, pose), rows padded to 3
+__device__ inline void edge_jacobians(const Cam& c, const double* T, const double* Xc, int stereo, double* Ji, double* Jj)
+{
+    double R[9];
+    quat_to_R(T, R);
+    const double x = Xc[0], y = Xc[1], z = Xc[2];
+    if (!stereo) {
+        const double p00 = -(c.fx / z), p02 = c.fx * x / (z * z), p11 = -(c.fy / z), p12 = c.fy * y / (z * z);    // -projectJac
+        for (int k = 0; k < 3; k++) {
+            Ji[k] = p00 * R[k] + p02 * R[6 + k];
+            Ji[3 + k] = p11 * R[3 + k] + p12 * R[6 + k];
+            Ji[6 + k] = 0;
+        }
+        // SE3deriv rows: [0 z -y 1 0 0; -z 0 x 0 1 0; y -x 0 0 0 1]
+        Jj[0] = p02 * y;            Jj[1] = p00 * z + p02 * (-x); Jj[2] = p00 * (-y);
+        Jj[3] = p00;                Jj[4] = 0;                    Jj[5] = p02;
+        Jj[6] = p11 * (-z) + p12 * y; Jj[7] = p12 * (-x);         Jj[8] = p11 * x;
+        Jj[9] = 0;                  Jj[10] = p11;                 Jj[11] = p12;
+        for (int k = 12; k < 18; k++) Jj[k] = 0;
+    } else {
+        const double z2 = z * z, fx = c.fx, fy = c.fy, bf = c.bf;
+        Ji[0] = -fx * R[0] / z + fx * x * R[6] / z2; Ji[1] = -fx * R[1] / z + fx * x * R[7] / z2; Ji[2] = -fx * R[2] / z + fx * x * R[8] / z2;
+        Ji[3] = -fy * R[3] / z + fy * y * R[6] / z2; Ji[4] = -fy * R[4] / z + fy * y * R[7] / z2; Ji[5] = -fy * R[5] / z + fy * y * R[8] / z2;
+        Ji[6] = Ji[0] - bf * R[6] / z2; Ji[7] = Ji[1] - bf * R[7] / z2; Ji[8] = Ji[2] - bf * R[8] / z2;
+        Jj[0] = x * y / z2 * fx;  Jj[1] = -(1 + (x * x / z2)) * fx; Jj[2] = y / z * fx;  Jj[3] = -1. / z * fx; Jj[4] = 0; Jj[5] = x / z2 * fx;
+        Jj[6] = (1 + y * y / z2) * fy; Jj[7] = -x * y / z2 * fy; Jj[8] = -x / z * fy; Jj[9] = 0; Jj[10] = -1. / z * fy; Jj[11] = y / z2 * fy;
+        Jj[12] = Jj[0] - bf * y / z2; Jj[13] = Jj[1] + bf * x / z2; Jj[14] = Jj[2]; Jj[15] = Jj[3]; Jj[16] = 0; Jj[17] = Jj[5] - bf / z2;
+    }
+}
+
+// ---- errors of a state (SparseOptimizer::computeActiveErrors + per-edge robust chi2) ----
+__global__ __launch_bounds__(256) void k_errors(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.nE) return;
+    double Xc[3], r[3];
+    pose_map(poses + 7 * (size_t)d.e_pose[e], pts + 3 * (size_t)d.e_point[e], Xc);
+    const int st = d.e_stereo[e];
+    edge_residual(d.cam, Xc, d.e_obs + 3 * (size_t)e, st, r);
+    const double w = d.e_w[e];
+    double chi = r[0] * (w * r[0]) + r[1] * (w * r[1]);
+    if (st) chi += r[2] * (w * r[2]);
+    double rho0, rho1;
+    huber(d.cam, st, chi, rho0, rho1);
+    d.err[3 * (size_t)e] = r[0]; d.err[3 * (size_t)e + 1] = r[1]; d.err[3 * (size_t)e + 2] = r[2];
+    d.rho0[e] = rho0;
+}
+
+// ---- buildSystem, landmark side: Hll, bl and the Hpl blocks W_e = B^T (rho1 Omega) A (6x3) ----
+__global__ __launch_bounds__(64) void k_lin_landmarks(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+{
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= d.nL) return;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    const double* X = pts + 3 * (size_t)l;
+    for (int k = d.l_off[l]; k < d.l_off[l + 1]; k++) {
+        const int e = d.l_edge[k];
+        const int ip = d.e_pose[e];
+        const double* T = poses + 7 * (size_t)ip;
+        const int st = d.e_stereo[e];
+        const int D = st ? 3 : 2;
+        double Xc[3], Ji[9], Jj[18];
+        pose_map(T, X, Xc);
+        edge_jacobians(d.cam, T, Xc, st, Ji, Jj);
+        const double* r = d.err + 3 * (size_t)e;
+        const double w = d.e_w[e];
+        double chi = r[0] * (w * r[0]) + r[1] * (w * r[1]);
+        if (st) chi += r[2] * (w * r[2]);
+        double rho0, rho1;
+        huber(d.cam, st, chi, rho0, rho1);
+        const double wr = rho1 * w;
+        double orr[3];
+        for (int q = 0; q < 3; q++) orr[q] = (-(w * r[q])) * rho1;
+        for (int a = 0; a < 3; a++) {
+            double s = 0;
+            for (int q = 0; q < D; q++) s += Ji[q * 3 + a] * orr[q];
+            b[a] += s;
+            for (int c = 0; c < 3; c++) {
+                double h = 0;
+                for (int q = 0; q < D; q++) h += Ji[q * 3 + a] * wr * Ji[q * 3 + c];
+                H[a * 3 + c] += h;
+            }
+        }
+        if (d.pose_col[ip] >= 0) {
+            double* W = d.W + 18 * (size_t)e;
+            for (int a = 0; a < 6; a++)
+                for (int c = 0; c < 3; c++) {
+                    double h = 0;
+                    for (int q = 0; q < D; q++) h += Jj[q * 6 + a] * wr * Ji[q * 3 + c];
+                    W[a * 3 + c] = h;
+                }
+        }
+    }
+    for (int k = 0; k < 9; k++) d.Hll[9 * (size_t)l + k] = H[k];
+    for (int k = 0; k < 3; k++) d.bl[3 * (size_t)l + k] = b[k];
+}
+
+// ---- buildSystem, pose side: Hpp (6x6) and bp; one wave per non-fixed pose, ordered tree reduction ----
+__global__ __launch_bounds__(64) void k_lin_poses(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+{
+    const int col = blockIdx.x, lane = threadIdx.x;
+    const int ip = d.col_pose[col];
+    const double* T = poses + 7 * (size_t)ip;
+    double acc[27];      // 21 upper-triangular entries of Hpp + 6 of bp
+    for (int k = 0; k < 27; k++) acc[k] = 0;
+    for (int k = d.p_off[col] + lane; k < d.p_off[col + 1]; k += 64) {
+        const int e = d.p_edge[k];
+        const int st = d.e_stereo[e];
+        const int D = st ? 3 : 2;
+        double Xc[3], Ji[9], Jj[18];
+        pose_map(T, pts + 3 * (size_t)d.e_point[e], Xc);
+        edge_jacobians(d.cam, T, Xc, st, Ji, Jj);
+        const double* r = d.err + 3 * (size_t)e;
+        const double w = d.e_w[e];
+        double chi = r[0] * (w * r[0]) + r[1] * (w * r[1]);
+        if (st) chi += r[2] * (w * r[2]);
+        double rho0, rho1;
+        huber(d.cam, st, chi, rho0, rho1);
+        const double wr = rho1 * w;
+        int idx = 0;
+        for (int a = 0; a < 6; a++)
+            for (int c = a; c < 6; c++, idx++) {
+                double h = 0;
+                for (int q = 0; q < D; q++) h += Jj[q * 6 + a] * wr * Jj[q * 6 + c];
+                acc[idx] += h;
+            }
+        for (int a = 0; a < 6; a++) {
+            double s = 0;
+            for (int q = 0; q < D; q++) s += Jj[q * 6 + a] * ((-(w * r[q])) * rho1);
+            acc[21 + a] += s;
+        }
+    }
+    for (int k = 0; k < 27; k++)
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if (lane == 0) {
+        int idx = 0;
+        double* H = d.Hpp + 36 * (size_t)col;
+        for (int a = 0; a < 6; a++)
+            for (int c = a; c < 6; c++, idx++) { H[a * 6 + c] = acc[idx]; H[c * 6 + a] = acc[idx]; }
+        for (int a = 0; a < 6; a++) d.bp[6 * (size_t)col + a] = acc[21 + a];
+    }
+}
+
+// ---- deterministic scalar reductions (single workgroup) ----
+// mode 0: chi2 = sum rho0, max diagonals.  mode 1: chi2 = sum rho0, scale = sum partials.
+__global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode)
+{
+    __shared__ double s_a[1024], s_b[1024], s_c[1024];
+    const int tid = threadIdx.x;
+    double a = 0, b = 0, c = 0;
+    for (int e = tid; e < d.nE; e += 1024) a += d.rho0[e];
+    if (mode == 0) {
+        for (int i = tid; i < d.nP * 6; i += 1024) b = fmax(b, fabs(d.Hpp[36 * (size_t)(i / 6) + (i % 6) * 7]));
+        for (int i = tid; i < d.nL * 3; i += 1024) c = fmax(c, fabs(d.Hll[9 * (size_t)(i / 3) + (i % 3) * 4]));
+    } else {
+        for (int i = tid; i < d.nP; i += 1024) b += d.part[d.nL + i];
+        for (int i = tid; i < d.nL; i += 1024) c += d.part[i];
+    }
+    s_a[tid] = a; s_b[tid] = b; s_c[tid] = c;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) {
+            s_a[tid] += s_a[tid + o];
+            if (mode == 0) { s_b[tid] = fmax(s_b[tid], s_b[tid + o]); s_c[tid] = fmax(s_c[tid], s_c[tid + o]); }
+            else { s_b[tid] += s_b[tid + o]; s_c[tid] += s_c[tid + o]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        d.scal[0] = s_a[0];
+        if (mode == 0) { d.scal[1] = s_b[0]; d.scal[2] = s_c[0]; }
+        else { d.scal[3] = s_b[0]; d.scal[4] = s_c[0]; }
+    }
+}
+
+// ---- Schur, landmark side (block_solver.hpp:381-395): Dinv, db, Z_e = W_e Dinv ----
+__global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
+{
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= d.nL) return;
+    double A[9];
+    for (int k = 0; k < 9; k++) A[k] = d.Hll[9 * (size_t)l + k] + ((k % 4 == 0) ? lambda : 0.0);
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    const double id = 1.0 / det;
+    double Di[9];
+    Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+    for (int k = 0; k < 9; k++) d.Dinv[9 * (size_t)l + k] = Di[k];
+    const double* b = d.bl + 3 * (size_t)l;
+    for (int a = 0; a < 3; a++) d.db[3 * (size_t)l + a] = Di[a * 3] * b[0] + Di[a * 3 + 1] * b[1] + Di[a * 3 + 2] * b[2];
+    for (int k = d.l_off[l]; k < d.l_off[l + 1]; k++) {
+        const int e = d.l_edge[k];
+        if (d.pose_col[d.e_pose[e]] < 0) continue;
+        const double* W = d.W + 18 * (size_t)e;
+        double* Z = d.Z + 18 * (size_t)e;
+        for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 3; c++) Z[r * 3 + c] = W[r * 3] * Di[c] + W[r * 3 + 1] * Di[3 + c] + W[r * 3 + 2] * Di[6 + c];
+    }
+}
+
+// ---- Schur, pose side: one wave per non-zero block (i<=j) of the reduced camera system ----
+// out: S (n x n, row-major, both triangles), bs (n), plus copies bp and diag(Hpp) for the multi-GPU reduce buffer.
+__global__ __launch_bounds__(64) void k_schur_blocks(Dev d, double* __restrict__ S, double* __restrict__ bs,
+                                                     double* __restrict__ bp_out, double* __restrict__ diag_out)
+{
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    const int i = d.b_i[blk], j = d.b_j[blk];
+    const int n = d.n;
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        double acc = (i == j) ? d.Hpp[36 * (size_t)i + lane] : 0.0;
+        for (int k = d.b_off[blk]; k < d.b_off[blk + 1]; k++) {
+            const int2 pr = d.b_pair[k];
+            const double* Z = d.Z + 18 * (size_t)pr.x + r * 3;
+            const double* W = d.W + 18 * (size_t)pr.y + c * 3;
+            acc -= Z[0] * W[0] + Z[1] * W[1] + Z[2] * W[2];
+        }
+        S[(size_t)(6 * i + r) * n + 6 * j + c] = acc;
+        if (i != j) S[(size_t)(6 * j + c) * n + 6 * i + r] = acc;
+    } else if (i == j && lane < 42) {
+        const int r = lane - 36;
+        double acc = d.bp[6 * (size_t)i + r];
+        for (int k = d.p_off[i]; k < d.p_off[i + 1]; k++) {
+            const int e = d.p_edge[k];
+            const double* W = d.W + 18 * (size_t)e + r * 3;
+            const double* db = d.db + 3 * (size_t)d.e_point[e];
+            acc -= W[0] * db[0] + W[1] * db[1] + W[2] * db[2];
+        }
+        bs[6 * i + r] = acc;
+        bp_out[6 * i + r] = d.bp[6 * (size_t)i + r];
+        diag_out[6 * i + r] = d.Hpp[36 * (size_t)i + r * 7];
+    }
+}
+
+__global__ void k_add_lambda(double* S, int n, double lambda)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) S[(size_t)i * n + i] += lambda;
+}
+
+// ---- blocked right-looking Cholesky of the (dense, small) reduced camera system, lower triangle ----
+// panel: every workgroup re-factors the diagonal block in LDS (nb^3/3 flops, trivial) and solves its slice of the
+// rows below: X L^T = A.  Workgroup 0 also writes L_kk and its inverse (used by the block substitutions).
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int n, int k0, int nb, double* __restrict__ Linv, double* __restrict__ scal)
+{
+    __shared__ double sL[NB * (NB + 1)];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int P = NB + 1;
+    if (tid == 0) s_fail = 0;
+    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i % nb; sL[r * P + c] = S[(size_t)(k0 + r) * n + k0 + c]; }
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+        if (tid == 0) {
+            const double dj = sL[j * P + j];
+            if (!(dj > 0.0) || !isfinite(dj)) s_fail = 1;
+            sL[j * P + j] = sqrt(dj);
+        }
+        __syncthreads();
+        if (s_fail) break;
+        const double ljj = sL[j * P + j];
+        for (int r = j + 1 + tid; r < nb; r += 256) sL[r * P + j] /= ljj;
+        __syncthreads();
+        // trailing update of the diagonal block: (r, c) with j < c <= r
+        const int m = nb - j - 1;
+        for (int i = tid; i < m * m; i += 256) {
+            const int r = j + 1 + i / m, c = j + 1 + i % m;
+            if (c <= r) sL[r * P + c] -= sL[r * P + j] * sL[c * P + j];
+        }
+        __syncthreads();
+    }
+    if (s_fail) { if (tid == 0 && blockIdx.x == 0) scal[5] = 1.0; return; }
+    if (blockIdx.x == 0) {
+        // L_kk itself is NOT written back: other workgroups are still reading the unfactored block, and later steps
+        // only need its inverse.  inverse of L_kk: thread c solves L y = e_c
+        if (tid < nb) {
+            double* Li = Linv + (size_t)(k0 / NB) * NB * NB;
+            const int c = tid;
+            for (int r = 0; r < nb; r++) {
+                double s = (r == c) ? 1.0 : 0.0;
+                for (int q = c; q < r; q++) s -= sL[r * P + q] * Li[q * NB + c];
+                Li[r * NB + c] = (r < c) ? 0.0 : s / sL[r * P + r];
+            }
+        }
+    }
+    // rows below the diagonal block: one thread per row
+    const int row = k0 + nb + blockIdx.x * 256 + tid;
+    if (row < n) {
+        double* a = S + (size_t)row * n + k0;
+        for (int j = 0; j < nb; j++) {
+            double s = a[j];
+            for (int q = 0; q < j; q++) s -= a[q] * sL[j * P + q];
+            a[j] = s / sL[j * P + j];
+        }
+    }
+}
+
+// trailing update S22 -= L21 L21^T (lower triangle), 32x32 tiles, panel rows staged in LDS
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb)
+{
+    __shared__ double sA[32 * (NB + 1)], sB[32 * (NB + 1)];
+    const int base = k0 + nb;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int r0 = base + ti * 32, c0 = base + tj * 32;
+    const int tid = threadIdx.x, P = NB + 1;
+    for (int i = tid; i < 32 * nb; i += 256) {
+        const int r = i / nb, q = i % nb;
+        sA[r * P + q] = (r0 + r < n) ? S[(size_t)(r0 + r) * n + k0 + q] : 0.0;
+        sB[r * P + q] = (c0 + r < n) ? S[(size_t)(c0 + r) * n + k0 + q] : 0.0;
+    }
+    __syncthreads();
+    const int tr = tid / 32, tc = tid % 32;
+    for (int rr = tr; rr < 32; rr += 8) {
+        const int r = r0 + rr, c = c0 + tc;
+        if (r < n && c < n && c <= r) {
+            double s = 0;
+            for (int q = 0; q < nb; q++) s += sA[rr * P + q] * sB[tc * P + q];
+            S[(size_t)r * n + c] -= s;
+        }
+    }
+}
+
+// x = L^-T L^-1 b by block substitution with the inverted diagonal blocks; one workgroup.
+__global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ S, int n, const double* __restrict__ Linv,
+                                                     const double* __restrict__ b, double* __restrict__ x)
+{
+    extern __shared__ double sm[];      // y[n], tmp[n]
+    double* y = sm;
+    double* t = sm + n;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 1024) y[i] = b[i];
+    __syncthreads();
+    const int nblk = (n + NB - 1) / NB;
+    // forward: y_K = Linv_KK (b_K - sum_{J<K} L_KJ y_J)
+    for (int K = 0; K < nblk; K++) {
+        const int k0 = K * NB, nb = min(NB, n - k0);
+        for (int r = tid; r < nb; r += 1024) {
+            double s = y[k0 + r];
+            const double* Lr = S + (size_t)(k0 + r) * n;
+            for (int q = 0; q < k0; q++) s -= Lr[q] * y[q];
+            t[r] = s;
+        }
+        __syncthreads();
+        const double* Li = Linv + (size_t)K * NB * NB;
+        for (int r = tid; r < nb; r += 1024) {
+            double s = 0;
+            for (int q = 0; q <= r; q++) s += Li[r * NB + q] * t[q];
+            y[k0 + r] = s;
+        }
+        __syncthreads();
+    }
+    // backward: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J)
+    for (int K = nblk - 1; K >= 0; K--) {
+        const int k0 = K * NB, nb = min(NB, n - k0);
+        for (int r = tid; r < nb; r += 1024) {
+            double s = y[k0 + r];
+            for (int q = k0 + nb; q < n; q++) s -= S[(size_t)q * n + k0 + r] * y[q];
+            t[r] = s;
+        }
+        __syncthreads();
+        const double* Li = Linv + (size_t)K * NB * NB;
+        for (int r = tid; r < nb; r += 1024) {
+            double s = 0;
+            for (int q = r; q < nb; q++) s += Li[q * NB + r] * t[q];
+            y[k0 + r] = s;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 1024) x[i] = y[i];
+}
+
+// ---- landmark back-substitution, trial update (oplus) and scale partials (levenberg.cpp:187-194) ----
+__global__ __launch_bounds__(64) void k_backsub_update(Dev d, double lambda, const double* __restrict__ bp_full,
+                                                       const double* __restrict__ poses, const double* __restrict__ pts,
+                                                       double* __restrict__ poses_new, double* __restrict__ pts_new)
+{
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g < d.nL) {
+        const int l = g;
+        double c[3] = {d.bl[3 * (size_t)l], d.bl[3 * (size_t)l + 1], d.bl[3 * (size_t)l + 2]};
+        for (int k = d.l_off[l]; k < d.l_off[l + 1]; k++) {
+            const int e = d.l_edge[k];
+            const int col = d.pose_col[d.e_pose[e]];
+            if (col < 0) continue;
+            const double* W = d.W + 18 * (size_t)e;
+            const double* xp = d.x + 6 * (size_t)col;
+            for (int q = 0; q < 3; q++) {
+                double s = 0;
+                for (int r = 0; r < 6; r++) s += W[r * 3 + q] * xp[r];
+                c[q] -= s;
+            }
+        }
+        const double* Di = d.Dinv + 9 * (size_t)l;
+        double sc = 0;
+        for (int a = 0; a < 3; a++) {
+            const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
+            d.x[(size_t)d.n + 3 * (size_t)l + a] = xl;
+            pts_new[3 * (size_t)l + a] = pts[3 * (size_t)l + a] + xl;
+            sc += xl * (lambda * xl + d.bl[3 * (size_t)l + a]);
+        }
+        d.part[l] = sc;
+    } else if (g < d.nL + d.nPoses) {
+        const int ip = g - d.nL;
+        const int col = d.pose_col[ip];
+        if (col < 0) {
+            for (int k = 0; k < 7; k++) poses_new[7 * (size_t)ip + k] = poses[7 * (size_t)ip + k];
+        } else {
+            const double* xp = d.x + 6 * (size_t)col;
+            pose_oplus(poses + 7 * (size_t)ip, xp, poses_new + 7 * (size_t)ip);
+            double sc = 0;
+            for (int a = 0; a < 6; a++) sc += xp[a] * (lambda * xp[a] + bp_full[6 * (size_t)col + a]);
+            d.part[d.nL + col] = sc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_epilogue(Dev d, const double* __restrict__ poses, const double* __restrict__ pts,
+                                                  double* __restrict__ chi2, uint8_t* __restrict__ depth_pos)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.nE) return;
+    const double* r = d.err + 3 * (size_t)e;
+    const double w = d.e_w[e];
+    double chi = r[0] * (w * r[0]) + r[1] * (w * r[1]);
+    if (d.e_stereo[e]) chi += r[2] * (w * r[2]);
+    chi2[e] = chi;
+    double Xc[3];
+    pose_map(poses + 7 * (size_t)d.e_pose[e], pts + 3 * (size_t)d.e_point[e], Xc);
+    depth_pos[e] = Xc[2] > 0.0;
+}
+
+__global__ void k_normalize_poses(double* poses, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) quat_normalize(poses + 7 * (size_t)i);       // SE3Quat(Quaterniond, Vector3d) ctor (Optimizer.cc:1217)
+}
+
+}  // namespace lba
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct lba_shard {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    lba::Dev d;
+    int nblk = 0;
+    std::vector<void*> allocs;
+    double *poses[2] = {nullptr, nullptr}, *pts[2] = {nullptr, nullptr};
+    double *poses0 = nullptr, *pts0 = nullptr;      // initial estimates (lba_shard_reset)
+    int cur = 0;                // index of the accepted state; 1-cur holds the trial state
+    double* reduce = nullptr;   // [n*n | bs n | bp n | diag n]
+    double* Linv = nullptr;
+    double* d_chi2 = nullptr;
+    uint8_t* d_depth = nullptr;
+    double* h_scal = nullptr;   // pinned [16]
+    int64_t reduce_len = 0;
+    bool err_valid = false;
+
+    template <typename T>
+    int dalloc(T** p, size_t count)
+    {
+        *p = nullptr;
+        LBA_HIP(hipMalloc((void**)p, std::max(count, (size_t)1) * sizeof(T)));
+        allocs.push_back(*p);
+        return ORBX_OK;
+    }
+    template <typename T>
+    int upload(const T** p, const std::vector<T>& v)
+    {
+        T* q;
+        int r = dalloc(&q, v.size());
+        if (r) return r;
+        if (!v.empty()) LBA_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        *p = q;
+        return ORBX_OK;
+    }
+    double* S() { return reduce; }
+    double* bs() { return reduce + (size_t)d.n * d.n; }
+    double* bpf() { return reduce + (size_t)d.n * d.n + d.n; }
+    double* diag() { return reduce + (size_t)d.n * d.n + 2 * (size_t)d.n; }
+};
+
+static int shard_validate(const LbaProblem* p)
+{
+    if (!p) return fail(ORBX_ERR_ARG, "NULL problem");
+    if (p->n_poses < 1 || p->n_points < 0 || p->n_edges < 0) return fail(ORBX_ERR_ARG, "bad problem sizes");
+    if (!p->pose_q || !p->pose_t || !p->pose_fixed) return fail(ORBX_ERR_ARG, "NULL pose arrays");
+    if (p->n_points > 0 && !p->points) return fail(ORBX_ERR_ARG, "NULL points");
+    if (p->n_edges > 0 && (!p->edge_point || !p->edge_pose || !p->edge_obs || !p->edge_inv_sigma2 || !p->edge_stereo))
+        return fail(ORBX_ERR_ARG, "NULL edge arrays");
+    for (int e = 0; e < p->n_edges; e++)
+        if (p->edge_point[e] < 0 || p->edge_point[e] >= p->n_points || p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses)
+            return fail(ORBX_ERR_ARG, "edge %d references vertex out of range", e);
+    return ORBX_OK;
+}
+
+extern "C" {
+
+int lba_shard_create(int device, const LbaProblem* p, lba_shard** out)
+{
+    if (!out) return fail(ORBX_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int r = shard_validate(p);
+    if (r) return r;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ORBX_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(ORBX_ERR_ARG, "device %d out of range", device);
+    LBA_HIP(hipSetDevice(device));
+    lba_shard* s = new lba_shard();
+    s->device = device;
+    std::memset(&s->d, 0, sizeof(s->d));
+    lba::Dev& d = s->d;
+    d.nPoses = p->n_poses; d.nL = p->n_points; d.nE = p->n_edges;
+    std::vector<int> pose_col(p->n_poses, -1), col_pose;
+    for (int i = 0; i < p->n_poses; i++) if (!p->pose_fixed[i]) { pose_col[i] = (int)col_pose.size(); col_pose.push_back(i); }
+    d.nP = (int)col_pose.size();
+    d.n = 6 * d.nP;
+    // CSR by landmark / by pose column (caller order inside)
+    std::vector<int> l_off(d.nL + 1, 0), p_off(d.nP + 1, 0);
+    for (int e = 0; e < d.nE; e++) { l_off[p->edge_point[e] + 1]++; const int c = pose_col[p->edge_pose[e]]; if (c >= 0) p_off[c + 1]++; }
+    for (int l = 0; l < d.nL; l++) l_off[l + 1] += l_off[l];
+    for (int c = 0; c < d.nP; c++) p_off[c + 1] += p_off[c];
+    std::vector<int> l_edge(std::max(d.nE, 1)), p_edge(std::max(p_off[d.nP], 1)), lc(l_off.begin(), l_off.end() - 1), pc(p_off.begin(), p_off.end() - 1);
+    for (int e = 0; e < d.nE; e++) { l_edge[lc[p->edge_point[e]]++] = e; const int c = pose_col[p->edge_pose[e]]; if (c >= 0) p_edge[pc[c]++] = e; }
+    // pair list per block (i <= j)
+    std::vector<int64_t> cnt((size_t)d.nP * d.nP, 0);
+    for (int l = 0; l < d.nL; l++)
+        for (int a = l_off[l]; a < l_off[l + 1]; a++) {
+            const int i = pose_col[p->edge_pose[l_edge[a]]];
+            if (i < 0) continue;
+            for (int b = l_off[l]; b < l_off[l + 1]; b++) {
+                const int j = pose_col[p->edge_pose[l_edge[b]]];
+                if (j < 0 || j < i) continue;
+                cnt[(size_t)i * d.nP + j]++;
+            }
+        }
+    std::vector<int> b_i, b_j, b_off(1, 0);
+    std::vector<int64_t> blk_of((size_t)d.nP * d.nP, -1);
+    for (int i = 0; i < d.nP; i++)
+        for (int j = i; j < d.nP; j++)
+            if (i == j || cnt[(size_t)i * d.nP + j] > 0) {
+                blk_of[(size_t)i * d.nP + j] = (int64_t)b_i.size();
+                b_i.push_back(i); b_j.push_back(j);
+                b_off.push_back(b_off.back() + (int)cnt[(size_t)i * d.nP + j]);
+            }
+    d.nBlocks = (int)b_i.size();
+    std::vector<int2> pairs(std::max(b_off.back(), 1));
+    std::vector<int> bc(b_off.begin(), b_off.end() - 1);
+    for (int l = 0; l < d.nL; l++)
+        for (int a = l_off[l]; a < l_off[l + 1]; a++) {
+            const int i = pose_col[p->edge_pose[l_edge[a]]];
+            if (i < 0) continue;
+            for (int b = l_off[l]; b < l_off[l + 1]; b++) {
+                const int j = pose_col[p->edge_pose[l_edge[b]]];
+                if (j < 0 || j < i) continue;
+                int2 pr; pr.x = l_edge[a]; pr.y = l_edge[b];
+                pairs[bc[blk_of[(size_t)i * d.nP + j]]++] = pr;
+            }
+        }
+    std::vector<int> e_point(p->edge_point, p->edge_point + d.nE), e_pose(p->edge_pose, p->edge_pose + d.nE);
+    std::vector<double> e_obs(p->edge_obs, p->edge_obs + 3 * (size_t)d.nE), e_w(p->edge_inv_sigma2, p->edge_inv_sigma2 + d.nE);
+    std::vector<uint8_t> e_st(p->edge_stereo, p->edge_stereo + d.nE);
+    std::vector<double> poses(7 * (size_t)p->n_poses);
+    for (int i = 0; i < p->n_poses; i++) {
+        for (int k = 0; k < 4; k++) poses[7 * i + k] = p->pose_q[4 * i + k];
+        for (int k = 0; k < 3; k++) poses[7 * i + 4 + k] = p->pose_t[3 * i + k];
+    }
+#define LBA_TRY(x) do { r = (x); if (r) { lba_shard_destroy(s); return r; } } while (0)
+    LBA_TRY(s->upload(&d.pose_col, pose_col)); LBA_TRY(s->upload(&d.col_pose, col_pose));
+    LBA_TRY(s->upload(&d.e_point, e_point)); LBA_TRY(s->upload(&d.e_pose, e_pose)); LBA_TRY(s->upload(&d.e_obs, e_obs));
+    LBA_TRY(s->upload(&d.e_w, e_w)); LBA_TRY(s->upload(&d.e_stereo, e_st));
+    LBA_TRY(s->upload(&d.l_off, l_off)); LBA_TRY(s->upload(&d.l_edge, l_edge)); LBA_TRY(s->upload(&d.p_off, p_off)); LBA_TRY(s->upload(&d.p_edge, p_edge));
+    LBA_TRY(s->upload(&d.b_i, b_i)); LBA_TRY(s->upload(&d.b_j, b_j)); LBA_TRY(s->upload(&d.b_off, b_off)); LBA_TRY(s->upload(&d.b_pair, pairs));
+    LBA_TRY(s->dalloc(&d.Hll, 9 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.bl, 3 * (size_t)d.nL));
+    LBA_TRY(s->dalloc(&d.Hpp, 36 * (size_t)d.nP)); LBA_TRY(s->dalloc(&d.bp, 6 * (size_t)d.nP));
+    LBA_TRY(s->dalloc(&d.W, 18 * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.Z, 18 * (size_t)d.nE));
+    LBA_TRY(s->dalloc(&d.Dinv, 9 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.db, 3 * (size_t)d.nL));
+    LBA_TRY(s->dalloc(&d.err, 3 * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.rho0, (size_t)d.nE));
+    LBA_TRY(s->dalloc(&d.x, (size_t)d.n + 3 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.part, (size_t)d.nL + d.nP));
+    LBA_TRY(s->dalloc(&d.scal, 16));
+    for (int k = 0; k < 2; k++) { LBA_TRY(s->dalloc(&s->poses[k], 7 * (size_t)p->n_poses)); LBA_TRY(s->dalloc(&s->pts[k], 3 * (size_t)d.nL)); }
+    s->reduce_len = (int64_t)d.n * d.n + 3 * (int64_t)d.n;
+    LBA_TRY(s->dalloc(&s->reduce, (size_t)s->reduce_len));
+    s->nblk = (d.n + lba::NB - 1) / lba::NB;
+    LBA_TRY(s->dalloc(&s->Linv, (size_t)std::max(s->nblk, 1) * lba::NB * lba::NB));
+    LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
+    if (hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "stream create failed"); }
+#undef LBA_TRY
+    LBA_HIP(hipMemcpy(s->poses[0], poses.data(), poses.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (d.nL > 0) LBA_HIP(hipMemcpy(s->pts[0], p->points, 3 * (size_t)d.nL * sizeof(double), hipMemcpyHostToDevice));
+    LBA_HIP(hipMemset(d.err, 0, 3 * (size_t)std::max(d.nE, 1) * sizeof(double)));
+    LBA_HIP(hipMemset(d.scal, 0, 16 * sizeof(double)));
+    d.cam.fx = p->fx; d.cam.fy = p->fy; d.cam.cx = p->cx; d.cam.cy = p->cy; d.cam.bf = p->bf;
+    d.cam.huber_mono = p->huber_mono; d.cam.huber_stereo = p->huber_stereo;
+    d.cam.dsqr_mono = p->huber_mono * p->huber_mono; d.cam.dsqr_stereo = p->huber_stereo * p->huber_stereo;    // RobustKernelHuber::setDelta
+    hipLaunchKernelGGL(lba::k_normalize_poses, dim3((p->n_poses + 63) / 64), dim3(64), 0, s->stream, s->poses[0], p->n_poses);
+    LBA_HIP(hipStreamSynchronize(s->stream));
+    if ((r = s->dalloc(&s->poses0, 7 * (size_t)p->n_poses)) || (r = s->dalloc(&s->pts0, 3 * (size_t)d.nL))) { lba_shard_destroy(s); return r; }
+    LBA_HIP(hipMemcpy(s->poses0, s->poses[0], 7 * (size_t)p->n_poses * sizeof(double), hipMemcpyDeviceToDevice));
+    if (d.nL > 0) LBA_HIP(hipMemcpy(s->pts0, s->pts[0], 3 * (size_t)d.nL * sizeof(double), hipMemcpyDeviceToDevice));
+    *out = s;
+    return ORBX_OK;
+}
+
+// restore the initial estimates (lets a benchmark re-run the optimisation without re-uploading the problem)
+int lba_shard_reset(lba_shard* s)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    s->cur = 0;
+    LBA_HIP(hipMemcpyAsync(s->poses[0], s->poses0, 7 * (size_t)s->d.nPoses * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    if (s->d.nL > 0) LBA_HIP(hipMemcpyAsync(s->pts[0], s->pts0, 3 * (size_t)s->d.nL * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    LBA_HIP(hipMemsetAsync(s->d.err, 0, 3 * (size_t)std::max(s->d.nE, 1) * sizeof(double), s->stream));
+    return ORBX_OK;
+}
+
+void lba_shard_destroy(lba_shard* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->h_scal) (void)hipHostFree(s->h_scal);
+    delete s;
+}
+
+int64_t lba_shard_reduce_len(const lba_shard* s) { return s ? s->reduce_len : 0; }
+double* lba_shard_reduce_buffer(lba_shard* s) { return s ? s->reduce : nullptr; }
+
+// Lets the caller own the reduce buffer (e.g. a torch.float64 CUDA tensor that torch.distributed all-reduces in place).
+int lba_shard_set_reduce_buffer(lba_shard* s, double* device_buffer)
+{
+    if (!s || !device_buffer) return fail(ORBX_ERR_ARG, "NULL argument");
+    s->reduce = device_buffer;
+    return ORBX_OK;
+}
+
+static int read_scalars(lba_shard* s)
+{
+    LBA_HIP(hipMemcpyAsync(s->h_scal, s->d.scal, 16 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    LBA_HIP(hipStreamSynchronize(s->stream));
+    return ORBX_OK;
+}
+
+// computeActiveErrors + activeRobustChi2 + buildSystem on the accepted state
+int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses_local, double* max_diag_landmarks_local)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    const lba::Dev& d = s->d;
+    const double* P = s->poses[s->cur];
+    const double* X = s->pts[s->cur];
+    if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, P, X);
+    if (d.nL > 0) hipLaunchKernelGGL(lba::k_lin_landmarks, dim3((d.nL + 63) / 64), dim3(64), 0, s->stream, d, P, X);
+    if (d.nP > 0) hipLaunchKernelGGL(lba::k_lin_poses, dim3(d.nP), dim3(64), 0, s->stream, d, P, X);
+    hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0);
+    LBA_HIP(hipGetLastError());
+    int r = read_scalars(s);
+    if (r) return r;
+    s->err_valid = true;
+    if (chi2_local) *chi2_local = s->h_scal[0];
+    if (max_diag_poses_local) *max_diag_poses_local = s->h_scal[1];
+    if (max_diag_landmarks_local) *max_diag_landmarks_local = s->h_scal[2];
+    return ORBX_OK;
+}
+
+// partial Schur complement of this shard's landmarks into the reduce buffer (lambda enters through Hll only)
+int lba_shard_reduce(lba_shard* s, double lambda)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    const lba::Dev& d = s->d;
+    LBA_HIP(hipMemsetAsync(s->reduce, 0, (size_t)s->reduce_len * sizeof(double), s->stream));
+    if (d.nL > 0) hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 63) / 64), dim3(64), 0, s->stream, d, lambda);
+    if (d.nBlocks > 0) hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks), dim3(64), 0, s->stream, d, s->S(), s->bs(), s->bpf(), s->diag());
+    LBA_HIP(hipGetLastError());
+    LBA_HIP(hipStreamSynchronize(s->stream));      // the caller may hand the buffer to RCCL on another stream
+    return ORBX_OK;
+}
+
+// (after the caller's all-reduce) S += lambda I, solve, back-substitute, trial update, errors of the trial state.
+// returns 1 when the linear solve succeeded, 0 when the reduced system was not positive definite.
+int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double* scale_poses, double* scale_landmarks_local)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    const lba::Dev& d = s->d;
+    const int n = d.n;
+    const double* P = s->poses[s->cur];
+    const double* X = s->pts[s->cur];
+    double* Pn = s->poses[1 - s->cur];
+    double* Xn = s->pts[1 - s->cur];
+    LBA_HIP(hipMemsetAsync(d.scal + 5, 0, sizeof(double), s->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(lba::k_add_lambda, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->S(), n, lambda);
+        for (int K = 0; K < s->nblk; K++) {
+            const int k0 = K * lba::NB, nb = std::min(lba::NB, n - k0);
+            const int rows_below = n - k0 - nb;
+            hipLaunchKernelGGL(lba::k_chol_panel, dim3(std::max((rows_below + 255) / 256, 1)), dim3(256), 0, s->stream, s->S(), n, k0, nb, s->Linv, d.scal);
+            if (rows_below > 0) {
+                const int t = (rows_below + 31) / 32;
+                hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, k0, nb);
+            }
+        }
+        hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), 2 * (size_t)n * sizeof(double), s->stream, s->S(), n, s->Linv, s->bs(), d.x);
+    }
+    hipLaunchKernelGGL(lba::k_backsub_update, dim3((d.nL + d.nPoses + 63) / 64), dim3(64), 0, s->stream, d, lambda, s->bpf(), P, X, Pn, Xn);
+    if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, (const double*)Pn, (const double*)Xn);
+    hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 1);
+    LBA_HIP(hipGetLastError());
+    int r = read_scalars(s);
+    if (r) return r;
+    if (chi2_local_new) *chi2_local_new = s->h_scal[0];
+    if (scale_poses) *scale_poses = s->h_scal[3];
+    if (scale_landmarks_local) *scale_landmarks_local = s->h_scal[4];
+    return s->h_scal[5] != 0.0 ? 0 : 1;
+}
+
+int lba_shard_accept(lba_shard* s, int accept)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    if (accept) s->cur = 1 - s->cur;        // discardTop(): the trial state becomes the estimate; pop(): keep the old one
+    return ORBX_OK;
+}
+
+int lba_shard_download(lba_shard* s, double* pose_q, double* pose_t, double* points, double* chi2_per_edge, uint8_t* depth_positive)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    const lba::Dev& d = s->d;
+    if (d.nE > 0)
+        hipLaunchKernelGGL(lba::k_epilogue, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, (const double*)s->poses[s->cur], (const double*)s->pts[s->cur], s->d_chi2, s->d_depth);
+    LBA_HIP(hipGetLastError());
+    std::vector<double> poses(7 * (size_t)d.nPoses);
+    LBA_HIP(hipMemcpyAsync(poses.data(), s->poses[s->cur], poses.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (points && d.nL > 0) LBA_HIP(hipMemcpyAsync(points, s->pts[s->cur], 3 * (size_t)d.nL * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (chi2_per_edge && d.nE > 0) LBA_HIP(hipMemcpyAsync(chi2_per_edge, s->d_chi2, (size_t)d.nE * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (depth_positive && d.nE > 0) LBA_HIP(hipMemcpyAsync(depth_positive, s->d_depth, (size_t)d.nE, hipMemcpyDeviceToHost, s->stream));
+    LBA_HIP(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < d.nPoses; i++) {
+        if (pose_q) for (int k = 0; k < 4; k++) pose_q[4 * i + k] = poses[7 * (size_t)i + k];
+        if (pose_t) for (int k = 0; k < 3; k++) pose_t[3 * i + k] = poses[7 * (size_t)i + 4 + k];
+    }
+    return ORBX_OK;
+}
+
+// ---- single-GPU driver: optimizer.initializeOptimization(); optimizer.optimize(max_iters) ----
+struct lba_solver { int device; };
+
+int lba_create(int device, lba_solver** out)
+{
+    if (!out) return fail(ORBX_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ORBX_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(ORBX_ERR_ARG, "device %d out of range", device);
+    lba_solver* s = new lba_solver();
+    s->device = device;
+    *out = s;
+    return ORBX_OK;
+}
+
+void lba_destroy(lba_solver* s) { delete s; }
+
+int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t* stop_flag, int max_iters, double lambda_init,
+              double* pose_q_out, double* pose_t_out, double* points_out,
+              double* chi2_per_edge, uint8_t* depth_positive, LbaStats* stats_out)
+{
+    if (!sv) return fail(ORBX_ERR_ARG, "NULL solver");
+    lba_shard* s = nullptr;
+    int r = lba_shard_create(sv->device, problem, &s);
+    if (r) return r;
+    LbaStats st;
+    std::memset(&st, 0, sizeof(st));
+    double lambda = -1, ni = 2;
+    int nBad = 0;
+    auto terminate = [&]() { return stop_flag && *stop_flag; };
+    // SparseOptimizer::optimize (sparse_optimizer.cpp:354-419) driving OptimizationAlgorithmLevenberg::solve (:61-169)
+    for (int it = 0; it < max_iters; it++) {
+        if (terminate()) { st.stop_reason = 3; break; }
+        double currentChi = 0, mdp = 0, mdl = 0;
+        if ((r = lba_shard_linearize(s, &currentChi, &mdp, &mdl))) break;
+        const double iniChi = currentChi;
+        if (it == 0) {
+            st.chi2_initial = currentChi;
+            lambda = lambda_init > 0 ? lambda_init : 1e-5 * std::max(mdp, mdl);     // computeLambdaInit (:171-185)
+            ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        bool stopped = false;
+        do {
+            if ((r = lba_shard_reduce(s, lambda))) break;
+            double tempChi = 0, sp = 0, sl = 0;
+            const int ok2 = lba_shard_finish(s, lambda, &tempChi, &sp, &sl);
+            if (ok2 < 0) { r = ok2; break; }
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            rho = currentChi - tempChi;
+            double scale = sp + sl;
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                lba_shard_accept(s, 1);
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                lba_shard_accept(s, 0);
+            }
+            qmax++;
+            st.trials++;
+            stopped = terminate();
+        } while (rho < 0 && qmax < 10 && !stopped);
+        if (r) break;
+        st.iterations++;
+        if (it < 16) st.chi2_trace[it] = currentChi;
+        st.chi2_final = currentChi;
+        if (qmax == 10 || rho == 0) { st.stop_reason = 1; break; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) { st.stop_reason = 2; break; }
+    }
+    st.lambda = lambda;
+    if (!r) r = lba_shard_download(s, pose_q_out, pose_t_out, points_out, chi2_per_edge, depth_positive);
+    lba_shard_destroy(s);
+    if (stats_out) *stats_out = st;
+    return r;
+}
+
+}  // extern "C"

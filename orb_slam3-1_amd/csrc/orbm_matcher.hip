@@ -1,0 +1,757 @@
+// orbm_matcher.hip -- gfx950 kernels + C ABI for the ORBmatcher searches on the hot path
+// (reference src/ORBmatcher.cc: SearchByBoW :223-425 / :765-905, SearchByProjection :43-213 / :1676-1887,
+// ComputeThreeMaxima :2012-2053, DescriptorDistance :2058-2074).
+//
+// Hamming distance = 4 x popcount(u64 xor) per 256-bit descriptor pair.  The greedy "already matched"
+// dependences of the reference are kept exactly:
+//   * SearchByBoW: a Frame feature belongs to exactly one vocabulary node (DBoW2::FeatureVector::addFeature),
+//     so nodes are independent work items: one lane per common node runs the reference's loops verbatim.
+//     If a caller passes feature vectors that violate the invariant the kernel runs the nodes serially.
+//   * SearchByProjection: later map points see earlier assignments (F.mvpMapPoints), so points are processed
+//     in order by one wave; the candidate window of a point (GetFeaturesInArea) is searched by 64 lanes and
+//     reduced with a lexicographic (distance, candidate order) top-2, which reproduces the sequential
+//     best / second-best bookkeeping including ties.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbslam3_hip.h"
+
+namespace orbx {
+extern thread_local std::string g_last_error;
+int fail(int code, const char* fmt, ...);
+}
+using orbx::fail;
+
+#define ORBM_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(ORBX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace orbm {
+
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;    // src/ORBmatcher.cc:35-37
+
+__device__ __forceinline__ int hamming256(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b)
+{
+    const unsigned long long* pa = (const unsigned long long*)a;
+    const unsigned long long* pb = (const unsigned long long*)b;
+    return __popcll(pa[0] ^ pb[0]) + __popcll(pa[1] ^ pb[1]) + __popcll(pa[2] ^ pb[2]) + __popcll(pa[3] ^ pb[3]);
+}
+
+// rotation histogram bin (:345-350).  factor = 1/HISTO_LENGTH is the reference's quirk; round() = C round on a float.
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0f) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// ComputeThreeMaxima (:2012-2053)
+__device__ inline void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// ---- SearchByBoW -------------------------------------------------------------------------------------------
+struct BowPairDev {
+    // side 1 = KeyFrame (KF1), side 2 = Frame (KF2 for the KF-KF variant); all offsets index the pair blob
+    const uint8_t* d1; const uint8_t* v1; const float* a1; const uint32_t* node1; const int32_t* off1; const uint32_t* feat1;
+    const uint8_t* d2; const uint8_t* v2; const float* a2; const uint32_t* node2; const int32_t* off2; const uint32_t* feat2;
+    int32_t n1, n2, nn1, nn2;
+    int32_t* match;         // [n2] (KF-F: Frame feature -> KF feature) or [n1] (KF-KF: KF1 feature -> KF2 feature)
+    uint8_t* matched2;      // [n2] KF-KF only
+    int32_t* n_matches;
+    int32_t serial;
+};
+
+template <bool KFKF>
+__device__ void bow_node(const BowPairDev& P, int k, int f, float nnratio, int check_ori, int* s_hist)
+{
+    for (int i1 = P.off1[k]; i1 < P.off1[k + 1]; i1++) {
+        const int idx1 = (int)P.feat1[i1];
+        if (!P.v1[idx1]) continue;                           // !pMP || pMP->isBad()
+        const uint8_t* da = P.d1 + (size_t)idx1 * 32;
+        int best1 = 256, bestIdx = -1, best2 = 256;
+        for (int i2 = P.off2[f]; i2 < P.off2[f + 1]; i2++) {
+            const int idx2 = (int)P.feat2[i2];
+            if (KFKF) { if (P.matched2[idx2] || !P.v2[idx2]) continue; }
+            else { if (P.match[idx2] >= 0) continue; }
+            const int dist = hamming256(da, P.d2 + (size_t)idx2 * 32);
+            if (dist < best1) { best2 = best1; best1 = dist; bestIdx = idx2; }
+            else if (dist < best2) best2 = dist;
+        }
+        const bool low = KFKF ? (best1 < TH_LOW) : (best1 <= TH_LOW);       // :848 is strict, :327 is not
+        if (low && (float)best1 < nnratio * (float)best2) {
+            if (KFKF) { P.match[idx1] = bestIdx; P.matched2[bestIdx] = 1; }
+            else P.match[bestIdx] = idx1;
+            if (check_ori) atomicAdd(&s_hist[rot_bin(P.a1[idx1], P.a2[bestIdx])], 1);
+        }
+    }
+}
+
+template <bool KFKF>
+__global__ __launch_bounds__(256) void k_bow(const BowPairDev* __restrict__ pairs, float nnratio, int check_ori)
+{
+    __shared__ int s_hist[HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_count;
+    const BowPairDev P = pairs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n_out = KFKF ? P.n1 : P.n2;
+    for (int i = tid; i < n_out; i += 256) P.match[i] = -1;
+    if (KFKF) for (int i = tid; i < P.n2; i += 256) P.matched2[i] = 0;
+    if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    if (P.serial) {
+        if (tid == 0) {
+            // merge-join of the two ascending node lists (:248-401)
+            int k = 0, f = 0;
+            while (k < P.nn1 && f < P.nn2) {
+                if (P.node1[k] == P.node2[f]) { bow_node<KFKF>(P, k, f, nnratio, check_ori, s_hist); k++; f++; }
+                else if (P.node1[k] < P.node2[f]) k++;
+                else f++;
+            }
+        }
+    } else {
+        for (int k = tid; k < P.nn1; k += 256) {
+            const uint32_t key = P.node1[k];
+            int lo = 0, hi = P.nn2;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.node2[mid] < key) lo = mid + 1; else hi = mid; }
+            if (lo < P.nn2 && P.node2[lo] == key) bow_node<KFKF>(P, k, lo, nnratio, check_ori, s_hist);
+        }
+    }
+    __syncthreads();
+    if (check_ori) {
+        if (tid == 0) { int a, b, c; three_maxima(s_hist, HISTO_LENGTH, a, b, c); s_keep[0] = a; s_keep[1] = b; s_keep[2] = c; }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int i = tid; i < n_out; i += 256) {
+        const int m = P.match[i];
+        if (m < 0) continue;
+        if (check_ori) {
+            const int bin = KFKF ? rot_bin(P.a1[i], P.a2[m]) : rot_bin(P.a1[m], P.a2[i]);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) { P.match[i] = -1; continue; }
+        }
+        local++;
+    }
+    if (local) atomicAdd(&s_count, local);
+    __syncthreads();
+    if (tid == 0) *P.n_matches = s_count;
+}
+
+// ---- SearchByProjection ------------------------------------------------------------------------------------
+struct ProjFrameDev {
+    const float* x; const float* y; const int32_t* octave; const float* angle; const uint8_t* desc;
+    const int32_t* cell_off;    // [cols*rows + 1], cell index = ix*rows + iy (mGrid[ix][iy])
+    const int32_t* cell_feat;   // features of a cell in insertion order (AssignFeaturesToGrid, src/Frame.cc:472-503)
+    const float* scale_factors;
+    float min_x, min_y, max_x, max_y, winv, hinv;
+    int32_t n, cols, rows;
+};
+
+constexpr unsigned long long kNoKey = ~0ull;
+// key: dist (9 bits) | cell ordinal in the window (20) | position in the cell (14) | feature index (21)
+__device__ __forceinline__ unsigned long long make_key(int dist, int cell_ord, int j, int idx)
+{
+    return ((unsigned long long)dist << 55) | ((unsigned long long)cell_ord << 35) | ((unsigned long long)j << 21) | (unsigned long long)idx;
+}
+__device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 55); }
+__device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 0x1FFFFFull); }
+
+__device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned long long& k2, unsigned long long k)
+{
+    if (k < k1) { k2 = k1; k1 = k; }
+    else if (k < k2) k2 = k;
+}
+
+// Frame::GetFeaturesInArea (src/Frame.cc:744-810) + the candidate loop of SearchByProjection: returns the two
+// smallest candidates in (distance, visiting order) lexicographic order == the reference's best / second best.
+__device__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float x, float y, float r, int minLevel, int maxLevel,
+                              const uint8_t* dmp, int lane, unsigned long long& best, unsigned long long& second)
+{
+    best = second = kNoKey;
+    const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.winv));
+    if (nMinCellX >= F.cols) return;
+    const int nMaxCellX = min(F.cols - 1, (int)ceilf((x - F.min_x + r) * F.winv));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = max(0, (int)floorf((y - F.min_y - r) * F.hinv));
+    if (nMinCellY >= F.rows) return;
+    const int nMaxCellY = min(F.rows - 1, (int)ceilf((y - F.min_y + r) * F.hinv));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    const int ny = nMaxCellY - nMinCellY + 1, nx = nMaxCellX - nMinCellX + 1;
+    const int ncell = nx * ny;
+    unsigned long long k1 = kNoKey, k2 = kNoKey;
+    for (int c = lane; c < ncell; c += 64) {
+        const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;       // ix outer, iy inner (:774-778)
+        const int cell = ix * F.rows + iy;
+        const int e0 = F.cell_off[cell], e1 = F.cell_off[cell + 1];
+        for (int e = e0; e < e1; e++) {
+            const int idx = F.cell_feat[e];
+            if (bCheckLevels) {
+                const int oc = F.octave[idx];
+                if (oc < minLevel) continue;
+                if (maxLevel >= 0 && oc > maxLevel) continue;
+            }
+            const float distx = F.x[idx] - x, disty = F.y[idx] - y;
+            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+            if (s_occ[idx]) continue;                                        // mvpMapPoints[idx] && Observations()>0
+            const int dist = hamming256(dmp, F.desc + (size_t)idx * 32);
+            if (dist >= 256) continue;                                       // never beats the initial bestDist = 256
+            top2_insert(k1, k2, make_key(dist, c, e - e0, idx));
+        }
+    }
+    // wave reduction of (k1, k2) pairs
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+        top2_insert(k1, k2, o1);
+        top2_insert(k1, k2, o2);
+    }
+    best = k1; second = k2;
+}
+
+struct ProjArgs {
+    ProjFrameDev F;
+    int32_t n_pts;
+    const uint8_t* valid;       // in_view (M4) / last_valid (M5)
+    const float* u; const float* v;
+    const int32_t* level;       // predicted level (M4) / last octave (M5)
+    const float* view_cos; const float* depth; const uint8_t* bad;      // M4 only
+    const float* angle;         // M5: last frame keypoint angle
+    const uint8_t* desc; const uint8_t* has_obs;
+    float th, th_far, nnratio;
+    int32_t far_points, check_ori, last_frame_mode;
+    int32_t* assign; uint8_t* occupied;
+    int32_t* log_feat; int32_t* log_bin;     // M5 rotation log, capacity n_pts
+    int32_t* n_matches;
+};
+
+__global__ __launch_bounds__(64) void k_proj(ProjArgs A)
+{
+    extern __shared__ uint8_t s_occ[];      // occupancy flags of the frame's features
+    __shared__ int s_hist[HISTO_LENGTH];
+    const int lane = threadIdx.x;
+    const ProjFrameDev& F = A.F;
+    for (int i = lane; i < F.n; i += 64) s_occ[i] = A.occupied[i];
+    if (lane < HISTO_LENGTH) s_hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0, nlog = 0;
+    const bool bFactor = A.th != 1.0f;
+    for (int i = 0; i < A.n_pts; i++) {
+        if (!A.valid[i]) continue;
+        float x = A.u[i], y = A.v[i], r;
+        int minLevel, maxLevel;
+        if (!A.last_frame_mode) {
+            if (A.far_points && A.depth[i] > A.th_far) continue;
+            if (A.bad[i]) continue;
+            const int lvl = A.level[i];
+            r = ((double)A.view_cos[i] > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos (:215-221)
+            if (bFactor) r *= A.th;
+            r = r * F.scale_factors[lvl];
+            minLevel = lvl - 1; maxLevel = lvl;
+        } else {
+            if (x < F.min_x || x > F.max_x) continue;                  // :1711-1714
+            if (y < F.min_y || y > F.max_y) continue;
+            const int oct = A.level[i];
+            r = A.th * F.scale_factors[oct];
+            minLevel = oct - 1; maxLevel = oct + 1;
+        }
+        unsigned long long kb, ks;
+        search_window(F, s_occ, x, y, r, minLevel, maxLevel, A.desc + (size_t)i * 32, lane, kb, ks);
+        if (kb == kNoKey) continue;
+        const int bestDist = key_dist(kb), bestIdx = key_idx(kb);
+        if (bestDist > TH_HIGH) continue;
+        if (!A.last_frame_mode) {
+            const int bestDist2 = (ks == kNoKey) ? 256 : key_dist(ks);
+            const int bestLevel = F.octave[bestIdx];
+            const int bestLevel2 = (ks == kNoKey) ? -1 : F.octave[key_idx(ks)];
+            if (bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2) continue;   // :126-127
+        }
+        if (lane == 0) {
+            A.assign[bestIdx] = i;
+            s_occ[bestIdx] = A.has_obs[i];
+            if (A.last_frame_mode && A.check_ori) {
+                const int bin = rot_bin(A.angle[i], F.angle[bestIdx]);
+                A.log_feat[nlog] = bestIdx; A.log_bin[nlog] = bin;
+                s_hist[bin]++;
+            }
+        }
+        nlog++;
+        nmatches++;
+        __syncthreads();        // the occupancy update must be seen by the next point's window search
+    }
+    __syncthreads();
+    if (A.last_frame_mode && A.check_ori && lane == 0) {
+        int i1, i2, i3;
+        three_maxima(s_hist, HISTO_LENGTH, i1, i2, i3);
+        for (int k = 0; k < nlog; k++) {
+            const int b = A.log_bin[k];
+            if (b != i1 && b != i2 && b != i3) {
+                A.assign[A.log_feat[k]] = -1;           // CurrentFrame.mvpMapPoints[...] = NULL (:1878)
+                s_occ[A.log_feat[k]] = 0;
+                nmatches--;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < F.n; i += 64) A.occupied[i] = s_occ[i];
+    if (lane == 0) *A.n_matches = nmatches;
+}
+
+}  // namespace orbm
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct orbm_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_blob = nullptr;
+    size_t blob_cap = 0;
+    std::vector<uint8_t> h_blob;
+
+    int ensure(size_t bytes)
+    {
+        if (bytes <= blob_cap) return ORBX_OK;
+        if (d_blob) (void)hipFree(d_blob);
+        d_blob = nullptr; blob_cap = 0;
+        const size_t cap = std::max(bytes * 2, (size_t)1 << 20);
+        ORBM_HIP(hipMalloc((void**)&d_blob, cap));
+        blob_cap = cap;
+        return ORBX_OK;
+    }
+};
+
+namespace {
+
+struct Blob {                   // host-side packer: every array is appended 16-byte aligned, device address = base + offset
+    std::vector<uint8_t>& buf;
+    explicit Blob(std::vector<uint8_t>& b) : buf(b) { buf.clear(); }
+    size_t put(const void* src, size_t bytes)
+    {
+        const size_t off = (buf.size() + 15) & ~(size_t)15;
+        buf.resize(off + bytes);
+        if (src && bytes) std::memcpy(buf.data() + off, src, bytes);
+        return off;
+    }
+    size_t reserve(size_t bytes) { return put(nullptr, bytes); }
+};
+
+bool features_unique(const OrbmFeatVec* fv, int n)
+{
+    std::vector<uint8_t> seen(std::max(n, 1), 0);
+    const int total = fv->n_nodes > 0 ? fv->offset[fv->n_nodes] : 0;
+    for (int i = 0; i < total; i++) {
+        const uint32_t f = fv->feat[i];
+        if ((int)f >= n || seen[f]) return false;
+        seen[f] = 1;
+    }
+    return true;
+}
+
+int check_fv(const OrbmFeatVec* fv, int n, const char* name)
+{
+    if (!fv) return fail(ORBX_ERR_ARG, "%s is NULL", name);
+    if (fv->n_nodes < 0) return fail(ORBX_ERR_ARG, "%s: negative node count", name);
+    if (fv->n_nodes == 0) return ORBX_OK;
+    if (!fv->node_id || !fv->offset || (!fv->feat && fv->offset[fv->n_nodes] > 0)) return fail(ORBX_ERR_ARG, "%s: NULL arrays", name);
+    for (int k = 0; k < fv->n_nodes; k++) {
+        if (fv->offset[k + 1] < fv->offset[k]) return fail(ORBX_ERR_ARG, "%s: offsets not monotone", name);
+        if (k > 0 && fv->node_id[k] <= fv->node_id[k - 1]) return fail(ORBX_ERR_ARG, "%s: node ids not ascending", name);
+    }
+    const int total = fv->offset[fv->n_nodes];
+    for (int i = 0; i < total; i++)
+        if ((int)fv->feat[i] < 0 || (int)fv->feat[i] >= n) return fail(ORBX_ERR_ARG, "%s: feature index %u out of range", name, fv->feat[i]);
+    return ORBX_OK;
+}
+
+struct PairOffsets {
+    size_t d1, v1, a1, node1, off1, feat1, d2, v2, a2, node2, off2, feat2, match, matched2, nmatch;
+    int n1, n2, nn1, nn2, serial, n_out;
+};
+
+}  // namespace
+
+template <bool KFKF>
+static int bow_batch(orbm_matcher* m, int n_pairs,
+                     const uint8_t* const* d1, const int* n1, const uint8_t* const* v1, const float* const* a1, const OrbmFeatVec* const* fv1,
+                     const uint8_t* const* d2, const int* n2, const uint8_t* const* v2, const float* const* a2, const OrbmFeatVec* const* fv2,
+                     float nnratio, int check_ori, int32_t* const* match_out, int32_t* nmatches_out)
+{
+    if (!m) return fail(ORBX_ERR_ARG, "NULL matcher");
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    std::vector<PairOffsets> po(n_pairs);
+    const size_t desc_off = blob.reserve(sizeof(orbm::BowPairDev) * n_pairs);
+    static const int32_t zero_off[1] = {0};
+    for (int p = 0; p < n_pairs; p++) {
+        int r;
+        if (n1[p] < 0 || n2[p] < 0) return fail(ORBX_ERR_ARG, "negative feature count");
+        if ((n1[p] > 0 && (!d1[p] || !v1[p])) || (n2[p] > 0 && !d2[p])) return fail(ORBX_ERR_ARG, "NULL descriptor/valid array");
+        if (KFKF && n2[p] > 0 && !v2[p]) return fail(ORBX_ERR_ARG, "NULL valid2");
+        if (check_ori && ((n1[p] > 0 && !a1[p]) || (n2[p] > 0 && !a2[p]))) return fail(ORBX_ERR_ARG, "NULL angle array");
+        if ((r = check_fv(fv1[p], n1[p], "fv1")) || (r = check_fv(fv2[p], n2[p], "fv2"))) return r;
+        PairOffsets& o = po[p];
+        o.n1 = n1[p]; o.n2 = n2[p]; o.nn1 = fv1[p]->n_nodes; o.nn2 = fv2[p]->n_nodes;
+        o.serial = !features_unique(fv2[p], n2[p]) || (KFKF && !features_unique(fv1[p], n1[p]));
+        o.d1 = blob.put(d1[p], (size_t)o.n1 * 32); o.v1 = blob.put(v1[p], o.n1);
+        o.a1 = blob.put(a1[p], a1[p] ? sizeof(float) * o.n1 : 0);
+        o.node1 = blob.put(fv1[p]->node_id, sizeof(uint32_t) * o.nn1);
+        o.off1 = blob.put(o.nn1 ? fv1[p]->offset : zero_off, sizeof(int32_t) * (o.nn1 + 1));
+        o.feat1 = blob.put(fv1[p]->feat, sizeof(uint32_t) * (o.nn1 ? fv1[p]->offset[o.nn1] : 0));
+        o.d2 = blob.put(d2[p], (size_t)o.n2 * 32); o.v2 = blob.put(KFKF ? v2[p] : nullptr, KFKF ? o.n2 : 0);
+        o.a2 = blob.put(a2[p], a2[p] ? sizeof(float) * o.n2 : 0);
+        o.node2 = blob.put(fv2[p]->node_id, sizeof(uint32_t) * o.nn2);
+        o.off2 = blob.put(o.nn2 ? fv2[p]->offset : zero_off, sizeof(int32_t) * (o.nn2 + 1));
+        o.feat2 = blob.put(fv2[p]->feat, sizeof(uint32_t) * (o.nn2 ? fv2[p]->offset[o.nn2] : 0));
+        o.n_out = KFKF ? o.n1 : o.n2;
+        o.match = blob.reserve(sizeof(int32_t) * std::max(o.n_out, 1));
+        o.matched2 = blob.reserve(KFKF ? std::max(o.n2, 1) : 0);
+        o.nmatch = blob.reserve(sizeof(int32_t));
+    }
+    int r = m->ensure(m->h_blob.size());
+    if (r) return r;
+    uint8_t* base = m->d_blob;
+    orbm::BowPairDev* descs = (orbm::BowPairDev*)(m->h_blob.data() + desc_off);
+    for (int p = 0; p < n_pairs; p++) {
+        const PairOffsets& o = po[p];
+        orbm::BowPairDev D;
+        D.d1 = base + o.d1; D.v1 = base + o.v1; D.a1 = (const float*)(base + o.a1);
+        D.node1 = (const uint32_t*)(base + o.node1); D.off1 = (const int32_t*)(base + o.off1); D.feat1 = (const uint32_t*)(base + o.feat1);
+        D.d2 = base + o.d2; D.v2 = base + o.v2; D.a2 = (const float*)(base + o.a2);
+        D.node2 = (const uint32_t*)(base + o.node2); D.off2 = (const int32_t*)(base + o.off2); D.feat2 = (const uint32_t*)(base + o.feat2);
+        D.n1 = o.n1; D.n2 = o.n2; D.nn1 = o.nn1; D.nn2 = o.nn2;
+        D.match = (int32_t*)(base + o.match); D.matched2 = base + o.matched2; D.n_matches = (int32_t*)(base + o.nmatch);
+        D.serial = o.serial;
+        descs[p] = D;
+    }
+    ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), m->h_blob.size(), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(orbm::k_bow<KFKF>, dim3(n_pairs), dim3(256), 0, m->stream, (const orbm::BowPairDev*)(base + desc_off), nnratio, check_ori);
+    ORBM_HIP(hipGetLastError());
+    for (int p = 0; p < n_pairs; p++) {
+        const PairOffsets& o = po[p];
+        if (o.n_out > 0) ORBM_HIP(hipMemcpyAsync(match_out[p], base + o.match, sizeof(int32_t) * o.n_out, hipMemcpyDeviceToHost, m->stream));
+        ORBM_HIP(hipMemcpyAsync(&nmatches_out[p], base + o.nmatch, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    }
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+// Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:472-503, 812-822): host-side flattening of mGrid into CSR.
+static int build_grid(const OrbmFrame* f, std::vector<int32_t>& cell_off, std::vector<int32_t>& cell_feat, float& winv, float& hinv)
+{
+    if (!f || f->n < 0 || f->grid_cols < 1 || f->grid_rows < 1 || f->grid_cols * (int64_t)f->grid_rows > (1 << 20))
+        return fail(ORBX_ERR_ARG, "bad frame grid");
+    if (f->n > 0 && (!f->x || !f->y || !f->octave || !f->desc)) return fail(ORBX_ERR_ARG, "NULL frame arrays");
+    if (!f->scale_factors || f->n_levels < 1) return fail(ORBX_ERR_ARG, "NULL scale factors");
+    if (f->n >= (1 << 21)) return fail(ORBX_ERR_ARG, "too many features");
+    winv = (float)f->grid_cols / (f->max_x - f->min_x);         // mfGridElementWidthInv (src/Frame.cc:338)
+    hinv = (float)f->grid_rows / (f->max_y - f->min_y);
+    const int ncell = f->grid_cols * f->grid_rows;
+    std::vector<int32_t> cell_of(f->n);
+    cell_off.assign(ncell + 1, 0);
+    for (int i = 0; i < f->n; i++) {
+        const int px = (int)std::round((f->x[i] - f->min_x) * winv);
+        const int py = (int)std::round((f->y[i] - f->min_y) * hinv);
+        if (px < 0 || px >= f->grid_cols || py < 0 || py >= f->grid_rows) { cell_of[i] = -1; continue; }
+        cell_of[i] = px * f->grid_rows + py;
+        cell_off[cell_of[i] + 1]++;
+    }
+    for (int c = 0; c < ncell; c++) {
+        if (cell_off[c + 1] >= (1 << 14)) return fail(ORBX_ERR_ARG, "grid cell %d holds %d features (limit 16383)", c, cell_off[c + 1]);
+        cell_off[c + 1] += cell_off[c];
+    }
+    cell_feat.assign(std::max(cell_off[ncell], 1), 0);
+    std::vector<int32_t> cur(cell_off.begin(), cell_off.end() - 1);
+    for (int i = 0; i < f->n; i++) if (cell_of[i] >= 0) cell_feat[cur[cell_of[i]]++] = i;
+    return ORBX_OK;
+}
+
+static int run_projection(orbm_matcher* m, const OrbmFrame* f, int last_mode, int n_pts, const uint8_t* valid,
+                          const float* u, const float* v, const int32_t* level, const float* view_cos, const float* depth,
+                          const uint8_t* bad, const float* angle, const uint8_t* desc, const uint8_t* has_obs,
+                          float th, int far_points, float th_far, float nnratio, int check_ori,
+                          int32_t* assign, uint8_t* occupied)
+{
+    if (!m) return fail(ORBX_ERR_ARG, "NULL matcher");
+    if (n_pts < 0 || (n_pts > 0 && (!valid || !u || !v || !level || !desc || !has_obs))) return fail(ORBX_ERR_ARG, "NULL point arrays");
+    if (!last_mode && n_pts > 0 && (!view_cos || !depth || !bad)) return fail(ORBX_ERR_ARG, "NULL map point arrays");
+    if (last_mode && check_ori && n_pts > 0 && (!angle || !f->angle)) return fail(ORBX_ERR_ARG, "NULL angle arrays");
+    if (!assign || !occupied) return fail(ORBX_ERR_ARG, "NULL assign/occupied");
+    std::vector<int32_t> cell_off, cell_feat;
+    float winv, hinv;
+    int r = build_grid(f, cell_off, cell_feat, winv, hinv);
+    if (r) return r;
+    for (int i = 0; i < n_pts; i++)
+        if (valid[i] && (level[i] < 0 || level[i] >= f->n_levels)) return fail(ORBX_ERR_ARG, "point %d: level %d out of range", i, level[i]);
+    if ((size_t)f->n + 256 > 150 * 1024) return fail(ORBX_ERR_ARG, "frame with %d features exceeds the LDS occupancy table", f->n);
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    const int n = f->n;
+    const size_t ox = blob.put(f->x, sizeof(float) * n), oy = blob.put(f->y, sizeof(float) * n);
+    const size_t ooct = blob.put(f->octave, sizeof(int32_t) * n);
+    const size_t oang = blob.put(f->angle, f->angle ? sizeof(float) * n : 0);
+    const size_t odesc = blob.put(f->desc, (size_t)n * 32);
+    const size_t ocoff = blob.put(cell_off.data(), sizeof(int32_t) * cell_off.size());
+    const size_t ocfeat = blob.put(cell_feat.data(), sizeof(int32_t) * cell_feat.size());
+    const size_t osf = blob.put(f->scale_factors, sizeof(float) * f->n_levels);
+    const size_t ovalid = blob.put(valid, n_pts), ou = blob.put(u, sizeof(float) * n_pts), ov = blob.put(v, sizeof(float) * n_pts);
+    const size_t olevel = blob.put(level, sizeof(int32_t) * n_pts);
+    const size_t ovc = blob.put(view_cos, view_cos ? sizeof(float) * n_pts : 0), odep = blob.put(depth, depth ? sizeof(float) * n_pts : 0);
+    const size_t obad = blob.put(bad, bad ? n_pts : 0), oangl = blob.put(angle, angle ? sizeof(float) * n_pts : 0);
+    const size_t odmp = blob.put(desc, (size_t)n_pts * 32), oobs = blob.put(has_obs, n_pts);
+    const size_t oassign = blob.put(assign, sizeof(int32_t) * n), oocc = blob.put(occupied, n);
+    const size_t ologf = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1)), ologb = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1));
+    const size_t onm = blob.reserve(sizeof(int32_t));
+    if ((r = m->ensure(m->h_blob.size()))) return r;
+    uint8_t* base = m->d_blob;
+    orbm::ProjArgs A;
+    A.F.x = (const float*)(base + ox); A.F.y = (const float*)(base + oy); A.F.octave = (const int32_t*)(base + ooct);
+    A.F.angle = (const float*)(base + oang); A.F.desc = base + odesc;
+    A.F.cell_off = (const int32_t*)(base + ocoff); A.F.cell_feat = (const int32_t*)(base + ocfeat);
+    A.F.scale_factors = (const float*)(base + osf);
+    A.F.min_x = f->min_x; A.F.min_y = f->min_y; A.F.max_x = f->max_x; A.F.max_y = f->max_y; A.F.winv = winv; A.F.hinv = hinv;
+    A.F.n = n; A.F.cols = f->grid_cols; A.F.rows = f->grid_rows;
+    A.n_pts = n_pts; A.valid = base + ovalid; A.u = (const float*)(base + ou); A.v = (const float*)(base + ov);
+    A.level = (const int32_t*)(base + olevel); A.view_cos = (const float*)(base + ovc); A.depth = (const float*)(base + odep);
+    A.bad = base + obad; A.angle = (const float*)(base + oangl); A.desc = base + odmp; A.has_obs = base + oobs;
+    A.th = th; A.th_far = th_far; A.nnratio = nnratio; A.far_points = far_points; A.check_ori = check_ori; A.last_frame_mode = last_mode;
+    A.assign = (int32_t*)(base + oassign); A.occupied = base + oocc;
+    A.log_feat = (int32_t*)(base + ologf); A.log_bin = (int32_t*)(base + ologb); A.n_matches = (int32_t*)(base + onm);
+    const size_t lds = ((size_t)n + 63) & ~(size_t)63;
+    ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)64)));
+    ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), m->h_blob.size(), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(orbm::k_proj, dim3(1), dim3(64), std::max(lds, (size_t)64), m->stream, A);
+    ORBM_HIP(hipGetLastError());
+    int nm = 0;
+    if (n > 0) {
+        ORBM_HIP(hipMemcpyAsync(assign, base + oassign, sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+        ORBM_HIP(hipMemcpyAsync(occupied, base + oocc, n, hipMemcpyDeviceToHost, m->stream));
+    }
+    ORBM_HIP(hipMemcpyAsync(&nm, base + onm, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    return nm;
+}
+
+extern "C" {
+
+int orbm_hamming(const uint8_t a[32], const uint8_t b[32])
+{
+    uint64_t x[4], y[4];
+    std::memcpy(x, a, 32);
+    std::memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+int orbm_create(int device, orbm_matcher** out)
+{
+    if (!out) return fail(ORBX_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ORBX_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(ORBX_ERR_ARG, "device %d out of range", device);
+    ORBM_HIP(hipSetDevice(device));
+    orbm_matcher* m = new orbm_matcher();
+    m->device = device;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return fail(ORBX_ERR_HIP, "stream create failed"); }
+    *out = m;
+    return ORBX_OK;
+}
+
+void orbm_destroy(orbm_matcher* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    if (m->d_blob) (void)hipFree(m->d_blob);
+    delete m;
+}
+
+int orbm_search_by_bow(orbm_matcher* m,
+                       const uint8_t* desc_kf, int n_kf, const uint8_t* valid_kf, const float* angle_kf, const OrbmFeatVec* fv_kf,
+                       const uint8_t* desc_f, int n_f, const float* angle_f, const OrbmFeatVec* fv_f,
+                       float nnratio, int check_orientation, int32_t* match_f2kf)
+{
+    if (!match_f2kf && n_f > 0) return fail(ORBX_ERR_ARG, "match_f2kf is NULL");
+    const uint8_t* v2 = nullptr;
+    int32_t nm = 0;
+    int r = bow_batch<false>(m, 1, &desc_kf, &n_kf, &valid_kf, &angle_kf, &fv_kf, &desc_f, &n_f, &v2, &angle_f, &fv_f,
+                             nnratio, check_orientation, &match_f2kf, &nm);
+    return r < 0 ? r : nm;
+}
+
+int orbm_search_by_bow_batch(orbm_matcher* m, OrbmBowPair* pairs, int n_pairs, float nnratio, int check_orientation)
+{
+    if (!pairs || n_pairs < 1) return fail(ORBX_ERR_ARG, "no pairs");
+    std::vector<const uint8_t*> d1(n_pairs), v1(n_pairs), d2(n_pairs), v2(n_pairs, nullptr);
+    std::vector<const float*> a1(n_pairs), a2(n_pairs);
+    std::vector<const OrbmFeatVec*> f1(n_pairs), f2(n_pairs);
+    std::vector<int> n1(n_pairs), n2(n_pairs);
+    std::vector<int32_t*> mo(n_pairs);
+    std::vector<int32_t> nm(n_pairs, 0);
+    for (int p = 0; p < n_pairs; p++) {
+        d1[p] = pairs[p].desc_kf; v1[p] = pairs[p].valid_kf; a1[p] = pairs[p].angle_kf; f1[p] = &pairs[p].fv_kf; n1[p] = pairs[p].n_kf;
+        d2[p] = pairs[p].desc_f; a2[p] = pairs[p].angle_f; f2[p] = &pairs[p].fv_f; n2[p] = pairs[p].n_f;
+        mo[p] = pairs[p].match_f2kf;
+        if (!mo[p] && n2[p] > 0) return fail(ORBX_ERR_ARG, "pair %d: match_f2kf is NULL", p);
+    }
+    int r = bow_batch<false>(m, n_pairs, d1.data(), n1.data(), v1.data(), a1.data(), f1.data(), d2.data(), n2.data(), v2.data(), a2.data(), f2.data(),
+                             nnratio, check_orientation, mo.data(), nm.data());
+    if (r < 0) return r;
+    for (int p = 0; p < n_pairs; p++) pairs[p].n_matches = nm[p];
+    return ORBX_OK;
+}
+
+// ---- device-resident batched SearchByBoW: upload once (plan), launch many times, fetch when needed ----
+struct orbm_bow_plan {
+    orbm_matcher* m = nullptr;
+    uint8_t* d_blob = nullptr;
+    size_t desc_off = 0;
+    int n_pairs = 0;
+    std::vector<PairOffsets> po;
+};
+
+int orbm_bow_plan_create(orbm_matcher* m, const OrbmBowPair* pairs, int n_pairs, orbm_bow_plan** out)
+{
+    if (!m || !pairs || n_pairs < 1 || !out) return fail(ORBX_ERR_ARG, "bad plan arguments");
+    *out = nullptr;
+    ORBM_HIP(hipSetDevice(m->device));
+    std::vector<uint8_t> host;
+    Blob blob(host);
+    orbm_bow_plan* pl = new orbm_bow_plan();
+    pl->m = m; pl->n_pairs = n_pairs; pl->po.resize(n_pairs);
+    pl->desc_off = blob.reserve(sizeof(orbm::BowPairDev) * n_pairs);
+    static const int32_t zero_off[1] = {0};
+    for (int p = 0; p < n_pairs; p++) {
+        const OrbmBowPair& q = pairs[p];
+        int r;
+        if (q.n_kf < 0 || q.n_f < 0 || (q.n_kf > 0 && (!q.desc_kf || !q.valid_kf || !q.angle_kf)) || (q.n_f > 0 && (!q.desc_f || !q.angle_f))) {
+            delete pl; return fail(ORBX_ERR_ARG, "pair %d: NULL arrays", p);
+        }
+        if ((r = check_fv(&q.fv_kf, q.n_kf, "fv_kf")) || (r = check_fv(&q.fv_f, q.n_f, "fv_f"))) { delete pl; return r; }
+        PairOffsets& o = pl->po[p];
+        o.n1 = q.n_kf; o.n2 = q.n_f; o.nn1 = q.fv_kf.n_nodes; o.nn2 = q.fv_f.n_nodes;
+        o.serial = !features_unique(&q.fv_f, q.n_f);
+        o.d1 = blob.put(q.desc_kf, (size_t)o.n1 * 32); o.v1 = blob.put(q.valid_kf, o.n1); o.a1 = blob.put(q.angle_kf, sizeof(float) * o.n1);
+        o.node1 = blob.put(q.fv_kf.node_id, sizeof(uint32_t) * o.nn1);
+        o.off1 = blob.put(o.nn1 ? q.fv_kf.offset : zero_off, sizeof(int32_t) * (o.nn1 + 1));
+        o.feat1 = blob.put(q.fv_kf.feat, sizeof(uint32_t) * (o.nn1 ? q.fv_kf.offset[o.nn1] : 0));
+        o.d2 = blob.put(q.desc_f, (size_t)o.n2 * 32); o.v2 = blob.reserve(0); o.a2 = blob.put(q.angle_f, sizeof(float) * o.n2);
+        o.node2 = blob.put(q.fv_f.node_id, sizeof(uint32_t) * o.nn2);
+        o.off2 = blob.put(o.nn2 ? q.fv_f.offset : zero_off, sizeof(int32_t) * (o.nn2 + 1));
+        o.feat2 = blob.put(q.fv_f.feat, sizeof(uint32_t) * (o.nn2 ? q.fv_f.offset[o.nn2] : 0));
+        o.n_out = o.n2;
+        o.match = blob.reserve(sizeof(int32_t) * std::max(o.n_out, 1));
+        o.matched2 = blob.reserve(0);
+        o.nmatch = blob.reserve(sizeof(int32_t));
+    }
+    if (hipMalloc((void**)&pl->d_blob, host.size()) != hipSuccess) { delete pl; return fail(ORBX_ERR_HIP, "hipMalloc(%zu) failed", host.size()); }
+    uint8_t* base = pl->d_blob;
+    orbm::BowPairDev* descs = (orbm::BowPairDev*)(host.data() + pl->desc_off);
+    for (int p = 0; p < n_pairs; p++) {
+        const PairOffsets& o = pl->po[p];
+        orbm::BowPairDev D;
+        D.d1 = base + o.d1; D.v1 = base + o.v1; D.a1 = (const float*)(base + o.a1);
+        D.node1 = (const uint32_t*)(base + o.node1); D.off1 = (const int32_t*)(base + o.off1); D.feat1 = (const uint32_t*)(base + o.feat1);
+        D.d2 = base + o.d2; D.v2 = base + o.v2; D.a2 = (const float*)(base + o.a2);
+        D.node2 = (const uint32_t*)(base + o.node2); D.off2 = (const int32_t*)(base + o.off2); D.feat2 = (const uint32_t*)(base + o.feat2);
+        D.n1 = o.n1; D.n2 = o.n2; D.nn1 = o.nn1; D.nn2 = o.nn2;
+        D.match = (int32_t*)(base + o.match); D.matched2 = base + o.matched2; D.n_matches = (int32_t*)(base + o.nmatch);
+        D.serial = o.serial;
+        descs[p] = D;
+    }
+    if (hipMemcpy(base, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(pl->d_blob); delete pl; return fail(ORBX_ERR_HIP, "upload failed"); }
+    *out = pl;
+    return ORBX_OK;
+}
+
+int orbm_bow_plan_run(orbm_bow_plan* pl, float nnratio, int check_orientation, void* stream)
+{
+    if (!pl) return fail(ORBX_ERR_ARG, "NULL plan");
+    ORBM_HIP(hipSetDevice(pl->m->device));
+    hipLaunchKernelGGL(orbm::k_bow<false>, dim3(pl->n_pairs), dim3(256), 0, (hipStream_t)stream,
+                       (const orbm::BowPairDev*)(pl->d_blob + pl->desc_off), nnratio, check_orientation);
+    ORBM_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbm_bow_plan_fetch(orbm_bow_plan* pl, OrbmBowPair* pairs, void* stream)
+{
+    if (!pl || !pairs) return fail(ORBX_ERR_ARG, "NULL argument");
+    ORBM_HIP(hipSetDevice(pl->m->device));
+    hipStream_t st = (hipStream_t)stream;
+    for (int p = 0; p < pl->n_pairs; p++) {
+        const PairOffsets& o = pl->po[p];
+        if (o.n_out > 0 && pairs[p].match_f2kf)
+            ORBM_HIP(hipMemcpyAsync(pairs[p].match_f2kf, pl->d_blob + o.match, sizeof(int32_t) * o.n_out, hipMemcpyDeviceToHost, st));
+        ORBM_HIP(hipMemcpyAsync(&pairs[p].n_matches, pl->d_blob + o.nmatch, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
+    ORBM_HIP(hipStreamSynchronize(st));
+    return ORBX_OK;
+}
+
+void orbm_bow_plan_destroy(orbm_bow_plan* pl)
+{
+    if (!pl) return;
+    (void)hipSetDevice(pl->m->device);
+    if (pl->d_blob) (void)hipFree(pl->d_blob);
+    delete pl;
+}
+
+int orbm_search_by_bow_kfkf(orbm_matcher* m,
+                            const uint8_t* desc1, int n1, const uint8_t* valid1, const float* angle1, const OrbmFeatVec* fv1,
+                            const uint8_t* desc2, int n2, const uint8_t* valid2, const float* angle2, const OrbmFeatVec* fv2,
+                            float nnratio, int check_orientation, int32_t* match12)
+{
+    if (!match12 && n1 > 0) return fail(ORBX_ERR_ARG, "match12 is NULL");
+    int32_t nm = 0;
+    int r = bow_batch<true>(m, 1, &desc1, &n1, &valid1, &angle1, &fv1, &desc2, &n2, &valid2, &angle2, &fv2,
+                            nnratio, check_orientation, &match12, &nm);
+    return r < 0 ? r : nm;
+}
+
+int orbm_search_by_projection(orbm_matcher* m, const OrbmFrame* f,
+                              int n_mp, const uint8_t* in_view, const float* proj_u, const float* proj_v,
+                              const int32_t* pred_level, const float* view_cos, const float* track_depth,
+                              const uint8_t* desc_mp, const uint8_t* mp_has_obs, const uint8_t* mp_bad,
+                              float th, int far_points, float th_far, float nnratio,
+                              int32_t* assign, uint8_t* occupied)
+{
+    return run_projection(m, f, 0, n_mp, in_view, proj_u, proj_v, pred_level, view_cos, track_depth, mp_bad, nullptr,
+                          desc_mp, mp_has_obs, th, far_points, th_far, nnratio, 0, assign, occupied);
+}
+
+int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
+                                   int n_last, const uint8_t* last_valid, const float* proj_u, const float* proj_v,
+                                   const int32_t* last_octave, const float* last_angle,
+                                   const uint8_t* desc_mp, const uint8_t* mp_has_obs,
+                                   float th, int check_orientation,
+                                   int32_t* assign, uint8_t* occupied)
+{
+    return run_projection(m, cur, 1, n_last, last_valid, proj_u, proj_v, last_octave, nullptr, nullptr, nullptr, last_angle,
+                          desc_mp, mp_has_obs, th, 0, 0.f, 0.f, check_orientation, assign, occupied);
+}
+
+}  // extern "C"

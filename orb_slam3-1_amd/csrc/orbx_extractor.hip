@@ -126,6 +126,12 @@ struct orbx_extractor {
     DevBuf<int> d_n, d_mono, d_status;
     int out_cap = 0;
     hipStream_t stream = nullptr;
+    // per-stage HIP-event profiling (off by default)
+    static constexpr int kProfEvents = 8;
+    bool profile = false;
+    hipEvent_t prof_ev[kProfEvents] = {};
+    int prof_marks = 0;
+    hipStream_t prof_stream = nullptr;
 
     int setup_geometry(int w, int h);
     int ensure_batch(int batch);
@@ -325,37 +331,76 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
 {
     const int B = batch;
     ORBX_HIP(hipMemsetAsync(o_status, 0, sizeof(int) * B, st));
+    // optional per-stage timing with HIP events on the launch stream (bench.py roofline leg)
+    int mark_i = 0;
+    auto mark = [&]() { if (profile && mark_i < kProfEvents) (void)hipEventRecord(prof_ev[mark_i++], st); };
+    mark();
     if (!level0_ready) {
         const LevelDesc& L0 = levels[0];
         dim3 g((L0.w / 4 + 255) / 256, L0.h, B);
         hipLaunchKernelGGL(k_copy_level0, g, dim3(256), 0, st, d_imgs, row_stride, frame_stride, d_pyr.p, pyr_frame_bytes, L0);
     }
+    mark();
     for (int l = 1; l < nlevels; l++) {
         const LevelDesc& D = levels[l];
         dim3 g(((D.w + 3) / 4 + 255) / 256, D.h, B);
         hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, d_pyr.p, pyr_frame_bytes, levels[l - 1], D,
                            d_xofs[l].p, d_ialpha[l].p, d_yofs[l].p, d_ibeta[l].p);
     }
+    mark();
     const int n_cells = (int)cells.size();
     if (n_cells > 0)
         hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
                            ini_th, min_th, tile_pitch, tile_rows, m_pitch, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
+    mark();
     hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), oct_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
                        d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, oct_lds_keys,
                        d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status);
+    mark();
     hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,
                        lap0, lap1, cap, d_kp_dst.p, sel_frame_entries, o_n, o_mono, o_status);
+    mark();
     hipLaunchKernelGGL(k_blur, dim3((unsigned)tiles.size(), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
                        taps[0], taps[1], taps[2], taps[3]);
+    mark();
     hipLaunchKernelGGL(k_orient_desc, dim3((sel_frame_entries + 3) / 4, B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
                        d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p, d_kp_dst.p, sel_frame_entries,
                        o_kps, o_desc, cap, d_lvl_kps.p);
+    mark();
+    prof_marks = mark_i;
+    prof_stream = st;
     ORBX_HIP(hipGetLastError());
     last_batch = B;
     return ORBX_OK;
 }
 
 extern "C" {
+
+// Per-stage device time of the LAST enqueue, measured with HIP events recorded on the launch stream.
+// stages: 0 level-0 copy, 1 pyramid resize (all levels), 2 FAST cells, 3 octree, 4 index, 5 blur, 6 orient+descriptor.
+int orbx_profile_enable(orbx_extractor* e, int on)
+{
+    if (!e) return fail(ORBX_ERR_ARG, "NULL handle");
+    ORBX_HIP(hipSetDevice(e->device));
+    if (on && !e->prof_ev[0])
+        for (int i = 0; i < orbx_extractor::kProfEvents; i++) ORBX_HIP(hipEventCreate(&e->prof_ev[i]));
+    e->profile = on != 0;
+    e->prof_marks = 0;
+    return ORBX_OK;
+}
+
+int orbx_profile_read(orbx_extractor* e, float* stage_ms, int n_stages)
+{
+    if (!e || !stage_ms) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (!e->profile || e->prof_marks < 2) return fail(ORBX_ERR_ARG, "profiling was not enabled for the last call");
+    ORBX_HIP(hipSetDevice(e->device));
+    ORBX_HIP(hipStreamSynchronize(e->prof_stream));
+    for (int i = 0; i < n_stages; i++) {
+        stage_ms[i] = 0.f;
+        if (i + 1 < e->prof_marks) ORBX_HIP(hipEventElapsedTime(&stage_ms[i], e->prof_ev[i], e->prof_ev[i + 1]));
+    }
+    return ORBX_OK;
+}
 
 const char* orbx_last_error(void) { return g_last_error.c_str(); }
 

@@ -1,0 +1,204 @@
+"""Multi-GPU side of the hot path.  One process per GPU, torch.distributed over RCCL/xGMI
+(backend "nccl" on ROCm) -- PyTorch is plumbing here: device tensors for the all-reduce buffer, nothing else.
+
+* Frames and local-BA windows are independent units: they shard with NO collective
+  (`shard_range` gives each rank its contiguous share; results are gathered by the host application).
+* Global bundle adjustment has exactly one exchange step per LM trial: landmarks (with all their edges) are
+  partitioned over ranks, poses are replicated, and the additive reduced camera system
+  [S | b_schur | b_p | diag Hpp] is summed with ONE all-reduce; chi2 / scale / max-diagonal scalars ride in a
+  second, tiny all-reduce.  `sharded_bundle_adjustment` is the LM driver (g2o control flow,
+  reference Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-169) written against a small
+  shard interface so that the same code runs on the HIP shard (capi.LbaShard) and, in the CPU gloo tests,
+  on the oracle's shard.
+"""
+import math
+
+import numpy as np
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block partition of n_items units (frames, windows, landmarks) over `world` ranks."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def partition_landmarks(w, rank, world):
+    """Local problem of one rank: all poses, landmarks [lo, hi) and every edge of those landmarks.
+    Returns (local problem dict, landmark index range, global indices of the local edges)."""
+    lo, hi = shard_range(len(w["points"]), rank, world)
+    sel = np.nonzero((w["edge_point"] >= lo) & (w["edge_point"] < hi))[0]
+    loc = dict(w)
+    loc["points"] = np.ascontiguousarray(w["points"][lo:hi])
+    loc["edge_point"] = (w["edge_point"][sel] - lo).astype(np.int32)
+    loc["edge_pose"] = np.ascontiguousarray(w["edge_pose"][sel])
+    loc["edge_obs"] = np.ascontiguousarray(w["edge_obs"][sel])
+    loc["edge_inv_sigma2"] = np.ascontiguousarray(w["edge_inv_sigma2"][sel])
+    loc["edge_stereo"] = np.ascontiguousarray(w["edge_stereo"][sel])
+    return loc, (lo, hi), sel
+
+
+class _NoDist:
+    """world_size 1: the collectives are identities."""
+    world = 1
+
+    def sum_(self, t):
+        return t
+
+    def sum_scalars(self, vals):
+        return list(vals)
+
+    def max_scalars(self, vals):
+        return list(vals)
+
+
+class TorchDist:
+    """torch.distributed collectives.  `device` is where scalar packs live (cuda for nccl/RCCL, cpu for gloo)."""
+
+    def __init__(self, dist, device):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.device = device
+        self.world = dist.get_world_size()
+
+    def sum_(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def sum_scalars(self, vals):
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().tolist()
+
+    def max_scalars(self, vals):
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.cpu().tolist()
+
+
+def sharded_bundle_adjustment(shard, reduce_tensor, comm=None, max_iters=10, lambda_init=0.0, stop_flag=None):
+    """LM loop over a landmark-sharded BA.  `shard` offers linearize() -> (chi2, maxdiag_p, maxdiag_l),
+    reduce(lambda), finish(lambda) -> (solved, chi2_new, scale_poses, scale_landmarks), accept(bool).
+    `reduce_tensor` is a torch tensor (or None when comm is None) aliasing the shard's reduce buffer.
+    Every rank takes identical decisions because every decision input is all-reduced.  Returns stats dict."""
+    comm = comm or _NoDist()
+    lam, ni, n_bad = -1.0, 2.0, 0
+    stats = dict(iterations=0, trials=0, stop_reason=0, chi2_trace=[])
+
+    def terminate():
+        local = 1.0 if (stop_flag is not None and stop_flag[0]) else 0.0
+        return comm.max_scalars([local])[0] > 0      # all ranks must agree on stopping
+
+    for it in range(max_iters):
+        if terminate():
+            stats["stop_reason"] = 3
+            break
+        chi_l, mdp_l, mdl_l = shard.linearize()
+        current_chi = comm.sum_scalars([chi_l])[0]
+        ini_chi = current_chi
+        if it == 0:
+            stats["chi2_initial"] = current_chi
+            if lambda_init > 0:
+                lam = lambda_init
+            else:
+                # pose diagonals are partial sums -> they are summed inside the reduce buffer; use the landmark max
+                # plus the summed pose diagonal (section 4 of the buffer) after a lambda-free reduce
+                shard.reduce(0.0)
+                if reduce_tensor is not None:
+                    comm.sum_(reduce_tensor)
+                mdp = shard.max_pose_diag()
+                mdl = comm.max_scalars([mdl_l])[0]
+                lam = 1e-5 * max(mdp, mdl)
+            ni, n_bad = 2.0, 0
+        rho, qmax, stopped = 0.0, 0, False
+        while True:
+            shard.reduce(lam)
+            if reduce_tensor is not None:
+                comm.sum_(reduce_tensor)
+            solved, chi_new_l, sp, sl_l = shard.finish(lam)
+            chi_new, sl, ok_all = comm.sum_scalars([chi_new_l, sl_l, float(solved)])
+            temp_chi = chi_new if ok_all >= comm.world - 0.5 else float("inf")
+            rho = (current_chi - temp_chi) / (sp + sl + 1e-3)
+            if rho > 0 and math.isfinite(temp_chi):
+                alpha = min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0)
+                lam *= max(1.0 / 3.0, alpha)
+                ni = 2.0
+                current_chi = temp_chi
+                shard.accept(True)
+            else:
+                lam *= ni
+                ni *= 2
+                shard.accept(False)
+            qmax += 1
+            stats["trials"] += 1
+            stopped = terminate()
+            if not (rho < 0 and qmax < 10 and not stopped):
+                break
+        stats["iterations"] += 1
+        stats["chi2_trace"].append(current_chi)
+        stats["chi2_final"] = current_chi
+        if qmax == 10 or rho == 0:
+            stats["stop_reason"] = 1
+            break
+        n_bad = n_bad + 1 if (ini_chi - current_chi) * 1e3 < ini_chi else 0
+        if n_bad >= 3:
+            stats["stop_reason"] = 2
+            break
+    stats["lambda_"] = lam
+    return stats
+
+
+class LocalHipShard:
+    """Adapter for world_size 1 without torch: the pose diagonal maximum comes straight from linearize()."""
+
+    def __init__(self, lba_shard):
+        self.s = lba_shard
+        self._mdp = 0.0
+
+    def linearize(self):
+        chi, mdp, mdl = self.s.linearize()
+        self._mdp = mdp
+        return chi, mdp, mdl
+
+    def reduce(self, lam):
+        self.s.reduce(lam)
+
+    def finish(self, lam):
+        return self.s.finish(lam)
+
+    def accept(self, ok):
+        self.s.accept(ok)
+
+    def max_pose_diag(self):
+        return self._mdp
+
+
+class HipShard:
+    """Adapter: capi.LbaShard (HIP kernels) + a torch.float64 CUDA tensor that owns the reduce buffer, so that
+    torch.distributed (RCCL) all-reduces it in place over xGMI with no staging copy."""
+
+    def __init__(self, lba_shard, torch, device):
+        self.s = lba_shard
+        self.n_red = lba_shard.reduce_len()
+        self.tensor = torch.zeros(self.n_red, dtype=torch.float64, device=device)
+        lba_shard.set_reduce_buffer(self.tensor.data_ptr())
+        # n*n + 3n = n_red  ->  n
+        self.n = int(round((-3 + math.sqrt(9 + 4 * self.n_red)) / 2))
+
+    def linearize(self):
+        return self.s.linearize()
+
+    def reduce(self, lam):
+        self.s.reduce(lam)
+
+    def finish(self, lam):
+        return self.s.finish(lam)
+
+    def accept(self, ok):
+        self.s.accept(ok)
+
+    def max_pose_diag(self):
+        if self.n == 0:
+            return 0.0
+        return float(self.tensor[self.n * self.n + 2 * self.n:].abs().max().item())

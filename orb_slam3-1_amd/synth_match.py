@@ -1,0 +1,75 @@
+"""Synthetic inputs for the projection searches (ORBmatcher::SearchByProjection variants).
+
+A frame with N keypoints (grid 64x48 over the image bounds, octaves 0..7) and a set of map points / last-frame
+points that project close to some of them with descriptors a few bits away, plus distractors, occupied features
+and ties, so that the ratio test, the level bookkeeping, the 'already holds a map point' skip and the rotation
+histogram are all exercised."""
+import numpy as np
+
+
+def _flip(rs, d, p):
+    bits = np.unpackbits(d, axis=-1)
+    fl = (rs.uniform(size=bits.shape) < p).astype(np.uint8)
+    return np.packbits(bits ^ fl, axis=-1)
+
+
+def make_frame_features(seed, n=1000, w=752, h=480, nlevels=8, cluster=True):
+    rs = np.random.RandomState(31337 + seed)
+    x = rs.uniform(0, w - 1, n)
+    y = rs.uniform(0, h - 1, n)
+    if cluster:     # some crowded cells and exact duplicates of positions
+        k = n // 5
+        x[:k] = rs.normal(w * 0.4, 12.0, k).clip(0, w - 1)
+        y[:k] = rs.normal(h * 0.5, 10.0, k).clip(0, h - 1)
+    scale = (1.2 ** np.arange(nlevels)).astype(np.float32)
+    g = dict(x=x.astype(np.float32), y=y.astype(np.float32), octave=rs.randint(0, nlevels, n).astype(np.int32),
+             min_x=0.0, min_y=0.0, max_x=float(w), max_y=float(h), cols=64, rows=48)
+    desc = rs.randint(0, 256, size=(n, 32)).astype(np.uint8)
+    ang = rs.uniform(0, 360, n).astype(np.float32)
+    return g, desc, ang, scale
+
+
+def make_projection_case(seed, n=1000, n_mp=900, nlevels=8):
+    """Inputs of SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (reference src/ORBmatcher.cc:43-213)."""
+    rs = np.random.RandomState(777 + seed)
+    g, dF, angF, scale = make_frame_features(seed, n, nlevels=nlevels)
+    tgt = rs.randint(0, n, n_mp)
+    kind = rs.uniform(size=n_mp)
+    u = g["x"][tgt] + rs.normal(0, 1.5, n_mp)
+    v = g["y"][tgt] + rs.normal(0, 1.5, n_mp)
+    far = kind > 0.9                                       # project to nowhere in particular
+    u[far] = rs.uniform(-20, g["max_x"] + 20, far.sum())
+    v[far] = rs.uniform(-20, g["max_y"] + 20, far.sum())
+    level = np.clip(g["octave"][tgt] + rs.randint(0, 2, n_mp), 0, nlevels - 1).astype(np.int32)
+    desc = _flip(rs, dF[tgt], np.where(kind < 0.6, 0.04, 0.25)[:, None])
+    dup = rs.uniform(size=n_mp) < 0.05                     # exact copies -> distance ties between candidates
+    desc[dup] = dF[tgt[dup]]
+    mp = dict(u=u.astype(np.float32), v=v.astype(np.float32), level=level,
+              in_view=(rs.uniform(size=n_mp) < 0.92).astype(np.uint8),
+              view_cos=np.where(rs.uniform(size=n_mp) < 0.5, 0.9995, 0.97).astype(np.float32),
+              depth=rs.uniform(1, 40, n_mp).astype(np.float32), desc=np.ascontiguousarray(desc),
+              has_obs=(rs.uniform(size=n_mp) < 0.9).astype(np.uint8), bad=(rs.uniform(size=n_mp) < 0.03).astype(np.uint8))
+    occupied = (rs.uniform(size=n) < 0.1).astype(np.uint8)
+    assign = np.where(occupied > 0, 100000 + np.arange(n), -1).astype(np.int32)
+    return g, dF, angF, scale, mp, assign, occupied
+
+
+def make_last_frame_case(seed, n=1000, n_last=900, nlevels=8):
+    """Inputs of SearchByProjection(Frame& cur, const Frame& last, th, bMono) (reference src/ORBmatcher.cc:1676-1887)."""
+    rs = np.random.RandomState(999 + seed)
+    g, dF, angF, scale = make_frame_features(seed + 50, n, nlevels=nlevels)
+    tgt = rs.randint(0, n, n_last)
+    u = g["x"][tgt] + rs.normal(0, 3.0, n_last)
+    v = g["y"][tgt] + rs.normal(0, 3.0, n_last)
+    out = rs.uniform(size=n_last) < 0.05
+    u[out] = rs.choice([-5.0, g["max_x"] + 5.0], out.sum())        # outside the image bounds check
+    octave = np.clip(g["octave"][tgt] + rs.randint(-1, 2, n_last), 0, nlevels - 1).astype(np.int32)
+    desc = _flip(rs, dF[tgt], np.where(rs.uniform(size=n_last) < 0.7, 0.05, 0.3)[:, None])
+    true_rot = rs.uniform(size=n_last) < 0.75
+    ang = np.mod(angF[tgt].astype(np.float64) + np.where(true_rot, rs.normal(20, 4, n_last), rs.uniform(0, 360, n_last)), 360.0)
+    last = dict(u=u.astype(np.float32), v=v.astype(np.float32), octave=octave, angle=ang.astype(np.float32),
+                valid=(rs.uniform(size=n_last) < 0.85).astype(np.uint8), desc=np.ascontiguousarray(desc),
+                has_obs=(rs.uniform(size=n_last) < 0.8).astype(np.uint8))
+    occupied = np.zeros(n, np.uint8)
+    assign = np.full(n, -1, np.int32)
+    return g, dF, angF, scale, last, assign, occupied

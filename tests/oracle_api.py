@@ -166,6 +166,69 @@ class Oracle:
         return dict(pose_q=q, pose_t=t, points=pts, chi2=chi2, depth_positive=dpos, stats=stats)
 
 
+class OracleShard:
+    """CPU counterpart of capi.LbaShard + distributed.HipShard (same interface, numpy reduce buffer)."""
+
+    def __init__(self, orc, w):
+        L = self.L = orc.lib
+        L.lba_oracle_shard_create.restype = C.c_void_p
+        L.lba_oracle_shard_create.argtypes = [C.POINTER(LbaProblem)]
+        L.lba_oracle_shard_destroy.argtypes = [C.c_void_p]
+        L.lba_oracle_shard_reduce_len.restype = C.c_int64
+        L.lba_oracle_shard_reduce_len.argtypes = [C.c_void_p]
+        L.lba_oracle_shard_reduce_buffer.restype = C.POINTER(C.c_double)
+        L.lba_oracle_shard_reduce_buffer.argtypes = [C.c_void_p]
+        L.lba_oracle_shard_linearize.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 3
+        L.lba_oracle_shard_reduce.argtypes = [C.c_void_p, C.c_double]
+        L.lba_oracle_shard_finish.argtypes = [C.c_void_p, C.c_double] + [C.POINTER(C.c_double)] * 3
+        L.lba_oracle_shard_accept.argtypes = [C.c_void_p, C.c_int]
+        L.lba_oracle_shard_download.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        self.keep = {k: np.ascontiguousarray(w[k]) for k in ("pose_q", "pose_t", "pose_fixed", "points", "edge_point",
+                                                               "edge_pose", "edge_obs", "edge_inv_sigma2", "edge_stereo")}
+        k = self.keep
+        pr = LbaProblem(len(k["pose_q"]), _p(k["pose_q"]), _p(k["pose_t"]), _p(k["pose_fixed"]),
+                        len(k["points"]), _p(k["points"]), len(k["edge_point"]), _p(k["edge_point"]),
+                        _p(k["edge_pose"]), _p(k["edge_obs"]), _p(k["edge_inv_sigma2"]), _p(k["edge_stereo"]),
+                        w["fx"], w["fy"], w["cx"], w["cy"], w["bf"], w["huber_mono"], w["huber_stereo"])
+        self.h = C.c_void_p(L.lba_oracle_shard_create(C.byref(pr)))
+        self.n_red = L.lba_oracle_shard_reduce_len(self.h)
+        buf = L.lba_oracle_shard_reduce_buffer(self.h)
+        self.array = np.ctypeslib.as_array(buf, shape=(self.n_red,))        # aliases the C buffer
+        self.n = int(round((-3 + np.sqrt(9 + 4 * self.n_red)) / 2))
+
+    def __del__(self):
+        try:
+            self.L.lba_oracle_shard_destroy(self.h)
+        except Exception:
+            pass
+
+    def linearize(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.L.lba_oracle_shard_linearize(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def reduce(self, lam):
+        self.L.lba_oracle_shard_reduce(self.h, lam)
+
+    def finish(self, lam):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        r = self.L.lba_oracle_shard_finish(self.h, lam, C.byref(a), C.byref(b), C.byref(c))
+        return r, a.value, b.value, c.value
+
+    def accept(self, ok):
+        self.L.lba_oracle_shard_accept(self.h, int(ok))
+
+    def max_pose_diag(self):
+        return float(np.abs(self.array[self.n * self.n + 2 * self.n:]).max()) if self.n else 0.0
+
+    def download(self):
+        k = self.keep
+        q = np.zeros_like(k["pose_q"]); t = np.zeros_like(k["pose_t"]); pts = np.zeros_like(k["points"])
+        chi2 = np.zeros(len(k["edge_point"])); dpos = np.zeros(len(k["edge_point"]), np.uint8)
+        self.L.lba_oracle_shard_download(self.h, _p(q), _p(t), _p(pts), _p(chi2), _p(dpos))
+        return dict(pose_q=q, pose_t=t, points=pts, chi2=chi2, depth_positive=dpos)
+
+
 class OracleExtractor:
     def __init__(self, orc, nfeatures, scale, nlevels, ini, mn):
         self.o = orc

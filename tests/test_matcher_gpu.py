@@ -1,0 +1,119 @@
+"""Parity of the HIP matcher (through the C ABI) against the CPU oracle: match sets must be identical."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    return importlib.import_module("orb_slam3-1_amd.synth_match")
+
+
+@pytest.mark.parametrize("seed,n,ratio,ori", [(0, 1000, 0.7, True), (1, 1000, 0.75, True), (2, 1000, 0.9, False),
+                                              (3, 64, 0.7, True), (4, 2500, 0.6, True)])
+def test_search_by_bow(pkg, oracle, synth, seed, n, ratio, ori):
+    ms = synth.make_match_set(seed, n=n)
+    n0, m0 = oracle.search_by_bow(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], ms["angF"], ms["fvF"], ratio, ori)
+    m = pkg.Matcher(ratio, ori)
+    try:
+        n1, m1 = m.SearchByBoW(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], ms["angF"], ms["fvF"])
+    finally:
+        m.close()
+    assert n1 == n0
+    np.testing.assert_array_equal(m1, m0)
+    assert n0 > 0.2 * n * 0.5       # the case is not degenerate
+
+
+def test_search_by_bow_batch(pkg, oracle, synth):
+    sets = [synth.make_match_set(10 + i, n=500 + 100 * i) for i in range(5)]
+    m = pkg.Matcher(0.7, True)
+    try:
+        res = m.SearchByBoW_batch(sets)
+    finally:
+        m.close()
+    for ms, (n1, m1) in zip(sets, res):
+        n0, m0 = oracle.search_by_bow(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], ms["angF"], ms["fvF"], 0.7, True)
+        assert n1 == n0
+        np.testing.assert_array_equal(m1, m0)
+
+
+def test_search_by_bow_edge_cases(pkg, oracle, synth):
+    ms = synth.make_match_set(7, n=300)
+    m = pkg.Matcher(0.7, True)
+    try:
+        # no valid KF map points -> no matches
+        z = np.zeros_like(ms["validKF"])
+        n1, m1 = m.SearchByBoW(ms["dKF"], z, ms["angKF"], ms["fvKF"], ms["dF"], ms["angF"], ms["fvF"])
+        assert n1 == 0 and (m1 == -1).all()
+        # disjoint vocabularies -> no common node
+        fv2 = (ms["fvF"][0] + 100000, ms["fvF"][1], ms["fvF"][2])
+        n1, m1 = m.SearchByBoW(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], ms["angF"], fv2)
+        assert n1 == 0
+        # ragged: a frame feature listed under two nodes breaks the DBoW2 invariant -> serial path, still equal to the oracle
+        nodes, offs, feat = [a.copy() for a in ms["fvF"]]
+        feat2 = np.concatenate([feat, feat[:3]]).astype(np.uint32)
+        nodes2 = np.concatenate([nodes, [nodes[-1] + 5]]).astype(np.uint32)
+        offs2 = np.concatenate([offs, [offs[-1] + 3]]).astype(np.int32)
+        nodesK = np.concatenate([ms["fvKF"][0], [nodes[-1] + 5]]).astype(np.uint32)
+        offsK = np.concatenate([ms["fvKF"][1], [ms["fvKF"][1][-1] + 3]]).astype(np.int32)
+        featK = np.concatenate([ms["fvKF"][2], ms["fvKF"][2][:3]]).astype(np.uint32)
+        n0, m0 = oracle.search_by_bow(ms["dKF"], ms["validKF"], ms["angKF"], (nodesK, offsK, featK), ms["dF"], ms["angF"], (nodes2, offs2, feat2), 0.7, True)
+        n1, m1 = m.SearchByBoW(ms["dKF"], ms["validKF"], ms["angKF"], (nodesK, offsK, featK), ms["dF"], ms["angF"], (nodes2, offs2, feat2))
+        assert n1 == n0
+        np.testing.assert_array_equal(m1, m0)
+        # empty frame
+        e = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32))
+        n1, m1 = m.SearchByBoW(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], np.zeros((0, 32), np.uint8), np.zeros(0, np.float32), e)
+        assert n1 == 0 and len(m1) == 0
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_search_by_bow_kfkf(pkg, oracle, synth, seed):
+    ms = synth.make_match_set(20 + seed, n=800)
+    rs = np.random.RandomState(seed)
+    valid2 = (rs.uniform(size=len(ms["dF"])) < 0.9).astype(np.uint8)
+    n0, m0 = oracle.search_by_bow_kfkf(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], valid2, ms["angF"], ms["fvF"], 0.8, True)
+    m = pkg.Matcher(0.8, True)
+    try:
+        n1, m1 = m.SearchByBoW_KFKF(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], valid2, ms["angF"], ms["fvF"])
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 50
+    np.testing.assert_array_equal(m1, m0)
+
+
+@pytest.mark.parametrize("seed,th,far", [(0, 1.0, False), (1, 3.0, False), (2, 15.0, True), (3, 1.0, False)])
+def test_search_by_projection(pkg, oracle, sm, seed, th, far):
+    g, dF, angF, scale, mp, assign, occ = sm.make_projection_case(seed)
+    a0, o0 = assign.copy(), occ.copy()
+    n0 = oracle.search_by_projection(g, dF, scale, mp, th, 0.8, a0, o0, b_far=far, th_far=20.0)
+    m = pkg.Matcher(0.8, True)
+    try:
+        a1, o1 = assign.copy(), occ.copy()
+        n1 = m.SearchByProjection(g, dF, scale, mp, th, a1, o1, far_points=far, th_far=20.0)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 100
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(o1, o0)
+
+
+@pytest.mark.parametrize("seed,th,ori", [(0, 7.0, True), (1, 15.0, True), (2, 15.0, False)])
+def test_search_by_projection_last_frame(pkg, oracle, sm, seed, th, ori):
+    g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(seed)
+    a0, o0 = assign.copy(), occ.copy()
+    n0 = oracle.search_by_projection_last(g, dF, angF, scale, last, th, ori, a0, o0)
+    m = pkg.Matcher(0.9, ori)
+    try:
+        a1, o1 = assign.copy(), occ.copy()
+        n1 = m.SearchByProjection_last(g, dF, angF, scale, last, th, a1, o1)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 100
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(o1, o0)
