@@ -28,5 +28,13 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package (ctypes mirror of the C ABI).  Loading fails loudly if the HIP library is missing."""
+    """The product package (ctypes mirror of the C ABI).  Loading fails loudly if the HIP library is missing.
+
+    torch is imported FIRST: its wheel bundles its own libamdhip64.so.7, and a process must end up with exactly one HIP
+    runtime.  With torch loaded first our library's DT_NEEDED libamdhip64.so.7 binds to that copy; the other order gives
+    torch a second runtime that sees no GPU ("No HIP GPUs are available")."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     return importlib.import_module("orb_slam3-1_amd")
