@@ -229,63 +229,78 @@ __global__ __launch_bounds__(256) void k_errors(Dev d, const double* __restrict_
 }
 
 // ---- buildSystem, landmark side: Hll, bl and the Hpl blocks W_e = B^T (rho1 Omega) A (6x3) ----
+// 8 lanes per landmark (a landmark has ~10 edges): lane q takes edges q, q+8, ...; fixed butterfly reduction.
 __global__ __launch_bounds__(64) void k_lin_landmarks(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
 {
-    const int l = blockIdx.x * 64 + threadIdx.x;
-    if (l >= d.nL) return;
-    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    const double* X = pts + 3 * (size_t)l;
-    for (int k = d.l_off[l]; k < d.l_off[l + 1]; k++) {
-        const int e = d.l_edge[k];
-        const int ip = d.e_pose[e];
-        const double* T = poses + 7 * (size_t)ip;
-        const int st = d.e_stereo[e];
-        const int D = st ? 3 : 2;
-        double Xc[3], Ji[9], Jj[18];
-        pose_map(T, X, Xc);
-        edge_jacobians(d.cam, T, Xc, st, Ji, Jj);
-        const double* r = d.err + 3 * (size_t)e;
-        const double w = d.e_w[e];
-        double chi = r[0] * (w * r[0]) + r[1] * (w * r[1]);
-        if (st) chi += r[2] * (w * r[2]);
-        double rho0, rho1;
-        huber(d.cam, st, chi, rho0, rho1);
-        const double wr = rho1 * w;
-        double orr[3];
-        for (int q = 0; q < 3; q++) orr[q] = (-(w * r[q])) * rho1;
-        for (int a = 0; a < 3; a++) {
-            double s = 0;
-            for (int q = 0; q < D; q++) s += Ji[q * 3 + a] * orr[q];
-            b[a] += s;
-            for (int c = 0; c < 3; c++) {
-                double h = 0;
-                for (int q = 0; q < D; q++) h += Ji[q * 3 + a] * wr * Ji[q * 3 + c];
-                H[a * 3 + c] += h;
+    const int l = blockIdx.x * 8 + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
+    const bool live = l < d.nL;
+    double acc[9];      // Hll upper triangle (6) + bl (3)
+    for (int k = 0; k < 9; k++) acc[k] = 0;
+    if (live) {
+        const double* X = pts + 3 * (size_t)l;
+        for (int k = d.l_off[l] + sub; k < d.l_off[l + 1]; k += 8) {
+            const int e = d.l_edge[k];
+            const int ip = d.e_pose[e];
+            const double* T = poses + 7 * (size_t)ip;
+            const int st = d.e_stereo[e];
+            const int D = st ? 3 : 2;
+            double Xc[3], Ji[9], Jj[18];
+            pose_map(T, X, Xc);
+            edge_jacobians(d.cam, T, Xc, st, Ji, Jj);
+            const double* r = d.err + 3 * (size_t)e;
+            const double w = d.e_w[e];
+            double chi = r[0] * (w * r[0]) + r[1] * (w * r[1]);
+            if (st) chi += r[2] * (w * r[2]);
+            double rho0, rho1;
+            huber(d.cam, st, chi, rho0, rho1);
+            const double wr = rho1 * w;
+            double orr[3];
+            for (int q = 0; q < 3; q++) orr[q] = (-(w * r[q])) * rho1;
+            int idx = 0;
+            for (int a = 0; a < 3; a++)
+                for (int c = a; c < 3; c++, idx++) {
+                    double h = 0;
+                    for (int q = 0; q < D; q++) h += Ji[q * 3 + a] * wr * Ji[q * 3 + c];
+                    acc[idx] += h;
+                }
+            for (int a = 0; a < 3; a++) {
+                double sv = 0;
+                for (int q = 0; q < D; q++) sv += Ji[q * 3 + a] * orr[q];
+                acc[6 + a] += sv;
+            }
+            if (d.pose_col[ip] >= 0) {
+                double* W = d.W + 18 * (size_t)e;
+                for (int a = 0; a < 6; a++)
+                    for (int c = 0; c < 3; c++) {
+                        double h = 0;
+                        for (int q = 0; q < D; q++) h += Jj[q * 6 + a] * wr * Ji[q * 3 + c];
+                        W[a * 3 + c] = h;
+                    }
             }
         }
-        if (d.pose_col[ip] >= 0) {
-            double* W = d.W + 18 * (size_t)e;
-            for (int a = 0; a < 6; a++)
-                for (int c = 0; c < 3; c++) {
-                    double h = 0;
-                    for (int q = 0; q < D; q++) h += Jj[q * 6 + a] * wr * Ji[q * 3 + c];
-                    W[a * 3 + c] = h;
-                }
-        }
     }
-    for (int k = 0; k < 9; k++) d.Hll[9 * (size_t)l + k] = H[k];
-    for (int k = 0; k < 3; k++) d.bl[3 * (size_t)l + k] = b[k];
+    for (int k = 0; k < 9; k++)
+        for (int o = 4; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if (live && sub == 0) {
+        double* H = d.Hll + 9 * (size_t)l;
+        H[0] = acc[0]; H[1] = acc[1]; H[2] = acc[2];
+        H[3] = acc[1]; H[4] = acc[3]; H[5] = acc[4];
+        H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
+        d.bl[3 * (size_t)l] = acc[6]; d.bl[3 * (size_t)l + 1] = acc[7]; d.bl[3 * (size_t)l + 2] = acc[8];
+    }
 }
 
-// ---- buildSystem, pose side: Hpp (6x6) and bp; one wave per non-fixed pose, ordered tree reduction ----
-__global__ __launch_bounds__(64) void k_lin_poses(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+// ---- buildSystem, pose side: Hpp (6x6) and bp; one 256-thread workgroup per non-fixed pose, fixed reduction tree ----
+__global__ __launch_bounds__(256) void k_lin_poses(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
 {
-    const int col = blockIdx.x, lane = threadIdx.x;
+    __shared__ double s_part[4][27];
+    const int col = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ip = d.col_pose[col];
     const double* T = poses + 7 * (size_t)ip;
     double acc[27];      // 21 upper-triangular entries of Hpp + 6 of bp
     for (int k = 0; k < 27; k++) acc[k] = 0;
-    for (int k = d.p_off[col] + lane; k < d.p_off[col + 1]; k += 64) {
+    for (int k = d.p_off[col] + tid; k < d.p_off[col + 1]; k += 256) {
         const int e = d.p_edge[k];
         const int st = d.e_stereo[e];
         const int D = st ? 3 : 2;
@@ -307,19 +322,26 @@ __global__ __launch_bounds__(64) void k_lin_poses(Dev d, const double* __restric
                 acc[idx] += h;
             }
         for (int a = 0; a < 6; a++) {
-            double s = 0;
-            for (int q = 0; q < D; q++) s += Jj[q * 6 + a] * ((-(w * r[q])) * rho1);
-            acc[21 + a] += s;
+            double sv = 0;
+            for (int q = 0; q < D; q++) sv += Jj[q * 6 + a] * ((-(w * r[q])) * rho1);
+            acc[21 + a] += sv;
         }
     }
     for (int k = 0; k < 27; k++)
         for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
-    if (lane == 0) {
-        int idx = 0;
-        double* H = d.Hpp + 36 * (size_t)col;
-        for (int a = 0; a < 6; a++)
-            for (int c = a; c < 6; c++, idx++) { H[a * 6 + c] = acc[idx]; H[c * 6 + a] = acc[idx]; }
-        for (int a = 0; a < 6; a++) d.bp[6 * (size_t)col + a] = acc[21 + a];
+    if (lane == 0) for (int k = 0; k < 27; k++) s_part[wave][k] = acc[k];
+    __syncthreads();
+    if (tid < 27) {
+        const double v = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
+        if (tid < 21) {
+            int a = 0, rem = tid;
+            while (rem >= 6 - a) { rem -= 6 - a; a++; }
+            const int c = a + rem;
+            double* H = d.Hpp + 36 * (size_t)col;
+            H[a * 6 + c] = v; H[c * 6 + a] = v;
+        } else {
+            d.bp[6 * (size_t)col + (tid - 21)] = v;
+        }
     }
 }
 
@@ -355,10 +377,11 @@ __global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode)
     }
 }
 
-// ---- Schur, landmark side (block_solver.hpp:381-395): Dinv, db, Z_e = W_e Dinv ----
+// ---- Schur, landmark side (block_solver.hpp:381-395): Dinv, db, Z_e = W_e Dinv; 8 lanes per landmark ----
 __global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
 {
-    const int l = blockIdx.x * 64 + threadIdx.x;
+    const int l = blockIdx.x * 8 + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 7;
     if (l >= d.nL) return;
     double A[9];
     for (int k = 0; k < 9; k++) A[k] = d.Hll[9 * (size_t)l + k] + ((k % 4 == 0) ? lambda : 0.0);
@@ -369,10 +392,12 @@ __global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
     Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
     Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
     Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-    for (int k = 0; k < 9; k++) d.Dinv[9 * (size_t)l + k] = Di[k];
-    const double* b = d.bl + 3 * (size_t)l;
-    for (int a = 0; a < 3; a++) d.db[3 * (size_t)l + a] = Di[a * 3] * b[0] + Di[a * 3 + 1] * b[1] + Di[a * 3 + 2] * b[2];
-    for (int k = d.l_off[l]; k < d.l_off[l + 1]; k++) {
+    if (sub == 0) {
+        for (int k = 0; k < 9; k++) d.Dinv[9 * (size_t)l + k] = Di[k];
+        const double* b = d.bl + 3 * (size_t)l;
+        for (int a = 0; a < 3; a++) d.db[3 * (size_t)l + a] = Di[a * 3] * b[0] + Di[a * 3 + 1] * b[1] + Di[a * 3 + 2] * b[2];
+    }
+    for (int k = d.l_off[l] + sub; k < d.l_off[l + 1]; k += 8) {
         const int e = d.l_edge[k];
         if (d.pose_col[d.e_pose[e]] < 0) continue;
         const double* W = d.W + 18 * (size_t)e;
@@ -382,37 +407,57 @@ __global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
     }
 }
 
-// ---- Schur, pose side: one wave per non-zero block (i<=j) of the reduced camera system ----
-// out: S (n x n, row-major, both triangles), bs (n), plus copies bp and diag(Hpp) for the multi-GPU reduce buffer.
-__global__ __launch_bounds__(64) void k_schur_blocks(Dev d, double* __restrict__ S, double* __restrict__ bs,
-                                                     double* __restrict__ bp_out, double* __restrict__ diag_out)
+// ---- Schur, pose side: one workgroup per non-zero block (i<=j) of the reduced camera system ----
+// 7 groups of 36 lanes split the block's (edge_a, edge_b) pair list; partials are combined in a fixed order.
+// out: S (n x n, row-major, both triangles).
+__global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict__ S)
 {
-    const int blk = blockIdx.x, lane = threadIdx.x;
+    __shared__ double s_part[7][36];
+    const int blk = blockIdx.x, tid = threadIdx.x;
     const int i = d.b_i[blk], j = d.b_j[blk];
     const int n = d.n;
-    if (lane < 36) {
-        const int r = lane / 6, c = lane % 6;
-        double acc = (i == j) ? d.Hpp[36 * (size_t)i + lane] : 0.0;
-        for (int k = d.b_off[blk]; k < d.b_off[blk + 1]; k++) {
+    const int g = tid / 36, ent = tid - g * 36;
+    if (g < 7) {
+        const int r = ent / 6, c = ent - r * 6;
+        double acc = 0.0;
+        for (int k = d.b_off[blk] + g; k < d.b_off[blk + 1]; k += 7) {
             const int2 pr = d.b_pair[k];
             const double* Z = d.Z + 18 * (size_t)pr.x + r * 3;
             const double* W = d.W + 18 * (size_t)pr.y + c * 3;
-            acc -= Z[0] * W[0] + Z[1] * W[1] + Z[2] * W[2];
+            acc += Z[0] * W[0] + Z[1] * W[1] + Z[2] * W[2];
         }
-        S[(size_t)(6 * i + r) * n + 6 * j + c] = acc;
-        if (i != j) S[(size_t)(6 * j + c) * n + 6 * i + r] = acc;
-    } else if (i == j && lane < 42) {
-        const int r = lane - 36;
-        double acc = d.bp[6 * (size_t)i + r];
-        for (int k = d.p_off[i]; k < d.p_off[i + 1]; k++) {
-            const int e = d.p_edge[k];
-            const double* W = d.W + 18 * (size_t)e + r * 3;
-            const double* db = d.db + 3 * (size_t)d.e_point[e];
-            acc -= W[0] * db[0] + W[1] * db[1] + W[2] * db[2];
-        }
-        bs[6 * i + r] = acc;
-        bp_out[6 * i + r] = d.bp[6 * (size_t)i + r];
-        diag_out[6 * i + r] = d.Hpp[36 * (size_t)i + r * 7];
+        s_part[g][ent] = acc;
+    }
+    __syncthreads();
+    if (tid < 36) {
+        const int r = tid / 6, c = tid - r * 6;
+        double sum = s_part[0][tid];
+        for (int q = 1; q < 7; q++) sum += s_part[q][tid];
+        const double v = ((i == j) ? d.Hpp[36 * (size_t)i + tid] : 0.0) - sum;
+        S[(size_t)(6 * i + r) * n + 6 * j + c] = v;
+        if (i != j) S[(size_t)(6 * j + c) * n + 6 * i + r] = v;
+    }
+}
+
+// b_schur = b_p - sum_e W_e db_l(e) (block_solver.hpp:413,436-439); one wave per non-fixed pose.  Also copies b_p and
+// diag(Hpp) into the reduce buffer (additive over shards).
+__global__ __launch_bounds__(64) void k_schur_b(Dev d, double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = d.p_off[i] + lane; k < d.p_off[i + 1]; k += 64) {
+        const int e = d.p_edge[k];
+        const double* W = d.W + 18 * (size_t)e;
+        const double* db = d.db + 3 * (size_t)d.e_point[e];
+        for (int r = 0; r < 6; r++) acc[r] += W[r * 3] * db[0] + W[r * 3 + 1] * db[1] + W[r * 3 + 2] * db[2];
+    }
+    for (int r = 0; r < 6; r++)
+        for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
+    if (lane < 6) {
+        const double a = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : lane == 3 ? acc[3] : lane == 4 ? acc[4] : acc[5];
+        bs[6 * i + lane] = d.bp[6 * (size_t)i + lane] - a;
+        bp_out[6 * i + lane] = d.bp[6 * (size_t)i + lane];
+        diag_out[6 * i + lane] = d.Hpp[36 * (size_t)i + lane * 7];
     }
 }
 
@@ -423,69 +468,83 @@ __global__ void k_add_lambda(double* S, int n, double lambda)
 }
 
 // ---- blocked right-looking Cholesky of the (dense, small) reduced camera system, lower triangle ----
-// panel: every workgroup re-factors the diagonal block in LDS (nb^3/3 flops, trivial) and solves its slice of the
-// rows below: X L^T = A.  Workgroup 0 also writes L_kk and its inverse (used by the block substitutions).
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int n, int k0, int nb, double* __restrict__ Linv, double* __restrict__ scal)
+// Per 60-column step: k_chol_diag factors the diagonal block AND inverts it (Gauss-Jordan on [L | I]) in LDS with
+// O(1)-depth steps; k_chol_panel then gets the rows below as a dense product X = A * Linv^T (no substitution chains);
+// k_chol_update applies the trailing update.  The substitutions in k_chol_solve also only need Linv.
+__global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
+                                                   double* __restrict__ Linv, double* __restrict__ scal)
 {
-    __shared__ double sL[NB * (NB + 1)];
-    __shared__ int s_fail;
+    constexpr int P = NB + 1;
+    __shared__ double sL[NB * P];
+    __shared__ double sI[NB * P];
     const int tid = threadIdx.x;
-    const int P = NB + 1;
-    if (tid == 0) s_fail = 0;
-    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i % nb; sL[r * P + c] = S[(size_t)(k0 + r) * n + k0 + c]; }
+    for (int i = tid; i < nb * nb; i += 256) {
+        const int r = i / nb, c = i - r * nb;
+        sL[r * P + c] = S[(size_t)(k0 + r) * n + k0 + c];
+        sI[r * P + c] = (r == c) ? 1.0 : 0.0;
+    }
     __syncthreads();
+    bool failed = false;
     for (int j = 0; j < nb; j++) {
-        if (tid == 0) {
-            const double dj = sL[j * P + j];
-            if (!(dj > 0.0) || !isfinite(dj)) s_fail = 1;
-            sL[j * P + j] = sqrt(dj);
-        }
-        __syncthreads();
-        if (s_fail) break;
-        const double ljj = sL[j * P + j];
+        const double djj = sL[j * P + j];           // = A_jj - sum_q L_jq^2 after the trailing updates; never overwritten
+        if (!(djj > 0.0) || !isfinite(djj)) { failed = true; break; }      // uniform: every thread reads the same value
+        const double ljj = sqrt(djj);
+        // column j of L below the diagonal, and row j of X = L^-1 (entries c <= j)
         for (int r = j + 1 + tid; r < nb; r += 256) sL[r * P + j] /= ljj;
+        for (int c = tid; c <= j; c += 256) sI[j * P + c] /= ljj;
         __syncthreads();
-        // trailing update of the diagonal block: (r, c) with j < c <= r
+        // trailing update of L: (r, c) with j < c <= r ; Gauss-Jordan update of X: rows r > j, columns c <= j
         const int m = nb - j - 1;
         for (int i = tid; i < m * m; i += 256) {
             const int r = j + 1 + i / m, c = j + 1 + i % m;
             if (c <= r) sL[r * P + c] -= sL[r * P + j] * sL[c * P + j];
         }
+        for (int i = tid; i < m * (j + 1); i += 256) {
+            const int r = j + 1 + i / (j + 1), c = i % (j + 1);
+            sI[r * P + c] -= sL[r * P + j] * sI[j * P + c];
+        }
         __syncthreads();
     }
-    if (s_fail) { if (tid == 0 && blockIdx.x == 0) scal[5] = 1.0; return; }
-    if (blockIdx.x == 0) {
-        // L_kk itself is NOT written back: other workgroups are still reading the unfactored block, and later steps
-        // only need its inverse.  inverse of L_kk: thread c solves L y = e_c
-        if (tid < nb) {
-            double* Li = Linv + (size_t)(k0 / NB) * NB * NB;
-            const int c = tid;
-            for (int r = 0; r < nb; r++) {
-                double s = (r == c) ? 1.0 : 0.0;
-                for (int q = c; q < r; q++) s -= sL[r * P + q] * Li[q * NB + c];
-                Li[r * NB + c] = (r < c) ? 0.0 : s / sL[r * P + r];
-            }
-        }
-    }
-    // rows below the diagonal block: one thread per row
-    const int row = k0 + nb + blockIdx.x * 256 + tid;
-    if (row < n) {
-        double* a = S + (size_t)row * n + k0;
-        for (int j = 0; j < nb; j++) {
-            double s = a[j];
-            for (int q = 0; q < j; q++) s -= a[q] * sL[j * P + q];
-            a[j] = s / sL[j * P + j];
+    if (failed) { if (tid == 0) scal[5] = 1.0; return; }
+    double* Li = Linv + (size_t)(k0 / NB) * NB * NB;
+    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i - r * nb; Li[r * NB + c] = (c <= r) ? sI[r * P + c] : 0.0; }
+}
+
+constexpr int kPanelRows = 64;
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int n, int k0, int nb, const double* __restrict__ Linv,
+                                                    const double* __restrict__ scal)
+{
+    constexpr int P = NB + 1;
+    __shared__ double sI[NB * P];
+    __shared__ double sA[kPanelRows * P];
+    if (scal[5] != 0.0) return;         // diagonal block was not positive definite
+    const int tid = threadIdx.x;
+    const int row0 = k0 + nb + blockIdx.x * kPanelRows;
+    const int nrows = min(kPanelRows, n - row0);
+    const double* Li = Linv + (size_t)(k0 / NB) * NB * NB;
+    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i - r * nb; sI[r * P + c] = Li[r * NB + c]; }
+    for (int i = tid; i < nrows * nb; i += 256) { const int r = i / nb, c = i - r * nb; sA[r * P + c] = S[(size_t)(row0 + r) * n + k0 + c]; }
+    __syncthreads();
+    // X = A * Linv^T :  X[r][c] = sum_{q <= c} A[r][q] * Linv[c][q]
+    const int r = tid >> 2;
+    if (r < nrows) {
+        const double* a = sA + r * P;
+        for (int c = tid & 3; c < nb; c += 4) {
+            const double* li = sI + c * P;
+            double sv = 0;
+            for (int q = 0; q <= c; q++) sv += a[q] * li[q];
+            S[(size_t)(row0 + r) * n + k0 + c] = sv;
         }
     }
 }
 
 // trailing update S22 -= L21 L21^T (lower triangle), 32x32 tiles, panel rows staged in LDS
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb)
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb, const double* __restrict__ scal)
 {
     __shared__ double sA[32 * (NB + 1)], sB[32 * (NB + 1)];
     const int base = k0 + nb;
     const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti) return;
+    if (tj > ti || scal[5] != 0.0) return;
     const int r0 = base + ti * 32, c0 = base + tj * 32;
     const int tid = threadIdx.x, P = NB + 1;
     for (int i = tid; i < 32 * nb; i += 256) {
@@ -498,56 +557,71 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
     for (int rr = tr; rr < 32; rr += 8) {
         const int r = r0 + rr, c = c0 + tc;
         if (r < n && c < n && c <= r) {
-            double s = 0;
-            for (int q = 0; q < nb; q++) s += sA[rr * P + q] * sB[tc * P + q];
-            S[(size_t)r * n + c] -= s;
+            double sv = 0;
+            for (int q = 0; q < nb; q++) sv += sA[rr * P + q] * sB[tc * P + q];
+            S[(size_t)r * n + c] -= sv;
         }
     }
 }
 
-// x = L^-T L^-1 b by block substitution with the inverted diagonal blocks; one workgroup.
+// x = L^-T L^-1 b by block substitution with the inverted diagonal blocks; one 1024-thread workgroup.
+// Row dot products are split over 16 lanes (coalesced along the row) / 16 row groups (coalesced along the column).
 __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ S, int n, const double* __restrict__ Linv,
-                                                     const double* __restrict__ b, double* __restrict__ x)
+                                                     const double* __restrict__ b, double* __restrict__ x, const double* __restrict__ scal)
 {
-    extern __shared__ double sm[];      // y[n], tmp[n]
+    extern __shared__ double sm[];      // y[n], t[64], part[16][64]
     double* y = sm;
     double* t = sm + n;
+    double* part = t + 64;
     const int tid = threadIdx.x;
+    if (scal[5] != 0.0) { for (int i = tid; i < n; i += 1024) x[i] = 0.0; return; }
     for (int i = tid; i < n; i += 1024) y[i] = b[i];
     __syncthreads();
     const int nblk = (n + NB - 1) / NB;
+    const int r16 = tid >> 4, l16 = tid & 15;       // 64 rows x 16 lanes
+    const int g64 = tid >> 6, r64 = tid & 63;       // 16 groups x 64 rows
     // forward: y_K = Linv_KK (b_K - sum_{J<K} L_KJ y_J)
     for (int K = 0; K < nblk; K++) {
         const int k0 = K * NB, nb = min(NB, n - k0);
-        for (int r = tid; r < nb; r += 1024) {
-            double s = y[k0 + r];
-            const double* Lr = S + (size_t)(k0 + r) * n;
-            for (int q = 0; q < k0; q++) s -= Lr[q] * y[q];
-            t[r] = s;
+        {
+            double sv = 0;
+            if (r16 < nb) {
+                const double* Lr = S + (size_t)(k0 + r16) * n;
+                for (int q = l16; q < k0; q += 16) sv += Lr[q] * y[q];
+            }
+            for (int o = 8; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+            if (r16 < nb && l16 == 0) t[r16] = y[k0 + r16] - sv;
         }
         __syncthreads();
-        const double* Li = Linv + (size_t)K * NB * NB;
-        for (int r = tid; r < nb; r += 1024) {
-            double s = 0;
-            for (int q = 0; q <= r; q++) s += Li[r * NB + q] * t[q];
-            y[k0 + r] = s;
+        {
+            const double* Li = Linv + (size_t)K * NB * NB;
+            double sv = 0;
+            if (r16 < nb) for (int q = l16; q <= r16; q += 16) sv += Li[r16 * NB + q] * t[q];
+            for (int o = 8; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+            if (r16 < nb && l16 == 0) y[k0 + r16] = sv;
         }
         __syncthreads();
     }
     // backward: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J)
     for (int K = nblk - 1; K >= 0; K--) {
         const int k0 = K * NB, nb = min(NB, n - k0);
-        for (int r = tid; r < nb; r += 1024) {
-            double s = y[k0 + r];
-            for (int q = k0 + nb; q < n; q++) s -= S[(size_t)q * n + k0 + r] * y[q];
-            t[r] = s;
+        {
+            double sv = 0;
+            if (r64 < nb) for (int q = k0 + nb + g64; q < n; q += 16) sv += S[(size_t)q * n + k0 + r64] * y[q];
+            part[g64 * 64 + r64] = sv;
         }
         __syncthreads();
-        const double* Li = Linv + (size_t)K * NB * NB;
-        for (int r = tid; r < nb; r += 1024) {
-            double s = 0;
-            for (int q = r; q < nb; q++) s += Li[q * NB + r] * t[q];
-            y[k0 + r] = s;
+        if (tid < nb) {
+            double sv = 0;
+            for (int g = 0; g < 16; g++) sv += part[g * 64 + tid];
+            t[tid] = y[k0 + tid] - sv;
+        }
+        __syncthreads();
+        if (tid < nb) {
+            const double* Li = Linv + (size_t)K * NB * NB;
+            double sv = 0;
+            for (int q = tid; q < nb; q++) sv += Li[q * NB + tid] * t[q];
+            y[k0 + tid] = sv;
         }
         __syncthreads();
     }
@@ -636,6 +710,8 @@ struct lba_shard {
     int cur = 0;                // index of the accepted state; 1-cur holds the trial state
     double* reduce = nullptr;   // [n*n | bs n | bp n | diag n]
     double* Linv = nullptr;
+    double* Ldiag = nullptr;
+    bool sync_after_reduce = true;      // lba_solve() keeps everything on one stream and turns this off
     double* d_chi2 = nullptr;
     uint8_t* d_depth = nullptr;
     double* h_scal = nullptr;   // pinned [16]
@@ -769,6 +845,7 @@ int lba_shard_create(int device, const LbaProblem* p, lba_shard** out)
     LBA_TRY(s->dalloc(&s->reduce, (size_t)s->reduce_len));
     s->nblk = (d.n + lba::NB - 1) / lba::NB;
     LBA_TRY(s->dalloc(&s->Linv, (size_t)std::max(s->nblk, 1) * lba::NB * lba::NB));
+    LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
     if (hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "stream create failed"); }
@@ -838,8 +915,8 @@ int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses
     const double* P = s->poses[s->cur];
     const double* X = s->pts[s->cur];
     if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, P, X);
-    if (d.nL > 0) hipLaunchKernelGGL(lba::k_lin_landmarks, dim3((d.nL + 63) / 64), dim3(64), 0, s->stream, d, P, X);
-    if (d.nP > 0) hipLaunchKernelGGL(lba::k_lin_poses, dim3(d.nP), dim3(64), 0, s->stream, d, P, X);
+    if (d.nL > 0) hipLaunchKernelGGL(lba::k_lin_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, P, X);
+    if (d.nP > 0) hipLaunchKernelGGL(lba::k_lin_poses, dim3(d.nP), dim3(256), 0, s->stream, d, P, X);
     hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0);
     LBA_HIP(hipGetLastError());
     int r = read_scalars(s);
@@ -858,10 +935,11 @@ int lba_shard_reduce(lba_shard* s, double lambda)
     LBA_HIP(hipSetDevice(s->device));
     const lba::Dev& d = s->d;
     LBA_HIP(hipMemsetAsync(s->reduce, 0, (size_t)s->reduce_len * sizeof(double), s->stream));
-    if (d.nL > 0) hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 63) / 64), dim3(64), 0, s->stream, d, lambda);
-    if (d.nBlocks > 0) hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks), dim3(64), 0, s->stream, d, s->S(), s->bs(), s->bpf(), s->diag());
+    if (d.nL > 0) hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, lambda);
+    if (d.nBlocks > 0) hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks), dim3(256), 0, s->stream, d, s->S());
+    if (d.nP > 0) hipLaunchKernelGGL(lba::k_schur_b, dim3(d.nP), dim3(64), 0, s->stream, d, s->bs(), s->bpf(), s->diag());
     LBA_HIP(hipGetLastError());
-    LBA_HIP(hipStreamSynchronize(s->stream));      // the caller may hand the buffer to RCCL on another stream
+    if (s->sync_after_reduce) LBA_HIP(hipStreamSynchronize(s->stream));      // the caller hands the buffer to RCCL on another stream
     return ORBX_OK;
 }
 
@@ -883,13 +961,16 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
         for (int K = 0; K < s->nblk; K++) {
             const int k0 = K * lba::NB, nb = std::min(lba::NB, n - k0);
             const int rows_below = n - k0 - nb;
-            hipLaunchKernelGGL(lba::k_chol_panel, dim3(std::max((rows_below + 255) / 256, 1)), dim3(256), 0, s->stream, s->S(), n, k0, nb, s->Linv, d.scal);
+            hipLaunchKernelGGL(lba::k_chol_diag, dim3(1), dim3(256), 0, s->stream, (const double*)s->S(), n, k0, nb, s->Linv, d.scal);
             if (rows_below > 0) {
+                hipLaunchKernelGGL(lba::k_chol_panel, dim3((rows_below + lba::kPanelRows - 1) / lba::kPanelRows), dim3(256), 0, s->stream,
+                                   s->S(), n, k0, nb, (const double*)s->Linv, (const double*)d.scal);
                 const int t = (rows_below + 31) / 32;
-                hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, k0, nb);
+                hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, k0, nb, (const double*)d.scal);
             }
         }
-        hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), 2 * (size_t)n * sizeof(double), s->stream, s->S(), n, s->Linv, s->bs(), d.x);
+        hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), ((size_t)n + 64 + 16 * 64) * sizeof(double), s->stream,
+                           (const double*)s->S(), n, (const double*)s->Linv, (const double*)s->bs(), d.x, (const double*)d.scal);
     }
     hipLaunchKernelGGL(lba::k_backsub_update, dim3((d.nL + d.nPoses + 63) / 64), dim3(64), 0, s->stream, d, lambda, s->bpf(), P, X, Pn, Xn);
     if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, (const double*)Pn, (const double*)Xn);
@@ -957,6 +1038,7 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
     lba_shard* s = nullptr;
     int r = lba_shard_create(sv->device, problem, &s);
     if (r) return r;
+    s->sync_after_reduce = false;
     LbaStats st;
     std::memset(&st, 0, sizeof(st));
     double lambda = -1, ni = 2;

@@ -104,7 +104,7 @@ struct orbx_extractor {
     std::vector<TileDesc> tiles;
     size_t pyr_frame_bytes = 0;
     int cand_frame_entries = 0, sel_frame_entries = 0;
-    int tile_pitch = 0, tile_rows = 0, m_pitch = 0, m_rows = 0;
+    int tile_pitch = 0, tile_rows = 0, m_pitch = 0, m_rows = 0, surv_off = 0;
     size_t fast_lds = 0, oct_lds = 0;
     int oct_pool = 0, oct_lds_keys = 0;
 
@@ -272,12 +272,15 @@ int orbx_extractor::setup_geometry(int w, int h)
     m_rows = std::max(max_th - 6, 1) + 2;
     fast_lds = (size_t)tile_rows * tile_pitch + (size_t)m_rows * m_pitch + 64;
     fast_lds = (fast_lds + 15) & ~(size_t)15;
+    surv_off = (int)fast_lds;
+    fast_lds += 2 * (size_t)std::max(max_tw - 6, 1) * std::max(max_th - 6, 1) + 16;
+    fast_lds = (fast_lds + 15) & ~(size_t)15;
     if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST cell of %dx%d px does not fit LDS", max_tw, max_th);
     // octree kernel LDS
     oct_pool = max_nfeat + 16;
     if (oct_pool > 16000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree", max_nfeat);
     const char* env = getenv("ORBX_OCT_LDS_KEYS");
-    oct_lds_keys = env ? atoi(env) : 6144;
+    oct_lds_keys = env ? atoi(env) : 0;      // measured on MI355X: L2-resident HBM scratch + more resident waves beats LDS keys
     const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 16) + (size_t)((oct_pool + 15) & ~15);
     if (node_bytes + 8 * (size_t)oct_lds_keys > 150 * 1024) oct_lds_keys = (int)((150 * 1024 - node_bytes) / 8);
     if (oct_lds_keys < 0) oct_lds_keys = 0;
@@ -351,7 +354,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     const int n_cells = (int)cells.size();
     if (n_cells > 0)
         hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
-                           ini_th, min_th, tile_pitch, tile_rows, m_pitch, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
+                           ini_th, min_th, tile_pitch, tile_rows, m_pitch, surv_off, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
     mark();
     hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), oct_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
                        d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, oct_lds_keys,

@@ -101,15 +101,17 @@ __device__ __forceinline__ int fast_m(const uint8_t* __restrict__ t, int pitch)
 // 1-px zero halo (NMS must treat everything outside the cell's own interior as 0), 2-bit pass flags.
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t frame_stride,
                                                     const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
-                                                    int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch,
+                                                    int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch, int surv_off,
                                                     uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                     int* __restrict__ cell_count, int n_cells)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* tile = smem;                                   // tile_rows x tile_pitch
     uint8_t* mt = smem + (size_t)tile_rows * tile_pitch;    // (ih+2) x m_pitch
+    uint16_t* surv = (uint16_t*)(smem + surv_off);          // survivors of the quick test (pixel index inside the cell)
     __shared__ int s_wave_cnt[4];
     __shared__ int s_ini_total;
+    __shared__ int s_nsurv;
 
     const CellDesc c = cells[blockIdx.x];
     const LevelDesc L = levels[c.level];
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const int shift = c.x0 - xa;
     const int row_dw = (shift + tw + 3) >> 2;           // dwords per tile row
 
-    if (tid == 0) s_ini_total = 0;
+    if (tid == 0) { s_ini_total = 0; s_nsurv = 0; }
     // load tile: coalesced dword loads, rows are 64-B aligned in HBM
     for (int i = tid; i < th * row_dw; i += 256) {
         const int r = i / row_dw, q = i - r * row_dw;
@@ -132,9 +134,40 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     // zero the M tile (halo included)
     for (int i = tid; i < (ih + 2) * m_pitch / 4; i += 256) ((uint32_t*)mt)[i] = 0;
     __syncthreads();
-    // scores
+    // scores, two passes: (1) the exact necessary condition for "corner at minThFAST" -- in each of the 8 opposite ring
+    // pairs (k, k+8) at least one pixel is beyond the threshold with the same polarity (a 9-arc covers one pixel of
+    // every pair) -- rejects most pixels with 16 loads and a few compares; survivors are compacted into an LDS list.
+    // (2) the full arc min/max tree runs densely on the survivors only.  Rejected pixels keep M = 0, which is what the
+    // NMS and the threshold tests below see for any pixel with M <= minThFAST anyway.
     const int n_int = iw * ih;
     for (int q = tid; q < n_int; q += 256) {
+        const int y = q / iw, x = q - y * iw;
+        const uint8_t* t = tile + (y + 3) * tile_pitch + shift + x + 3;
+        const int pitch = tile_pitch;
+        const int v = t[0];
+        const int lo = v - min_th, hi = v + min_th;     // dark: ring < lo, bright: ring > hi
+        int r0 = t[3 * pitch], r8 = t[-3 * pitch];
+        int dark = (r0 < lo) | (r8 < lo), bright = (r0 > hi) | (r8 > hi);
+        if (dark | bright) {
+            int a, b;
+#define ORBX_PAIR(oa, ob) a = t[oa]; b = t[ob]; dark &= (a < lo) | (b < lo); bright &= (a > hi) | (b > hi);
+            ORBX_PAIR(3, -3)
+            ORBX_PAIR(-2 * pitch + 2, 2 * pitch - 2)
+            ORBX_PAIR(2 * pitch + 2, -2 * pitch - 2)
+            if (dark | bright) {
+                ORBX_PAIR(3 * pitch + 1, -3 * pitch - 1)
+                ORBX_PAIR(pitch + 3, -pitch - 3)
+                ORBX_PAIR(-pitch + 3, pitch - 3)
+                ORBX_PAIR(-3 * pitch + 1, 3 * pitch - 1)
+            }
+#undef ORBX_PAIR
+            if (dark | bright) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)q;
+        }
+    }
+    __syncthreads();
+    const int nsurv = s_nsurv;
+    for (int i = tid; i < nsurv; i += 256) {
+        const int q = surv[i];
         const int y = q / iw, x = q - y * iw;
         const int m = fast_m(tile + (y + 3) * tile_pitch + shift + x + 3, tile_pitch);
         mt[(y + 1) * m_pitch + x + 1] = (uint8_t)m;
@@ -512,42 +545,70 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                                               const LevelDesc* __restrict__ levels, const TileDesc* __restrict__ tiles,
                                               int t0, int t1, int t2, int t3)
 {
-    __shared__ uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
-    __shared__ uint16_t s_h[(kBlurTH + 6) * kBlurTW];
+    __shared__ __align__(16) uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
+    __shared__ __align__(16) uint16_t s_h[(kBlurTH + 6) * kBlurTW];
     const TileDesc T = tiles[blockIdx.x];
     const LevelDesc L = levels[T.level];
     const uint8_t* img = pyr + (size_t)blockIdx.y * frame_stride + L.off;
     uint8_t* dst = blur + (size_t)blockIdx.y * frame_stride + L.off;
     const int tid = threadIdx.x;
     const int x0 = T.x0, y0 = T.y0;
-    constexpr int SP = kBlurTW + 8;
-    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
-        const int r = i / (kBlurTW + 6), c = i - r * (kBlurTW + 6);
-        const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 + c - 3, L.w);
-        s_src[r * SP + c] = img[(size_t)sy * L.stride + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i / kBlurTW, c = i - r * kBlurTW;
-        const uint8_t* p = s_src + r * SP + c;
-        const uint32_t acc = (uint32_t)t0 * (p[0] + p[6]) + (uint32_t)t1 * (p[1] + p[5]) + (uint32_t)t2 * (p[2] + p[4]) + (uint32_t)t3 * p[3];
-        s_h[i] = (uint16_t)min(acc, 65535u);
-    }
-    __syncthreads();
-    // 4 output pixels per thread (one dword store)
-    for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
-        const int r = i / (kBlurTW / 4), c4 = (i - r * (kBlurTW / 4)) * 4;
-        const int oy = y0 + r;
-        if (oy >= L.h || x0 + c4 >= L.w) continue;
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint16_t* h = s_h + r * kBlurTW + c4 + k;
-            const uint32_t acc = (uint32_t)t0 * ((uint32_t)h[0] + h[6 * kBlurTW]) + (uint32_t)t1 * ((uint32_t)h[kBlurTW] + h[5 * kBlurTW]) +
-                                 (uint32_t)t2 * ((uint32_t)h[2 * kBlurTW] + h[4 * kBlurTW]) + (uint32_t)t3 * h[3 * kBlurTW];
-            packed |= min((acc + 0x8000u) >> 16, 255u) << (8 * k);
+    constexpr int SP = kBlurTW + 8;         // LDS row = source columns x0-4 .. x0+67 (18 dwords)
+    const bool interior = (x0 >= 4) && (x0 + kBlurTW + 4 <= L.stride) && (x0 + kBlurTW + 3 <= L.w) && (y0 >= 3) && (y0 + kBlurTH + 3 <= L.h);
+    if (interior) {
+        // rows are 64-B aligned and x0 is a multiple of 64: aligned dword loads, no reflection needed
+        for (int i = tid; i < (kBlurTH + 6) * (SP / 4); i += 256) {
+            const int r = i / (SP / 4), q = i - r * (SP / 4);
+            *(uint32_t*)(s_src + r * SP + 4 * q) = *(const uint32_t*)(img + (size_t)(y0 + r - 3) * L.stride + x0 - 4 + 4 * q);
         }
-        *(uint32_t*)(dst + (size_t)oy * L.stride + x0 + c4) = packed;   // row padding absorbs the tail of the last dword
+    } else {
+        for (int i = tid; i < (kBlurTH + 6) * SP; i += 256) {
+            const int r = i / SP, c = i - r * SP;
+            const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 - 4 + c, L.w);
+            s_src[i] = img[(size_t)sy * L.stride + sx];
+        }
+    }
+    __syncthreads();
+    // horizontal pass: one work item = 4 adjacent outputs, fed by three aligned dword LDS reads (12 source bytes)
+    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW / 4); i += 256) {
+        const int r = i / (kBlurTW / 4), q = i - r * (kBlurTW / 4);
+        const uint32_t* w = (const uint32_t*)(s_src + r * SP) + q;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xFFu; b[4 + k] = (w1 >> (8 * k)) & 0xFFu; b[8 + k] = (w2 >> (8 * k)) & 0xFFu; }
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)        // output column 4q+k uses source bytes k+1 .. k+7 of the 12
+            o[k] = min((uint32_t)t0 * (b[k + 1] + b[k + 7]) + (uint32_t)t1 * (b[k + 2] + b[k + 6]) + (uint32_t)t2 * (b[k + 3] + b[k + 5]) + (uint32_t)t3 * b[k + 4], 65535u);
+        uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
+        *(uint2*)(s_h + r * kBlurTW + 4 * q) = pk;
+    }
+    __syncthreads();
+    // vertical pass: one work item = 2 rows x 4 columns of outputs, fed by eight 8-byte LDS reads
+    {
+        const int q = tid & 15, g = tid >> 4;          // 16 column quads x 16 row pairs
+        const int c4 = 4 * q, r0 = 2 * g;
+        uint32_t h[8][4];
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) {
+            const uint2 v = *(const uint2*)(s_h + (r0 + rr) * kBlurTW + c4);
+            h[rr][0] = v.x & 0xFFFFu; h[rr][1] = v.x >> 16; h[rr][2] = v.y & 0xFFFFu; h[rr][3] = v.y >> 16;
+        }
+#pragma unroll
+        for (int orow = 0; orow < 2; orow++) {
+            const int oy = y0 + r0 + orow;
+            if (oy < L.h && x0 + c4 < L.w) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t acc = (uint32_t)t0 * (h[orow][k] + h[orow + 6][k]) + (uint32_t)t1 * (h[orow + 1][k] + h[orow + 5][k]) +
+                                         (uint32_t)t2 * (h[orow + 2][k] + h[orow + 4][k]) + (uint32_t)t3 * h[orow + 3][k];
+                    packed |= min((acc + 0x8000u) >> 16, 255u) << (8 * k);
+                }
+                *(uint32_t*)(dst + (size_t)oy * L.stride + x0 + c4) = packed;   // row padding absorbs the tail of the last dword
+            }
+        }
     }
 }
 
