@@ -257,6 +257,8 @@ int64_t lba_shard_reduce_len(const lba_shard* s);
 double* lba_shard_reduce_buffer(lba_shard* s);
 /* optional: use a caller-owned device buffer of lba_shard_reduce_len() doubles (e.g. a torch CUDA tensor) instead */
 int lba_shard_set_reduce_buffer(lba_shard* s, double* device_buffer);
+/* local != 0: world size 1, no all-reduce between reduce() and finish() -> lambda is folded into the Schur kernel, no sync */
+int lba_shard_set_local(lba_shard* s, int local);
 int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses_local, double* max_diag_landmarks_local);
 int lba_shard_reduce(lba_shard* s, double lambda);
 /* returns 1 if the reduced system was solved, 0 if it was not positive definite (step is rejected), <0 on error.

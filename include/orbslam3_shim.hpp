@@ -1,0 +1,399 @@
+// orbslam3_shim.hpp -- header-only C++ adapter from the C ABI (orbslam3_hip.h) to the reference's own call signatures,
+// so that Tracking / LocalMapping / Frame compile and run unchanged.
+//
+// It is written against the reference's real types (cv::Mat, cv::KeyPoint, ORB_SLAM3::Frame, KeyFrame, MapPoint, Map,
+// Sophus::SE3f) and is therefore only compilable INSIDE an ORB-SLAM3 tree that has OpenCV / Eigen / Sophus -- which this
+// image lacks (that is why the repo's own tests drive the C ABI through ctypes instead).  Define ORBSLAM3_HIP_WITH_REFERENCE
+// before including it from the reference tree; without the macro the header only provides the POD-level C++ wrappers that
+// need nothing but the C ABI, which IS compiled by tests/test_shim_compiles.py.
+//
+// Reference signatures mirrored here:
+//   int  ORBextractor::operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&, cv::OutputArray,
+//                                 std::vector<int>& vLappingArea)                       include/ORBextractor.h:57-59
+//   int  ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&)            include/ORBmatcher.h:56
+//   int  ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, float, bool, float)   :43
+//   int  ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)               :47
+//   static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)            :40
+//   static void Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&, int&, int&, int&)     include/Optimizer.h:58
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "orbslam3_hip.h"
+
+namespace orbslam3_hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c) : std::runtime_error(std::string("orbslam3_hip: ") + orbx_last_error()), code(c) {}
+};
+inline int check(int rc) { if (rc < 0 && rc != ORBX_ERR_EMPTY) throw Error(rc); return rc; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// POD-level wrappers (need only the C ABI)
+// ---------------------------------------------------------------------------------------------------------------
+class Extractor {
+public:
+    Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0)
+    { check(orbx_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, &h_)); }
+    ~Extractor() { orbx_destroy(h_); }
+    Extractor(const Extractor&) = delete;
+    Extractor& operator=(const Extractor&) = delete;
+
+    // returns the reference's return value (monoIndex, -1 for an empty image)
+    int extract(const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
+                std::vector<OrbxKeyPoint>& kps, std::vector<uint8_t>& desc)
+    {
+        const int cap = orbx_max_keypoints(h_);
+        kps.resize(cap);
+        desc.resize((size_t)cap * 32);
+        int n = 0, mono = -1;
+        const int rc = orbx_extract(h_, img, w, h, stride, lap0, lap1, kps.data(), desc.data(), cap, &n, &mono);
+        if (rc == ORBX_ERR_EMPTY) { kps.clear(); desc.clear(); return -1; }
+        check(rc);
+        kps.resize(n);
+        desc.resize((size_t)n * 32);
+        return mono;
+    }
+    int GetLevels() const { return orbx_levels(h_); }
+    float GetScaleFactor() const { return orbx_scale_factor(h_); }
+    std::vector<float> GetScaleFactors() const { return table(0); }
+    std::vector<float> GetInverseScaleFactors() const { return table(1); }
+    std::vector<float> GetScaleSigmaSquares() const { return table(2); }
+    std::vector<float> GetInverseScaleSigmaSquares() const { return table(3); }
+    orbx_extractor* handle() { return h_; }
+
+private:
+    std::vector<float> table(int which) const
+    {
+        std::vector<float> t[4];
+        for (auto& v : t) v.resize(orbx_levels(h_));
+        orbx_scale_tables(h_, t[0].data(), t[1].data(), t[2].data(), t[3].data());
+        return t[which];
+    }
+    orbx_extractor* h_ = nullptr;
+};
+
+// DBoW2::FeatureVector (std::map<unsigned, std::vector<unsigned>>-like) -> CSR
+template <class FeatVecMap>
+struct FlatFeatVec {
+    std::vector<uint32_t> node, feat;
+    std::vector<int32_t> off;
+    OrbmFeatVec view;
+    explicit FlatFeatVec(const FeatVecMap& fv)
+    {
+        off.push_back(0);
+        for (auto it = fv.begin(); it != fv.end(); ++it) {
+            node.push_back((uint32_t)it->first);
+            for (unsigned f : it->second) feat.push_back(f);
+            off.push_back((int32_t)feat.size());
+        }
+        view.n_nodes = (int32_t)node.size();
+        view.node_id = node.data(); view.offset = off.data(); view.feat = feat.data();
+    }
+};
+
+}  // namespace orbslam3_hip
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reference-typed adapters (compile inside an ORB-SLAM3 tree only)
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef ORBSLAM3_HIP_WITH_REFERENCE
+
+#include <algorithm>
+#include <list>
+#include <map>
+#include <mutex>
+#include <opencv2/core/core.hpp>
+
+#include "Frame.h"
+#include "KeyFrame.h"
+#include "Map.h"
+#include "MapPoint.h"
+
+namespace ORB_SLAM3 {
+
+// Drop-in for ORB_SLAM3::ORBextractor (same public surface incl. mvImagePyramid, filled lazily on request).
+class ORBextractorHIP {
+public:
+    ORBextractorHIP(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+        : ex_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) { mvImagePyramid.resize(nlevels); }
+
+    int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                   cv::OutputArray _descriptors, std::vector<int>& vLappingArea)
+    {
+        if (_image.empty()) return -1;
+        cv::Mat image = _image.getMat();
+        assert(image.type() == CV_8UC1);
+        std::vector<OrbxKeyPoint> kps;
+        std::vector<uint8_t> desc;
+        const int mono = ex_.extract(image.data, image.cols, image.rows, (int)image.step, vLappingArea[0], vLappingArea[1], kps, desc);
+        static_assert(sizeof(cv::KeyPoint) == sizeof(OrbxKeyPoint), "cv::KeyPoint layout");
+        _keypoints.resize(kps.size());
+        if (!kps.empty()) std::memcpy((void*)_keypoints.data(), kps.data(), kps.size() * sizeof(OrbxKeyPoint));
+        if (kps.empty()) _descriptors.release();
+        else {
+            _descriptors.create((int)kps.size(), 32, CV_8U);
+            std::memcpy(_descriptors.getMat().data, desc.data(), desc.size());
+        }
+        pyramid_valid_ = false;
+        return mono;
+    }
+    // Frame::ComputeStereoMatches reads mvImagePyramid (src/Frame.cc:938,1028,1043): materialise it on demand, with the
+    // EDGE_THRESHOLD border exactly as ComputePyramid lays it out (level image = ROI inside the bordered buffer).
+    void SyncPyramid()
+    {
+        if (pyramid_valid_) return;
+        for (int l = 0; l < ex_.GetLevels(); l++) {
+            int w, h;
+            orbslam3_hip::check(orbx_pyramid_level_size(ex_.handle(), l, &w, &h));
+            cv::Mat temp(h + 38, w + 38, CV_8UC1);
+            orbslam3_hip::check(orbx_pyramid_level(ex_.handle(), 0, l, 19, temp.data, (int)temp.step));
+            mvImagePyramid[l] = temp(cv::Rect(19, 19, w, h));
+        }
+        pyramid_valid_ = true;
+    }
+    int GetLevels() { return ex_.GetLevels(); }
+    float GetScaleFactor() { return ex_.GetScaleFactor(); }
+    std::vector<float> GetScaleFactors() { return ex_.GetScaleFactors(); }
+    std::vector<float> GetInverseScaleFactors() { return ex_.GetInverseScaleFactors(); }
+    std::vector<float> GetScaleSigmaSquares() { return ex_.GetScaleSigmaSquares(); }
+    std::vector<float> GetInverseScaleSigmaSquares() { return ex_.GetInverseScaleSigmaSquares(); }
+    std::vector<cv::Mat> mvImagePyramid;
+
+private:
+    orbslam3_hip::Extractor ex_;
+    bool pyramid_valid_ = false;
+};
+
+// Drop-in for the ORBmatcher calls on the hot path.
+class ORBmatcherHIP {
+public:
+    ORBmatcherHIP(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri)
+    { orbslam3_hip::check(orbm_create(0, &m_)); }
+    ~ORBmatcherHIP() { orbm_destroy(m_); }
+
+    static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return orbm_hamming(a.ptr<uint8_t>(), b.ptr<uint8_t>()); }
+
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches)
+    {
+        const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+        const int nKF = (int)vpMapPointsKF.size(), nF = F.N;
+        std::vector<uint8_t> valid(nKF);
+        std::vector<float> angKF(nKF), angF(nF);
+        for (int i = 0; i < nKF; i++) { valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad(); angKF[i] = pKF->mvKeysUn[i].angle; }
+        for (int i = 0; i < nF; i++) angF[i] = F.mvKeys[i].angle;
+        orbslam3_hip::FlatFeatVec<DBoW2::FeatureVector> fvKF(pKF->mFeatVec), fvF(F.mFeatVec);
+        std::vector<int32_t> match(nF, -1);
+        const int n = orbslam3_hip::check(orbm_search_by_bow(m_, pKF->mDescriptors.data, nKF, valid.data(), angKF.data(), &fvKF.view,
+                                                              F.mDescriptors.data, nF, angF.data(), &fvF.view,
+                                                              mfNNratio, mbCheckOrientation, match.data()));
+        vpMapPointMatches.assign(nF, static_cast<MapPoint*>(NULL));
+        for (int f = 0; f < nF; f++) if (match[f] >= 0) vpMapPointMatches[f] = vpMapPointsKF[match[f]];
+        return n;
+    }
+
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
+    {
+        const int nMP = (int)vpMapPoints.size(), nF = F.N;
+        std::vector<uint8_t> inView(nMP), hasObs(nMP), bad(nMP), desc((size_t)nMP * 32), occ(nF);
+        std::vector<float> u(nMP), v(nMP), vc(nMP), depth(nMP);
+        std::vector<int32_t> lvl(nMP), assign(nF, -2);
+        for (int i = 0; i < nMP; i++) {
+            MapPoint* p = vpMapPoints[i];
+            inView[i] = p->mbTrackInView; u[i] = p->mTrackProjX; v[i] = p->mTrackProjY; lvl[i] = p->mnTrackScaleLevel;
+            vc[i] = p->mTrackViewCos; depth[i] = p->mTrackDepth; bad[i] = p->isBad(); hasObs[i] = p->Observations() > 0;
+            const cv::Mat d = p->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        OrbmFrame f = frameView(F, occ);
+        const int n = orbslam3_hip::check(orbm_search_by_projection(m_, &f, nMP, inView.data(), u.data(), v.data(), lvl.data(), vc.data(),
+                                                                     depth.data(), desc.data(), hasObs.data(), bad.data(),
+                                                                     th, bFarPoints, thFarPoints, mfNNratio, assign.data(), occ.data()));
+        for (int i = 0; i < nF; i++) if (assign[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assign[i]];
+        return n;
+    }
+
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
+    {
+        (void)bMono;    // the stereo forward/backward branches are not on the accelerated path; callers keep the reference for them
+        const int nL = LastFrame.N, nF = CurrentFrame.N;
+        const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+        std::vector<uint8_t> valid(nL, 0), hasObs(nL, 0), desc((size_t)nL * 32, 0), occ(nF);
+        std::vector<float> u(nL, 0.f), v(nL, 0.f), ang(nL, 0.f);
+        std::vector<int32_t> oct(nL, 0), assign(nF, -2);      // -2 = untouched, -1 = nulled by the rotation check (:1878)
+        for (int i = 0; i < nL; i++) {
+            MapPoint* p = LastFrame.mvpMapPoints[i];
+            if (!p || LastFrame.mvbOutlier[i]) continue;
+            const Eigen::Vector3f x3Dc = Tcw * p->GetWorldPos();           // the reference's own float expressions (:1701-1710)
+            const float invzc = 1.0 / x3Dc(2);
+            if (invzc < 0) continue;
+            const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+            valid[i] = 1; u[i] = uv(0); v[i] = uv(1);
+            oct[i] = LastFrame.mvKeys[i].octave; ang[i] = LastFrame.mvKeysUn[i].angle; hasObs[i] = p->Observations() > 0;
+            const cv::Mat d = p->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        OrbmFrame f = frameView(CurrentFrame, occ);
+        const int n = orbslam3_hip::check(orbm_search_by_projection_last(m_, &f, nL, valid.data(), u.data(), v.data(), oct.data(), ang.data(),
+                                                                          desc.data(), hasObs.data(), th, mbCheckOrientation,
+                                                                          assign.data(), occ.data()));
+        for (int i = 0; i < nF; i++) {
+            if (assign[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[assign[i]];
+            else if (assign[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint*>(NULL);
+        }
+        return n;
+    }
+
+private:
+    OrbmFrame frameView(Frame& F, std::vector<uint8_t>& occ)
+    {
+        const int n = F.N;
+        x_.resize(n); y_.resize(n); o_.resize(n); a_.resize(n);
+        for (int i = 0; i < n; i++) {
+            x_[i] = F.mvKeysUn[i].pt.x; y_[i] = F.mvKeysUn[i].pt.y; o_[i] = F.mvKeysUn[i].octave; a_[i] = F.mvKeysUn[i].angle;
+            occ[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0;
+        }
+        OrbmFrame f;
+        f.n = n; f.x = x_.data(); f.y = y_.data(); f.octave = o_.data(); f.angle = a_.data(); f.desc = F.mDescriptors.data;
+        f.min_x = F.mnMinX; f.min_y = F.mnMinY; f.max_x = F.mnMaxX; f.max_y = F.mnMaxY;
+        f.grid_cols = FRAME_GRID_COLS; f.grid_rows = FRAME_GRID_ROWS;
+        f.scale_factors = F.mvScaleFactors.data(); f.n_levels = (int)F.mvScaleFactors.size();
+        return f;
+    }
+    float mfNNratio;
+    bool mbCheckOrientation;
+    orbm_matcher* m_ = nullptr;
+    std::vector<float> x_, y_, a_;
+    std::vector<int32_t> o_;
+};
+
+// Drop-in for Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&, int&, int&, int&) (src/Optimizer.cc:1116-1498).
+// The pointer-graph walk and the map write-back are the reference's own logic; only the g2o part is replaced.
+inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges)
+{
+    (void)num_MPs;      // never assigned by the reference overload either
+    std::list<KeyFrame*> lLocalKeyFrames;
+    lLocalKeyFrames.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    Map* pCurrentMap = pKF->GetMap();
+    const std::vector<KeyFrame*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+    for (KeyFrame* pKFi : vNeighKFs) {
+        pKFi->mnBALocalForKF = pKF->mnId;
+        if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lLocalKeyFrames.push_back(pKFi);
+    }
+    num_fixedKF = 0;
+    std::list<MapPoint*> lLocalMapPoints;
+    for (KeyFrame* pKFi : lLocalKeyFrames) {
+        if (pKFi->mnId == pMap->GetInitKFid()) num_fixedKF = 1;
+        for (MapPoint* pMP : pKFi->GetMapPointMatches())
+            if (pMP && !pMP->isBad() && pMP->GetMap() == pCurrentMap && pMP->mnBALocalForKF != pKF->mnId) {
+                lLocalMapPoints.push_back(pMP);
+                pMP->mnBALocalForKF = pKF->mnId;
+            }
+    }
+    std::list<KeyFrame*> lFixedCameras;
+    for (MapPoint* pMP : lLocalMapPoints)
+        for (auto& obs : pMP->GetObservations()) {
+            KeyFrame* pKFi = obs.first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                pKFi->mnBAFixedForKF = pKF->mnId;
+                if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lFixedCameras.push_back(pKFi);
+            }
+        }
+    num_fixedKF = (int)lFixedCameras.size() + num_fixedKF;
+    if (num_fixedKF == 0) return;                                                   // :1182-1186
+
+    // vertices in ascending id (g2o sorts active vertices by id, sparse_optimizer.cpp:482-487)
+    std::vector<KeyFrame*> kfs(lLocalKeyFrames.begin(), lLocalKeyFrames.end());
+    kfs.insert(kfs.end(), lFixedCameras.begin(), lFixedCameras.end());
+    std::sort(kfs.begin(), kfs.end(), [](KeyFrame* a, KeyFrame* b) { return a->mnId < b->mnId; });
+    std::vector<MapPoint*> mps(lLocalMapPoints.begin(), lLocalMapPoints.end());
+    std::sort(mps.begin(), mps.end(), [](MapPoint* a, MapPoint* b) { return a->mnId < b->mnId; });
+    std::map<KeyFrame*, int> kfIndex;
+    std::map<MapPoint*, int> mpIndex;
+    std::vector<double> q(kfs.size() * 4), t(kfs.size() * 3), X(mps.size() * 3);
+    std::vector<uint8_t> fixed(kfs.size());
+    for (size_t i = 0; i < kfs.size(); i++) {
+        kfIndex[kfs[i]] = (int)i;
+        const Sophus::SE3<float> Tcw = kfs[i]->GetPose();
+        const Eigen::Quaterniond qd = Tcw.unit_quaternion().cast<double>();
+        const Eigen::Vector3d td = Tcw.translation().cast<double>();
+        q[4 * i] = qd.x(); q[4 * i + 1] = qd.y(); q[4 * i + 2] = qd.z(); q[4 * i + 3] = qd.w();
+        t[3 * i] = td.x(); t[3 * i + 1] = td.y(); t[3 * i + 2] = td.z();
+        fixed[i] = kfs[i]->mnBALocalForKF != pKF->mnId || kfs[i]->mnId == pMap->GetInitKFid();     // :1220, :1237
+    }
+    num_OptKF = (int)lLocalKeyFrames.size();
+    for (size_t i = 0; i < mps.size(); i++) {
+        mpIndex[mps[i]] = (int)i;
+        const Eigen::Vector3d Xd = mps[i]->GetWorldPos().cast<double>();
+        X[3 * i] = Xd.x(); X[3 * i + 1] = Xd.y(); X[3 * i + 2] = Xd.z();
+    }
+    // edges in addEdge order: map points in list order, observations in map order (:1278-1401)
+    std::vector<int32_t> ePoint, ePose;
+    std::vector<double> eObs, eW;
+    std::vector<uint8_t> eStereo;
+    std::vector<KeyFrame*> eKF;
+    std::vector<MapPoint*> eMP;
+    double fx = 0, fy = 0, cx = 0, cy = 0, bf = 0;
+    for (MapPoint* pMP : lLocalMapPoints)
+        for (auto& obs : pMP->GetObservations()) {
+            KeyFrame* pKFi = obs.first;
+            if (pKFi->isBad() || pKFi->GetMap() != pCurrentMap) continue;
+            const int leftIndex = std::get<0>(obs.second);
+            if (leftIndex == -1) continue;
+            const cv::KeyPoint& kpUn = pKFi->mvKeysUn[leftIndex];
+            const float ur = pKFi->mvuRight[leftIndex];
+            ePoint.push_back(mpIndex[pMP]); ePose.push_back(kfIndex[pKFi]);
+            eObs.push_back(kpUn.pt.x); eObs.push_back(kpUn.pt.y); eObs.push_back(ur >= 0 ? (double)ur : -1.0);
+            eW.push_back((double)pKFi->mvInvLevelSigma2[kpUn.octave]);
+            eStereo.push_back(ur >= 0);
+            eKF.push_back(pKFi); eMP.push_back(pMP);
+            fx = pKFi->fx; fy = pKFi->fy; cx = pKFi->cx; cy = pKFi->cy; bf = pKFi->mbf;
+        }
+    num_edges = (int)ePoint.size();
+    if (pbStopFlag && *pbStopFlag) return;                                          // :1406-1408
+
+    LbaProblem pr;
+    pr.n_poses = (int)kfs.size(); pr.pose_q = q.data(); pr.pose_t = t.data(); pr.pose_fixed = fixed.data();
+    pr.n_points = (int)mps.size(); pr.points = X.data();
+    pr.n_edges = num_edges; pr.edge_point = ePoint.data(); pr.edge_pose = ePose.data(); pr.edge_obs = eObs.data();
+    pr.edge_inv_sigma2 = eW.data(); pr.edge_stereo = eStereo.data();
+    pr.fx = fx; pr.fy = fy; pr.cx = cx; pr.cy = cy; pr.bf = bf;
+    const float thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815);             // :1275-1276 (through float)
+    pr.huber_mono = thHuberMono; pr.huber_stereo = thHuberStereo;
+    static thread_local lba_solver* solver = nullptr;
+    if (!solver) orbslam3_hip::check(lba_create(0, &solver));
+    std::vector<double> qo(q.size()), to(t.size()), Xo(X.size()), chi2(num_edges);
+    std::vector<uint8_t> depthPos(num_edges);
+    LbaStats st;
+    orbslam3_hip::check(lba_solve(solver, &pr, (const volatile uint8_t*)pbStopFlag, 10, pMap->IsInertial() ? 100.0 : 0.0,
+                                  qo.data(), to.data(), Xo.data(), chi2.data(), depthPos.data(), &st));
+
+    std::vector<std::pair<KeyFrame*, MapPoint*> > vToErase;                         // :1413-1460
+    for (int e = 0; e < num_edges; e++) {
+        if (eMP[e]->isBad()) continue;
+        if (chi2[e] > (eStereo[e] ? 7.815 : 5.991) || !depthPos[e]) vToErase.push_back(std::make_pair(eKF[e], eMP[e]));
+    }
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                       // :1464
+    for (auto& er : vToErase) { er.first->EraseMapPointMatch(er.second); er.second->EraseObservation(er.first); }
+    for (KeyFrame* pKFi : lLocalKeyFrames) {
+        const int i = kfIndex[pKFi];
+        const Eigen::Quaterniond qd(qo[4 * i + 3], qo[4 * i], qo[4 * i + 1], qo[4 * i + 2]);
+        pKFi->SetPose(Sophus::SE3f(qd.cast<float>(), Eigen::Vector3d(to[3 * i], to[3 * i + 1], to[3 * i + 2]).cast<float>()));
+    }
+    for (MapPoint* pMP : lLocalMapPoints) {
+        const int i = mpIndex[pMP];
+        pMP->SetWorldPos(Eigen::Vector3d(Xo[3 * i], Xo[3 * i + 1], Xo[3 * i + 2]).cast<float>());
+        pMP->UpdateNormalAndDepth();
+    }
+    pMap->IncreaseChangeIndex();
+}
+
+}  // namespace ORB_SLAM3
+
+#endif  // ORBSLAM3_HIP_WITH_REFERENCE

@@ -472,6 +472,10 @@ class LbaShard:
     def reduce_buffer_ptr(self):
         return lib.lba_shard_reduce_buffer(self._h)
 
+    def set_local(self, local=True):
+        lib.lba_shard_set_local.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.lba_shard_set_local(self._h, int(local)))
+
     def set_reduce_buffer(self, device_ptr):
         lib.lba_shard_set_reduce_buffer.argtypes = [C.c_void_p, C.c_void_p]
         _check(lib.lba_shard_set_reduce_buffer(self._h, device_ptr))

@@ -407,19 +407,46 @@ __global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
     }
 }
 
-// ---- Schur, pose side: one workgroup per non-zero block (i<=j) of the reduced camera system ----
+// ---- Schur, pose side: one workgroup per 6x6 block (i<=j) of the reduced camera system ----
 // 7 groups of 36 lanes split the block's (edge_a, edge_b) pair list; partials are combined in a fixed order.
-// out: S (n x n, row-major, both triangles).
-__global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict__ S)
+// Every block of the upper triangle has an entry (empty pair list for poses that share no landmark), so S is fully
+// overwritten and needs no memset.  lambda_diag is added to the diagonal here in the single-GPU path (0 when the caller
+// all-reduces partial systems first and adds lambda afterwards).
+// Workgroups [nBlocks, nBlocks + nP): b_schur = b_p - sum_e W_e db_l(e) (block_solver.hpp:413,436-439), plus copies of
+// b_p and diag(Hpp) for the reduce buffer (additive over shards).
+__global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict__ S, double lambda_diag,
+                                                      double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out)
 {
     __shared__ double s_part[7][36];
     const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk >= d.nBlocks) {
+        const int i = blk - d.nBlocks, lane = tid & 63, wave = tid >> 6;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = d.p_off[i] + tid; k < d.p_off[i + 1]; k += 256) {
+            const int e = d.p_edge[k];
+            const double* W = d.W + 18 * (size_t)e;
+            const double* db = d.db + 3 * (size_t)d.e_point[e];
+            for (int r = 0; r < 6; r++) acc[r] += W[r * 3] * db[0] + W[r * 3 + 1] * db[1] + W[r * 3 + 2] * db[2];
+        }
+        for (int r = 0; r < 6; r++)
+            for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
+        if (lane == 0) for (int r = 0; r < 6; r++) s_part[wave][r] = acc[r];
+        __syncthreads();
+        if (tid < 6) {
+            const double a = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
+            bs[6 * i + tid] = d.bp[6 * (size_t)i + tid] - a;
+            bp_out[6 * i + tid] = d.bp[6 * (size_t)i + tid];
+            diag_out[6 * i + tid] = d.Hpp[36 * (size_t)i + tid * 7];
+        }
+        return;
+    }
     const int i = d.b_i[blk], j = d.b_j[blk];
     const int n = d.n;
     const int g = tid / 36, ent = tid - g * 36;
     if (g < 7) {
         const int r = ent / 6, c = ent - r * 6;
         double acc = 0.0;
+#pragma unroll 4
         for (int k = d.b_off[blk] + g; k < d.b_off[blk + 1]; k += 7) {
             const int2 pr = d.b_pair[k];
             const double* Z = d.Z + 18 * (size_t)pr.x + r * 3;
@@ -433,31 +460,10 @@ __global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict_
         const int r = tid / 6, c = tid - r * 6;
         double sum = s_part[0][tid];
         for (int q = 1; q < 7; q++) sum += s_part[q][tid];
-        const double v = ((i == j) ? d.Hpp[36 * (size_t)i + tid] : 0.0) - sum;
+        double v = ((i == j) ? d.Hpp[36 * (size_t)i + tid] : 0.0) - sum;
+        if (i == j && r == c) v += lambda_diag;
         S[(size_t)(6 * i + r) * n + 6 * j + c] = v;
         if (i != j) S[(size_t)(6 * j + c) * n + 6 * i + r] = v;
-    }
-}
-
-// b_schur = b_p - sum_e W_e db_l(e) (block_solver.hpp:413,436-439); one wave per non-fixed pose.  Also copies b_p and
-// diag(Hpp) into the reduce buffer (additive over shards).
-__global__ __launch_bounds__(64) void k_schur_b(Dev d, double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out)
-{
-    const int i = blockIdx.x, lane = threadIdx.x;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = d.p_off[i] + lane; k < d.p_off[i + 1]; k += 64) {
-        const int e = d.p_edge[k];
-        const double* W = d.W + 18 * (size_t)e;
-        const double* db = d.db + 3 * (size_t)d.e_point[e];
-        for (int r = 0; r < 6; r++) acc[r] += W[r * 3] * db[0] + W[r * 3 + 1] * db[1] + W[r * 3 + 2] * db[2];
-    }
-    for (int r = 0; r < 6; r++)
-        for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
-    if (lane < 6) {
-        const double a = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : lane == 3 ? acc[3] : lane == 4 ? acc[4] : acc[5];
-        bs[6 * i + lane] = d.bp[6 * (size_t)i + lane] - a;
-        bp_out[6 * i + lane] = d.bp[6 * (size_t)i + lane];
-        diag_out[6 * i + lane] = d.Hpp[36 * (size_t)i + lane * 7];
     }
 }
 
@@ -474,45 +480,101 @@ __global__ void k_add_lambda(double* S, int n, double lambda)
 __global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
                                                    double* __restrict__ Linv, double* __restrict__ scal)
 {
-    constexpr int P = NB + 1;
-    __shared__ double sL[NB * P];
-    __shared__ double sI[NB * P];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < nb * nb; i += 256) {
-        const int r = i / nb, c = i - r * nb;
-        sL[r * P + c] = S[(size_t)(k0 + r) * n + k0 + c];
-        sI[r * P + c] = (r == c) ? 1.0 : 0.0;
-    }
-    __syncthreads();
+    // Register-resident: thread (ty, tx) of a 16 x 16 grid owns the elements (ty + 16a, tx + 16b), a, b < 4, of the
+    // 64 x 64-padded block L and of X = L^-1.  Per column j one barrier: the owners publish column j of L, row j of X
+    // and the pivot through double-buffered LDS vectors; everybody then updates its registers.
+    __shared__ double s_col[2][64], s_row[2][64], s_piv[2];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double Lr[4][4], Xr[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            Lr[a][b] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
+            Xr[a][b] = (r == c) ? 1.0 : 0.0;
+        }
     bool failed = false;
-    for (int j = 0; j < nb; j++) {
-        const double djj = sL[j * P + j];           // = A_jj - sum_q L_jq^2 after the trailing updates; never overwritten
-        if (!(djj > 0.0) || !isfinite(djj)) { failed = true; break; }      // uniform: every thread reads the same value
-        const double ljj = sqrt(djj);
-        // column j of L below the diagonal, and row j of X = L^-1 (entries c <= j)
-        for (int r = j + 1 + tid; r < nb; r += 256) sL[r * P + j] /= ljj;
-        for (int c = tid; c <= j; c += 256) sI[j * P + c] /= ljj;
-        __syncthreads();
-        // trailing update of L: (r, c) with j < c <= r ; Gauss-Jordan update of X: rows r > j, columns c <= j
-        const int m = nb - j - 1;
-        for (int i = tid; i < m * m; i += 256) {
-            const int r = j + 1 + i / m, c = j + 1 + i % m;
-            if (c <= r) sL[r * P + c] -= sL[r * P + j] * sL[c * P + j];
+#pragma unroll
+    for (int ja = 0; ja < 4; ja++) {
+        for (int jy = 0; jy < 16; jy++) {
+            const int j = 16 * ja + jy;
+            if (j >= nb || failed) break;
+            const int p = j & 1;
+            if (tx == jy) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) s_col[p][ty + 16 * a] = Lr[a][ja];
+                if (ty == jy) s_piv[p] = Lr[ja][ja];
+            }
+            if (ty == jy) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) s_row[p][tx + 16 * b] = Xr[ja][b];
+            }
+            __syncthreads();
+            const double djj = s_piv[p];
+            if (!(djj > 0.0) || !isfinite(djj)) { failed = true; break; }      // uniform: same value in every thread
+            // 1/sqrt(d) from the hardware estimate + two Newton steps, sqrt(d) = d * (1/sqrt(d)) + one Heron correction:
+            // ~1 ulp, and far shorter than the correctly rounded f64 sqrt + divide on the critical path of every column
+            double inv = __builtin_amdgcn_rsq(djj);
+            inv = inv * fma(-0.5 * djj * inv, inv, 1.5);
+            inv = inv * fma(-0.5 * djj * inv, inv, 1.5);
+            double ljj = djj * inv;
+            ljj = fma(fma(-ljj, ljj, djj), 0.5 * inv, ljj);
+            // ja (= j / 16) is a compile-time constant inside the unrolled outer loop, so whole register tiles drop out:
+            // rows a < ja are finished, L-updates only touch columns b >= ja (and b <= a), X-updates only columns b <= ja.
+            double lr[4], lc[4], xc[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) lr[a] = (a >= ja) ? s_col[p][ty + 16 * a] * inv : 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                lc[b] = (b >= ja) ? s_col[p][tx + 16 * b] * inv : 0.0;
+                xc[b] = (b <= ja) ? s_row[p][tx + 16 * b] * inv : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (a < ja) continue;
+                const int r = ty + 16 * a;
+                const bool ra = r > j;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int c = tx + 16 * b;
+                    if (b > ja) {
+                        if (b <= a && ra && c <= r) Lr[a][b] -= lr[a] * lc[b];          // c > j holds for every b > ja
+                    } else if (b < ja) {
+                        if (ra) Xr[a][b] -= lr[a] * xc[b];                              // c <= j holds for every b < ja
+                    } else if (ra) {
+                        if (c > j) { if (c <= r) Lr[a][b] -= lr[a] * lc[b]; }
+                        else Xr[a][b] -= lr[a] * xc[b];
+                    }
+                }
+            }
+            if (tx == jy) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) { const int r = ty + 16 * a; if (r > j) Lr[a][ja] = lr[a]; else if (r == j) Lr[a][ja] = ljj; }
+            }
+            if (ty == jy) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) { if (tx + 16 * b <= j) Xr[ja][b] = xc[b]; }
+            }
         }
-        for (int i = tid; i < m * (j + 1); i += 256) {
-            const int r = j + 1 + i / (j + 1), c = i % (j + 1);
-            sI[r * P + c] -= sL[r * P + j] * sI[j * P + c];
-        }
-        __syncthreads();
     }
     if (failed) { if (tid == 0) scal[5] = 1.0; return; }
     double* Li = Linv + (size_t)(k0 / NB) * NB * NB;
-    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i - r * nb; Li[r * NB + c] = (c <= r) ? sI[r * P + c] : 0.0; }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            if (r < nb && c < nb) Li[r * NB + c] = (c <= r) ? Xr[a][b] : 0.0;
+        }
 }
 
 constexpr int kPanelRows = 64;
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int n, int k0, int nb, const double* __restrict__ Linv,
-                                                    const double* __restrict__ scal)
+// nr = n + 1: the right-hand side b_schur is stored right behind S in the reduce buffer, i.e. it IS row n of an
+// (n+1) x n row-major matrix; carrying it through panel/update as an extra row performs the forward substitution
+// y = L^-1 b for free.
+__global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ S, int n, int nr, int k0, int nb, const double* __restrict__ Linv,
+                                                     const double* __restrict__ scal)
 {
     constexpr int P = NB + 1;
     __shared__ double sI[NB * P];
@@ -520,26 +582,34 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int 
     if (scal[5] != 0.0) return;         // diagonal block was not positive definite
     const int tid = threadIdx.x;
     const int row0 = k0 + nb + blockIdx.x * kPanelRows;
-    const int nrows = min(kPanelRows, n - row0);
+    const int nrows = min(kPanelRows, nr - row0);
     const double* Li = Linv + (size_t)(k0 / NB) * NB * NB;
-    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i - r * nb; sI[r * P + c] = Li[r * NB + c]; }
-    for (int i = tid; i < nrows * nb; i += 256) { const int r = i / nb, c = i - r * nb; sA[r * P + c] = S[(size_t)(row0 + r) * n + k0 + c]; }
+    for (int i = tid; i < NB * NB; i += 1024) { const int r = i / NB, c = i - r * NB; sI[r * P + c] = (r < nb && c < nb) ? Li[r * NB + c] : 0.0; }
+    for (int i = tid; i < nrows * nb; i += 1024) { const int r = i / nb, c = i - r * nb; sA[r * P + c] = S[(size_t)(row0 + r) * n + k0 + c]; }
     __syncthreads();
-    // X = A * Linv^T :  X[r][c] = sum_{q <= c} A[r][q] * Linv[c][q]
-    const int r = tid >> 2;
-    if (r < nrows) {
+    // X = A * Linv^T :  X[r][c] = sum_{q <= c} A[r][q] * Linv[c][q]   (Linv is stored with explicit zeros above the diagonal)
+    // thread = (row, group of 4 adjacent columns): 4 independent accumulators share every a[q] load
+    const int r = tid >> 4, cg = tid & 15;
+    if (r < nrows && cg < NB / 4) {
         const double* a = sA + r * P;
-        for (int c = tid & 3; c < nb; c += 4) {
-            const double* li = sI + c * P;
-            double sv = 0;
-            for (int q = 0; q <= c; q++) sv += a[q] * li[q];
-            S[(size_t)(row0 + r) * n + k0 + c] = sv;
+        const double* l0 = sI + (4 * cg) * P;
+        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        const int qmax = min(nb, 4 * cg + 4);
+#pragma unroll 4
+        for (int q = 0; q < qmax; q++) {
+            const double aq = a[q];
+            acc0 += aq * l0[q]; acc1 += aq * l0[P + q]; acc2 += aq * l0[2 * P + q]; acc3 += aq * l0[3 * P + q];
         }
+        double* out = S + (size_t)(row0 + r) * n + k0 + 4 * cg;
+        if (4 * cg < nb) out[0] = acc0;
+        if (4 * cg + 1 < nb) out[1] = acc1;
+        if (4 * cg + 2 < nb) out[2] = acc2;
+        if (4 * cg + 3 < nb) out[3] = acc3;
     }
 }
 
 // trailing update S22 -= L21 L21^T (lower triangle), 32x32 tiles, panel rows staged in LDS
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb, const double* __restrict__ scal)
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int nr, int k0, int nb, const double* __restrict__ scal)
 {
     __shared__ double sA[32 * (NB + 1)], sB[32 * (NB + 1)];
     const int base = k0 + nb;
@@ -549,25 +619,26 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
     const int tid = threadIdx.x, P = NB + 1;
     for (int i = tid; i < 32 * nb; i += 256) {
         const int r = i / nb, q = i % nb;
-        sA[r * P + q] = (r0 + r < n) ? S[(size_t)(r0 + r) * n + k0 + q] : 0.0;
+        sA[r * P + q] = (r0 + r < nr) ? S[(size_t)(r0 + r) * n + k0 + q] : 0.0;
         sB[r * P + q] = (c0 + r < n) ? S[(size_t)(c0 + r) * n + k0 + q] : 0.0;
     }
     __syncthreads();
     const int tr = tid / 32, tc = tid % 32;
     for (int rr = tr; rr < 32; rr += 8) {
         const int r = r0 + rr, c = c0 + tc;
-        if (r < n && c < n && c <= r) {
+        if (r < nr && c < n && c <= r) {
             double sv = 0;
+#pragma unroll 4
             for (int q = 0; q < nb; q++) sv += sA[rr * P + q] * sB[tc * P + q];
             S[(size_t)r * n + c] -= sv;
         }
     }
 }
 
-// x = L^-T L^-1 b by block substitution with the inverted diagonal blocks; one 1024-thread workgroup.
-// Row dot products are split over 16 lanes (coalesced along the row) / 16 row groups (coalesced along the column).
+// x = L^-T y by block back-substitution with the inverted diagonal blocks (y = L^-1 b was produced by the factorisation
+// itself, see k_chol_panel); one 1024-thread workgroup, 16 row groups x 64 columns, coalesced along the columns.
 __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ S, int n, const double* __restrict__ Linv,
-                                                     const double* __restrict__ b, double* __restrict__ x, const double* __restrict__ scal)
+                                                     const double* __restrict__ yin, double* __restrict__ x, const double* __restrict__ scal)
 {
     extern __shared__ double sm[];      // y[n], t[64], part[16][64]
     double* y = sm;
@@ -575,39 +646,19 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
     double* part = t + 64;
     const int tid = threadIdx.x;
     if (scal[5] != 0.0) { for (int i = tid; i < n; i += 1024) x[i] = 0.0; return; }
-    for (int i = tid; i < n; i += 1024) y[i] = b[i];
+    for (int i = tid; i < n; i += 1024) y[i] = yin[i];
     __syncthreads();
     const int nblk = (n + NB - 1) / NB;
-    const int r16 = tid >> 4, l16 = tid & 15;       // 64 rows x 16 lanes
     const int g64 = tid >> 6, r64 = tid & 63;       // 16 groups x 64 rows
-    // forward: y_K = Linv_KK (b_K - sum_{J<K} L_KJ y_J)
-    for (int K = 0; K < nblk; K++) {
-        const int k0 = K * NB, nb = min(NB, n - k0);
-        {
-            double sv = 0;
-            if (r16 < nb) {
-                const double* Lr = S + (size_t)(k0 + r16) * n;
-                for (int q = l16; q < k0; q += 16) sv += Lr[q] * y[q];
-            }
-            for (int o = 8; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
-            if (r16 < nb && l16 == 0) t[r16] = y[k0 + r16] - sv;
-        }
-        __syncthreads();
-        {
-            const double* Li = Linv + (size_t)K * NB * NB;
-            double sv = 0;
-            if (r16 < nb) for (int q = l16; q <= r16; q += 16) sv += Li[r16 * NB + q] * t[q];
-            for (int o = 8; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
-            if (r16 < nb && l16 == 0) y[k0 + r16] = sv;
-        }
-        __syncthreads();
-    }
-    // backward: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J)
+    // backward sweep: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J)
     for (int K = nblk - 1; K >= 0; K--) {
         const int k0 = K * NB, nb = min(NB, n - k0);
         {
             double sv = 0;
-            if (r64 < nb) for (int q = k0 + nb + g64; q < n; q += 16) sv += S[(size_t)q * n + k0 + r64] * y[q];
+            if (r64 < nb) {
+#pragma unroll 4
+                for (int q = k0 + nb + g64; q < n; q += 16) sv += S[(size_t)q * n + k0 + r64] * y[q];
+            }
             part[g64 * 64 + r64] = sv;
         }
         __syncthreads();
@@ -620,6 +671,7 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
         if (tid < nb) {
             const double* Li = Linv + (size_t)K * NB * NB;
             double sv = 0;
+#pragma unroll 4
             for (int q = tid; q < nb; q++) sv += Li[q * NB + tid] * t[q];
             y[k0 + tid] = sv;
         }
@@ -712,17 +764,33 @@ struct lba_shard {
     double* Linv = nullptr;
     double* Ldiag = nullptr;
     bool sync_after_reduce = true;      // lba_solve() keeps everything on one stream and turns this off
+    bool lambda_in_reduce = false;      // single-GPU: add lambda to diag(S) inside k_schur_blocks (no all-reduce in between)
+    bool lambda_added = false;
     double* d_chi2 = nullptr;
     uint8_t* d_depth = nullptr;
     double* h_scal = nullptr;   // pinned [16]
     int64_t reduce_len = 0;
     bool err_valid = false;
+    bool err_current = false;           // d.err / d.rho0 belong to the accepted state poses[cur]
+    double chi_current = 0, chi_trial = 0, mdp_cached = 0, mdl_cached = 0;
+
+    // optional bump arena owned by an lba_solver (avoids ~40 hipMalloc/hipFree per LocalBundleAdjustment call)
+    uint8_t* arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0, bytes_wanted = 0;
+    bool owns_stream = true, owns_hscal = true;
 
     template <typename T>
     int dalloc(T** p, size_t count)
     {
         *p = nullptr;
-        LBA_HIP(hipMalloc((void**)p, std::max(count, (size_t)1) * sizeof(T)));
+        const size_t bytes = (std::max(count, (size_t)1) * sizeof(T) + 255) & ~(size_t)255;
+        bytes_wanted += bytes;
+        if (arena && arena_off + bytes <= arena_cap) {
+            *p = (T*)(arena + arena_off);
+            arena_off += bytes;
+            return ORBX_OK;
+        }
+        LBA_HIP(hipMalloc((void**)p, bytes));
         allocs.push_back(*p);
         return ORBX_OK;
     }
@@ -756,9 +824,17 @@ static int shard_validate(const LbaProblem* p)
     return ORBX_OK;
 }
 
-extern "C" {
+struct lba_solver {
+    int device = 0;
+    uint8_t* arena = nullptr;
+    size_t arena_cap = 0;
+    hipStream_t stream = nullptr;
+    double* h_scal = nullptr;
+};
 
-int lba_shard_create(int device, const LbaProblem* p, lba_shard** out)
+extern "C" void lba_shard_destroy(lba_shard* s);
+
+static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, lba_solver* owner)
 {
     if (!out) return fail(ORBX_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -770,6 +846,11 @@ int lba_shard_create(int device, const LbaProblem* p, lba_shard** out)
     LBA_HIP(hipSetDevice(device));
     lba_shard* s = new lba_shard();
     s->device = device;
+    if (owner) {
+        s->arena = owner->arena; s->arena_cap = owner->arena_cap;
+        s->stream = owner->stream; s->owns_stream = false;
+        s->h_scal = owner->h_scal; s->owns_hscal = false;
+    }
     std::memset(&s->d, 0, sizeof(s->d));
     lba::Dev& d = s->d;
     d.nPoses = p->n_poses; d.nL = p->n_points; d.nE = p->n_edges;
@@ -800,7 +881,7 @@ int lba_shard_create(int device, const LbaProblem* p, lba_shard** out)
     std::vector<int64_t> blk_of((size_t)d.nP * d.nP, -1);
     for (int i = 0; i < d.nP; i++)
         for (int j = i; j < d.nP; j++)
-            if (i == j || cnt[(size_t)i * d.nP + j] > 0) {
+            {       // every block of the upper triangle gets an entry (possibly with an empty pair list)
                 blk_of[(size_t)i * d.nP + j] = (int64_t)b_i.size();
                 b_i.push_back(i); b_j.push_back(j);
                 b_off.push_back(b_off.back() + (int)cnt[(size_t)i * d.nP + j]);
@@ -847,8 +928,8 @@ int lba_shard_create(int device, const LbaProblem* p, lba_shard** out)
     LBA_TRY(s->dalloc(&s->Linv, (size_t)std::max(s->nblk, 1) * lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
-    if (hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "stream create failed"); }
+    if (s->owns_hscal && hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
+    if (s->owns_stream && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "stream create failed"); }
 #undef LBA_TRY
     LBA_HIP(hipMemcpy(s->poses[0], poses.data(), poses.size() * sizeof(double), hipMemcpyHostToDevice));
     if (d.nL > 0) LBA_HIP(hipMemcpy(s->pts[0], p->points, 3 * (size_t)d.nL * sizeof(double), hipMemcpyHostToDevice));
@@ -866,12 +947,17 @@ int lba_shard_create(int device, const LbaProblem* p, lba_shard** out)
     return ORBX_OK;
 }
 
+extern "C" int lba_shard_create(int device, const LbaProblem* p, lba_shard** out) { return shard_create_impl(device, p, out, nullptr); }
+
+extern "C" {
+
 // restore the initial estimates (lets a benchmark re-run the optimisation without re-uploading the problem)
 int lba_shard_reset(lba_shard* s)
 {
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
     LBA_HIP(hipSetDevice(s->device));
     s->cur = 0;
+    s->err_current = false;
     LBA_HIP(hipMemcpyAsync(s->poses[0], s->poses0, 7 * (size_t)s->d.nPoses * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     if (s->d.nL > 0) LBA_HIP(hipMemcpyAsync(s->pts[0], s->pts0, 3 * (size_t)s->d.nL * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
     LBA_HIP(hipMemsetAsync(s->d.err, 0, 3 * (size_t)std::max(s->d.nE, 1) * sizeof(double), s->stream));
@@ -882,14 +968,24 @@ void lba_shard_destroy(lba_shard* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); if (s->owns_stream) (void)hipStreamDestroy(s->stream); }
     for (void* p : s->allocs) (void)hipFree(p);
-    if (s->h_scal) (void)hipHostFree(s->h_scal);
+    if (s->h_scal && s->owns_hscal) (void)hipHostFree(s->h_scal);
     delete s;
 }
 
 int64_t lba_shard_reduce_len(const lba_shard* s) { return s ? s->reduce_len : 0; }
 double* lba_shard_reduce_buffer(lba_shard* s) { return s ? s->reduce : nullptr; }
+
+// local != 0: the caller promises that NO all-reduce happens between lba_shard_reduce() and lba_shard_finish() (world size 1):
+// lambda is then added to diag(S) inside the Schur kernel and the stream is not synchronised after reduce().
+int lba_shard_set_local(lba_shard* s, int local)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    s->lambda_in_reduce = local != 0;
+    s->sync_after_reduce = local == 0;
+    return ORBX_OK;
+}
 
 // Lets the caller own the reduce buffer (e.g. a torch.float64 CUDA tensor that torch.distributed all-reduces in place).
 int lba_shard_set_reduce_buffer(lba_shard* s, double* device_buffer)
@@ -914,17 +1010,30 @@ int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses
     const lba::Dev& d = s->d;
     const double* P = s->poses[s->cur];
     const double* X = s->pts[s->cur];
-    if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, P, X);
+    // After an accepted trial the edge errors and their robust chi2 of the (new) estimate are already on the device
+    // (lba_shard_finish computed them for the trial state): computeActiveErrors would reproduce them bit for bit, so only
+    // the quadratic forms are rebuilt, with no host synchronisation.  The diagonal maxima are only refreshed on the
+    // synchronising path (they are needed for lambda initialisation at the first iteration only).
+    const bool reuse = s->err_current;
+    if (!reuse && d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, P, X);
     if (d.nL > 0) hipLaunchKernelGGL(lba::k_lin_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, P, X);
     if (d.nP > 0) hipLaunchKernelGGL(lba::k_lin_poses, dim3(d.nP), dim3(256), 0, s->stream, d, P, X);
-    hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0);
-    LBA_HIP(hipGetLastError());
-    int r = read_scalars(s);
-    if (r) return r;
+    if (!reuse) {
+        hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0);
+        LBA_HIP(hipGetLastError());
+        int r = read_scalars(s);
+        if (r) return r;
+        s->chi_current = s->h_scal[0];
+        s->mdp_cached = s->h_scal[1];
+        s->mdl_cached = s->h_scal[2];
+    } else {
+        LBA_HIP(hipGetLastError());
+    }
     s->err_valid = true;
-    if (chi2_local) *chi2_local = s->h_scal[0];
-    if (max_diag_poses_local) *max_diag_poses_local = s->h_scal[1];
-    if (max_diag_landmarks_local) *max_diag_landmarks_local = s->h_scal[2];
+    s->err_current = true;
+    if (chi2_local) *chi2_local = s->chi_current;
+    if (max_diag_poses_local) *max_diag_poses_local = s->mdp_cached;
+    if (max_diag_landmarks_local) *max_diag_landmarks_local = s->mdl_cached;
     return ORBX_OK;
 }
 
@@ -934,10 +1043,11 @@ int lba_shard_reduce(lba_shard* s, double lambda)
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
     LBA_HIP(hipSetDevice(s->device));
     const lba::Dev& d = s->d;
-    LBA_HIP(hipMemsetAsync(s->reduce, 0, (size_t)s->reduce_len * sizeof(double), s->stream));
     if (d.nL > 0) hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, lambda);
-    if (d.nBlocks > 0) hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks), dim3(256), 0, s->stream, d, s->S());
-    if (d.nP > 0) hipLaunchKernelGGL(lba::k_schur_b, dim3(d.nP), dim3(64), 0, s->stream, d, s->bs(), s->bpf(), s->diag());
+    if (d.nBlocks + d.nP > 0)
+        hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks + d.nP), dim3(256), 0, s->stream, d, s->S(),
+                           s->lambda_in_reduce ? lambda : 0.0, s->bs(), s->bpf(), s->diag());
+    s->lambda_added = s->lambda_in_reduce;
     LBA_HIP(hipGetLastError());
     if (s->sync_after_reduce) LBA_HIP(hipStreamSynchronize(s->stream));      // the caller hands the buffer to RCCL on another stream
     return ORBX_OK;
@@ -957,16 +1067,16 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
     double* Xn = s->pts[1 - s->cur];
     LBA_HIP(hipMemsetAsync(d.scal + 5, 0, sizeof(double), s->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(lba::k_add_lambda, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->S(), n, lambda);
+        if (!s->lambda_added) hipLaunchKernelGGL(lba::k_add_lambda, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->S(), n, lambda);
         for (int K = 0; K < s->nblk; K++) {
             const int k0 = K * lba::NB, nb = std::min(lba::NB, n - k0);
-            const int rows_below = n - k0 - nb;
+            const int rows_below = (n + 1) - k0 - nb;       // includes the right-hand-side row n (always >= 1)
             hipLaunchKernelGGL(lba::k_chol_diag, dim3(1), dim3(256), 0, s->stream, (const double*)s->S(), n, k0, nb, s->Linv, d.scal);
-            if (rows_below > 0) {
-                hipLaunchKernelGGL(lba::k_chol_panel, dim3((rows_below + lba::kPanelRows - 1) / lba::kPanelRows), dim3(256), 0, s->stream,
-                                   s->S(), n, k0, nb, (const double*)s->Linv, (const double*)d.scal);
+            hipLaunchKernelGGL(lba::k_chol_panel, dim3((rows_below + lba::kPanelRows - 1) / lba::kPanelRows), dim3(1024), 0, s->stream,
+                               s->S(), n, n + 1, k0, nb, (const double*)s->Linv, (const double*)d.scal);
+            if (k0 + nb < n) {
                 const int t = (rows_below + 31) / 32;
-                hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, k0, nb, (const double*)d.scal);
+                hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, n + 1, k0, nb, (const double*)d.scal);
             }
         }
         hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), ((size_t)n + 64 + 16 * 64) * sizeof(double), s->stream,
@@ -978,6 +1088,8 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
     LBA_HIP(hipGetLastError());
     int r = read_scalars(s);
     if (r) return r;
+    s->chi_trial = s->h_scal[0];
+    s->err_current = false;         // the error buffer now belongs to the trial state
     if (chi2_local_new) *chi2_local_new = s->h_scal[0];
     if (scale_poses) *scale_poses = s->h_scal[3];
     if (scale_landmarks_local) *scale_landmarks_local = s->h_scal[4];
@@ -987,7 +1099,11 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
 int lba_shard_accept(lba_shard* s, int accept)
 {
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
-    if (accept) s->cur = 1 - s->cur;        // discardTop(): the trial state becomes the estimate; pop(): keep the old one
+    if (accept) {       // discardTop(): the trial state becomes the estimate; its errors / chi2 are the current ones
+        s->cur = 1 - s->cur;
+        s->err_current = true;
+        s->chi_current = s->chi_trial;
+    }                   // pop(): keep the old estimate; the error buffer stays that of the rejected trial (as in g2o)
     return ORBX_OK;
 }
 
@@ -1013,8 +1129,6 @@ int lba_shard_download(lba_shard* s, double* pose_q, double* pose_t, double* poi
 }
 
 // ---- single-GPU driver: optimizer.initializeOptimization(); optimizer.optimize(max_iters) ----
-struct lba_solver { int device; };
-
 int lba_create(int device, lba_solver** out)
 {
     if (!out) return fail(ORBX_ERR_ARG, "out is NULL");
@@ -1022,13 +1136,26 @@ int lba_create(int device, lba_solver** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ORBX_ERR_NO_DEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(ORBX_ERR_ARG, "device %d out of range", device);
+    LBA_HIP(hipSetDevice(device));
     lba_solver* s = new lba_solver();
     s->device = device;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) {
+        delete s;
+        return fail(ORBX_ERR_HIP, "stream / pinned buffer creation failed");
+    }
     *out = s;
     return ORBX_OK;
 }
 
-void lba_destroy(lba_solver* s) { delete s; }
+void lba_destroy(lba_solver* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    if (s->arena) (void)hipFree(s->arena);
+    if (s->h_scal) (void)hipHostFree(s->h_scal);
+    delete s;
+}
 
 int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t* stop_flag, int max_iters, double lambda_init,
               double* pose_q_out, double* pose_t_out, double* points_out,
@@ -1036,9 +1163,11 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
 {
     if (!sv) return fail(ORBX_ERR_ARG, "NULL solver");
     lba_shard* s = nullptr;
-    int r = lba_shard_create(sv->device, problem, &s);
+    int r = shard_create_impl(sv->device, problem, &s, sv);
     if (r) return r;
     s->sync_after_reduce = false;
+    s->lambda_in_reduce = true;
+    const size_t wanted = s->bytes_wanted;
     LbaStats st;
     std::memset(&st, 0, sizeof(st));
     double lambda = -1, ni = 2;
@@ -1095,6 +1224,12 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
     st.lambda = lambda;
     if (!r) r = lba_shard_download(s, pose_q_out, pose_t_out, points_out, chi2_per_edge, depth_positive);
     lba_shard_destroy(s);
+    if (wanted > sv->arena_cap) {       // grow the arena so that the next window of this size needs no hipMalloc
+        if (sv->arena) (void)hipFree(sv->arena);
+        sv->arena = nullptr; sv->arena_cap = 0;
+        const size_t cap = wanted + wanted / 4 + (1 << 20);
+        if (hipMalloc((void**)&sv->arena, cap) == hipSuccess) sv->arena_cap = cap;
+    }
     if (stats_out) *stats_out = st;
     return r;
 }

@@ -104,8 +104,8 @@ def sharded_bundle_adjustment(shard, reduce_tensor, comm=None, max_iters=10, lam
             else:
                 # pose diagonals are partial sums -> they are summed inside the reduce buffer; use the landmark max
                 # plus the summed pose diagonal (section 4 of the buffer) after a lambda-free reduce
-                shard.reduce(0.0)
-                if reduce_tensor is not None:
+                if reduce_tensor is not None:       # world size 1: linearize() already returned the true maxima
+                    shard.reduce(0.0)
                     comm.sum_(reduce_tensor)
                 mdp = shard.max_pose_diag()
                 mdl = comm.max_scalars([mdl_l])[0]
@@ -155,6 +155,7 @@ class LocalHipShard:
     def __init__(self, lba_shard):
         self.s = lba_shard
         self._mdp = 0.0
+        lba_shard.set_local(True)       # no collective between reduce() and finish()
 
     def linearize(self):
         chi, mdp, mdl = self.s.linearize()

@@ -205,6 +205,7 @@ class OracleShard:
     def linearize(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self.L.lba_oracle_shard_linearize(self.h, C.byref(a), C.byref(b), C.byref(c))
+        self._mdp = b.value
         return a.value, b.value, c.value
 
     def reduce(self, lam):
@@ -219,7 +220,9 @@ class OracleShard:
         self.L.lba_oracle_shard_accept(self.h, int(ok))
 
     def max_pose_diag(self):
-        return float(np.abs(self.array[self.n * self.n + 2 * self.n:]).max()) if self.n else 0.0
+        # summed diagonal section of the (all-reduced) buffer; before any reduce() it is zero and the local maximum applies
+        sec = float(np.abs(self.array[self.n * self.n + 2 * self.n:]).max()) if self.n else 0.0
+        return max(sec, getattr(self, "_mdp", 0.0))
 
     def download(self):
         k = self.keep
