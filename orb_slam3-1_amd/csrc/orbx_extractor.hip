@@ -104,7 +104,7 @@ struct orbx_extractor {
     std::vector<TileDesc> tiles;
     size_t pyr_frame_bytes = 0;
     int cand_frame_entries = 0, sel_frame_entries = 0;
-    int tile_pitch = 0, tile_rows = 0, m_pitch = 0, m_rows = 0, surv_off = 0;
+    int tile_pitch = 0, tile_rows = 0, m_pitch = 0, m_rows = 0, surv_off = 0, bits_off = 0;
     size_t fast_lds = 0, oct_lds = 0;
     int oct_pool = 0, oct_lds_keys = 0;
 
@@ -237,8 +237,9 @@ int orbx_extractor::setup_geometry(int w, int h)
         if (l > 0) {
             const LevelDesc& P = levels[l - 1];
             const double scale_x = 1. / ((double)L.w / P.w), scale_y = 1. / ((double)L.h / P.h);
-            std::vector<int> xofs(L.w), yofs(L.h);
-            std::vector<short> ia((size_t)L.w * 2), ib((size_t)L.h * 2);
+            const int wpad = round_up(L.w, 4);          // k_resize reads 4 entries per 16-B load
+            std::vector<int> xofs(wpad, 0), yofs(L.h);
+            std::vector<short> ia((size_t)wpad * 2, 0), ib((size_t)L.h * 2);
             auto sat = [](float v) { int iv = (int)std::nearbyintf(v); return (short)std::min(std::max(iv, -32768), 32767); };
             for (int dx = 0; dx < L.w; dx++) {
                 float fx = (float)((dx + 0.5) * scale_x - 0.5);
@@ -266,7 +267,7 @@ int orbx_extractor::setup_geometry(int w, int h)
     cand_frame_entries = std::max(cand_off, 1);
     sel_frame_entries = sel_off;
     // FAST kernel LDS
-    tile_pitch = round_up(max_tw + 3, 4) + 4;
+    tile_pitch = round_up(max_tw + 8, 4);       // re-aligned tile + room for the 12-byte windows of the quick test
     tile_rows = std::max(max_th, 1);
     m_pitch = round_up(std::max(max_tw - 6, 1) + 2, 4);
     m_rows = std::max(max_th - 6, 1) + 2;
@@ -275,6 +276,9 @@ int orbx_extractor::setup_geometry(int w, int h)
     surv_off = (int)fast_lds;
     fast_lds += 2 * (size_t)std::max(max_tw - 6, 1) * std::max(max_th - 6, 1) + 16;
     fast_lds = (fast_lds + 15) & ~(size_t)15;
+    bits_off = (int)fast_lds;
+    fast_lds += 3 * 256 * sizeof(uint32_t);
+    if ((max_tw - 6) * (max_th - 6) > 8192) return fail(ORBX_ERR_ARG, "FAST cell interior of %dx%d px exceeds the 8192-px bitmask", max_tw - 6, max_th - 6);
     if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST cell of %dx%d px does not fit LDS", max_tw, max_th);
     // octree kernel LDS
     oct_pool = max_nfeat + 16;
@@ -346,15 +350,15 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     mark();
     for (int l = 1; l < nlevels; l++) {
         const LevelDesc& D = levels[l];
-        dim3 g(((D.w + 3) / 4 + 255) / 256, D.h, B);
+        dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + 3) / 4)), B);
         hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, d_pyr.p, pyr_frame_bytes, levels[l - 1], D,
                            d_xofs[l].p, d_ialpha[l].p, d_yofs[l].p, d_ibeta[l].p);
     }
     mark();
     const int n_cells = (int)cells.size();
     if (n_cells > 0)
-        hipLaunchKernelGGL(k_fast_cells, dim3(n_cells, B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
-                           ini_th, min_th, tile_pitch, tile_rows, m_pitch, surv_off, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
+        hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(n_cells), B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
+                           ini_th, min_th, tile_pitch, tile_rows, m_pitch, surv_off, bits_off, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
     mark();
     hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), oct_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
                        d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, oct_lds_keys,
@@ -363,8 +367,8 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,
                        lap0, lap1, cap, d_kp_dst.p, sel_frame_entries, o_n, o_mono, o_status);
     mark();
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)tiles.size(), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
-                       taps[0], taps[1], taps[2], taps[3]);
+    hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
+                       (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
     mark();
     hipLaunchKernelGGL(k_orient_desc, dim3((sel_frame_entries + 3) / 4, B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
                        d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p, d_kp_dst.p, sel_frame_entries,

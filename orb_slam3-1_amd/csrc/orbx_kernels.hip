@@ -38,11 +38,17 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
                                                 const int* __restrict__ xofs, const short* __restrict__ ialpha,
                                                 const int* __restrict__ yofs, const short* __restrict__ ibeta)
 {
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int dy = blockIdx.y;
-    if (x4 >= dst.w) return;
-    const uint8_t* sbase = pyr + (size_t)blockIdx.z * frame_stride + src.off;
-    uint8_t* dbase = pyr + (size_t)blockIdx.z * frame_stride + dst.off;
+    // 256 threads = 64 column quads x 4 rows; tiles are numbered row-major and handed to the XCDs in contiguous bands
+    // (xcd_remap), so the 2 source rows a destination row needs are fetched by one L2 only.
+    const int tiles_x = (dst.w + 255) >> 8, tiles_y = (dst.h + 3) >> 2;
+    const int tile = xcd_remap(blockIdx.x, blockIdx.y);
+    if (tile >= tiles_x * tiles_y) return;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x4 = (tx * 64 + (threadIdx.x & 63)) * 4;
+    const int dy = ty * 4 + (threadIdx.x >> 6);
+    if (x4 >= dst.w || dy >= dst.h) return;
+    const uint8_t* sbase = pyr + (size_t)blockIdx.y * frame_stride + src.off;
+    uint8_t* dbase = pyr + (size_t)blockIdx.y * frame_stride + dst.off;
     int sy0 = yofs[dy], sy1 = sy0 + 1;
     sy0 = min(max(sy0, 0), src.h - 1);
     sy1 = min(max(sy1, 0), src.h - 1);
@@ -50,13 +56,18 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
     const uint8_t* S1 = sbase + (size_t)sy1 * src.stride;
     const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
     uint32_t packed = 0;
+    // the coefficient tables are padded to a multiple of 4 entries: one 16-B load each instead of 12 scalar ones
+    const int4 sx4 = *(const int4*)(xofs + x4);
+    const uint4 al4 = *(const uint4*)(ialpha + 2 * x4);
+    const int sxs[4] = {sx4.x, sx4.y, sx4.z, sx4.w};
+    const uint32_t als[4] = {al4.x, al4.y, al4.z, al4.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int dx = x4 + k;
         if (dx < dst.w) {
-            const int sx = xofs[dx];
+            const int sx = sxs[k];
             const int sx1 = min(sx + 1, src.w - 1);
-            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            const int a0 = (int)(short)(als[k] & 0xFFFFu), a1 = (int)(short)(als[k] >> 16);
             const int r0 = S0[sx] * a0 + S0[sx1] * a1;
             const int r1 = S1[sx] * a0 + S1[sx1] * a1;
             int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
@@ -97,11 +108,22 @@ __device__ __forceinline__ int fast_m(const uint8_t* __restrict__ t, int pitch)
     return max(m, 0);
 }
 
-// One 256-thread workgroup per FAST cell.  LDS: image tile (cell + 3 px ring halo), M tile with a
-// 1-px zero halo (NMS must treat everything outside the cell's own interior as 0), 2-bit pass flags.
+// One 256-thread workgroup per FAST cell.  LDS: image tile (cell + 3 px ring halo, re-aligned so that tile column 0 sits
+// on a dword), M tile with a 1-px zero halo (NMS must treat everything outside the cell's own interior as 0), survivor
+// list, two keypoint bitmasks (iniTh / minTh) and their word-prefix sums.
+//
+// pass 1  exact necessary condition for "corner at minThFAST": in each of the 8 opposite ring pairs (k, k+8) at least one
+//         pixel is beyond the threshold with the same polarity (a 9-arc covers one pixel of every pair).  One work item =
+//         4 horizontally adjacent pixels fed by 19 aligned dword LDS reads (instead of 68 byte reads); survivors are
+//         compacted into an LDS list.  Rejected pixels keep M = 0, which is what NMS / thresholds see for M <= minTh anyway.
+// pass 2  full arc min/max tree, densely, on the survivors only.
+// pass 3  3x3 NMS at both thresholds on the survivors -> bitmasks over the cell's pixels (row-major bit order).
+// pass 4  per-cell fallback to minThFAST only when iniThFAST found nothing (:843); word popcount prefix sums.
+// pass 5  ordered (row-major) compaction: rank = prefix[word] + popcount(lower bits).
+#define ORBX_B(w, j) (((w)[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t frame_stride,
                                                     const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
-                                                    int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch, int surv_off,
+                                                    int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch, int surv_off, int bits_off,
                                                     uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                     int* __restrict__ cell_count, int n_cells)
 {
@@ -109,78 +131,93 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     uint8_t* tile = smem;                                   // tile_rows x tile_pitch
     uint8_t* mt = smem + (size_t)tile_rows * tile_pitch;    // (ih+2) x m_pitch
     uint16_t* surv = (uint16_t*)(smem + surv_off);          // survivors of the quick test (pixel index inside the cell)
-    __shared__ int s_wave_cnt[4];
-    __shared__ int s_ini_total;
+    uint32_t* bits_ini = (uint32_t*)(smem + bits_off);      // [256] keypoints at iniThFAST
+    uint32_t* bits_min = bits_ini + 256;                    // [256] keypoints at minThFAST
+    uint32_t* wbase = bits_min + 256;                       // [256] exclusive popcount prefix of the selected mask
+    __shared__ int s_wave_tot[4];
     __shared__ int s_nsurv;
 
-    const CellDesc c = cells[blockIdx.x];
+    // XCD-aware mapping (orbx_device.h): neighbouring cells share image rows and 128-B lines, keep them in one L2.
+    const int cell_idx = xcd_remap(blockIdx.x, blockIdx.y);
+    if (cell_idx >= n_cells) return;
+    const CellDesc c = cells[cell_idx];
     const LevelDesc L = levels[c.level];
     const int frame = blockIdx.y;
     const uint8_t* img = pyr + (size_t)frame * frame_stride + L.off;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tw = c.x1 - c.x0, th = c.y1 - c.y0;       // tile (cell sub-image) size
     const int iw = tw - 6, ih = th - 6;                 // interior (detection area)
-    const int xa = c.x0 & ~3;                           // dword-aligned tile origin
+    const int n_int = iw * ih;
+    const int xa = c.x0 & ~3;                           // dword-aligned address of the tile's first column
     const int shift = c.x0 - xa;
-    const int row_dw = (shift + tw + 3) >> 2;           // dwords per tile row
+    const int row_dw = (tw + 8) >> 2;                   // LDS dwords per tile row (covers the 12-byte windows of pass 1)
 
-    if (tid == 0) { s_ini_total = 0; s_nsurv = 0; }
-    // load tile: coalesced dword loads, rows are 64-B aligned in HBM
+    if (tid == 0) s_nsurv = 0;
+    // tile load: coalesced dword loads (rows are 64-B aligned in HBM), byte-realigned so that LDS column k = image column x0 + k
     for (int i = tid; i < th * row_dw; i += 256) {
         const int r = i / row_dw, q = i - r * row_dw;
-        const uint32_t v = *(const uint32_t*)(img + (size_t)(c.y0 + r) * L.stride + xa + 4 * q);
+        const uint32_t* g = (const uint32_t*)(img + (size_t)(c.y0 + r) * L.stride + xa) + q;
+        const uint32_t lo = g[0];
+        uint32_t v = lo;
+        if (shift) v = __builtin_amdgcn_alignbyte(g[1], lo, (uint32_t)shift);
         *(uint32_t*)(tile + r * tile_pitch + 4 * q) = v;
     }
-    // zero the M tile (halo included)
     for (int i = tid; i < (ih + 2) * m_pitch / 4; i += 256) ((uint32_t*)mt)[i] = 0;
+    for (int i = tid; i < 512; i += 256) bits_ini[i] = 0;       // both masks
     __syncthreads();
-    // scores, two passes: (1) the exact necessary condition for "corner at minThFAST" -- in each of the 8 opposite ring
-    // pairs (k, k+8) at least one pixel is beyond the threshold with the same polarity (a 9-arc covers one pixel of
-    // every pair) -- rejects most pixels with 16 loads and a few compares; survivors are compacted into an LDS list.
-    // (2) the full arc min/max tree runs densely on the survivors only.  Rejected pixels keep M = 0, which is what the
-    // NMS and the threshold tests below see for any pixel with M <= minThFAST anyway.
-    const int n_int = iw * ih;
-    for (int q = tid; q < n_int; q += 256) {
-        const int y = q / iw, x = q - y * iw;
-        const uint8_t* t = tile + (y + 3) * tile_pitch + shift + x + 3;
-        const int pitch = tile_pitch;
-        const int v = t[0];
-        const int lo = v - min_th, hi = v + min_th;     // dark: ring < lo, bright: ring > hi
-        int r0 = t[3 * pitch], r8 = t[-3 * pitch];
-        int dark = (r0 < lo) | (r8 < lo), bright = (r0 > hi) | (r8 > hi);
-        if (dark | bright) {
-            int a, b;
-#define ORBX_PAIR(oa, ob) a = t[oa]; b = t[ob]; dark &= (a < lo) | (b < lo); bright &= (a > hi) | (b > hi);
-            ORBX_PAIR(3, -3)
-            ORBX_PAIR(-2 * pitch + 2, 2 * pitch - 2)
-            ORBX_PAIR(2 * pitch + 2, -2 * pitch - 2)
+
+    // ---- pass 1 ----
+    const int ngx = (iw + 3) >> 2;
+    for (int gi = tid; gi < ngx * ih; gi += 256) {
+        const int y = gi / ngx, gx = gi - y * ngx;
+        const uint32_t* base = (const uint32_t*)(tile + y * tile_pitch) + gx;      // window: rows y..y+6, bytes 4gx..4gx+11
+        const int pd = tile_pitch >> 2;
+        uint32_t w0[3], w1[3], w2[3], w3[3], w4[3], w5[3], w6[3];
+        w0[0] = base[0]; w0[1] = base[1]; w0[2] = 0;
+        w1[0] = base[pd]; w1[1] = base[pd + 1]; w1[2] = base[pd + 2];
+        w2[0] = base[2 * pd]; w2[1] = base[2 * pd + 1]; w2[2] = base[2 * pd + 2];
+        w3[0] = base[3 * pd]; w3[1] = base[3 * pd + 1]; w3[2] = base[3 * pd + 2];
+        w4[0] = base[4 * pd]; w4[1] = base[4 * pd + 1]; w4[2] = base[4 * pd + 2];
+        w5[0] = base[5 * pd]; w5[1] = base[5 * pd + 1]; w5[2] = base[5 * pd + 2];
+        w6[0] = base[6 * pd]; w6[1] = base[6 * pd + 1]; w6[2] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = 4 * gx + k;
+            if (x >= iw) break;
+            const int v = (int)ORBX_B(w3, 3 + k);
+            const int lo = v - min_th, hi = v + min_th;     // dark: ring < lo, bright: ring > hi
+            int a = (int)ORBX_B(w6, 3 + k), b = (int)ORBX_B(w0, 3 + k);                 // ring 0 / 8
+            int dark = (a < lo) | (b < lo), bright = (a > hi) | (b > hi);
+#define ORBX_PAIR(A, B) a = (int)(A); b = (int)(B); dark &= (a < lo) | (b < lo); bright &= (a > hi) | (b > hi);
+            ORBX_PAIR(ORBX_B(w3, 6 + k), ORBX_B(w3, k))            // 4 / 12
+            ORBX_PAIR(ORBX_B(w5, 5 + k), ORBX_B(w1, 1 + k))        // 2 / 10
+            ORBX_PAIR(ORBX_B(w1, 5 + k), ORBX_B(w5, 1 + k))        // 6 / 14
             if (dark | bright) {
-                ORBX_PAIR(3 * pitch + 1, -3 * pitch - 1)
-                ORBX_PAIR(pitch + 3, -pitch - 3)
-                ORBX_PAIR(-pitch + 3, pitch - 3)
-                ORBX_PAIR(-3 * pitch + 1, 3 * pitch - 1)
+                ORBX_PAIR(ORBX_B(w6, 4 + k), ORBX_B(w0, 2 + k))    // 1 / 9
+                ORBX_PAIR(ORBX_B(w4, 6 + k), ORBX_B(w2, k))        // 3 / 11
+                ORBX_PAIR(ORBX_B(w2, 6 + k), ORBX_B(w4, k))        // 5 / 13
+                ORBX_PAIR(ORBX_B(w0, 4 + k), ORBX_B(w6, 2 + k))    // 7 / 15
+                if (dark | bright) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x);
             }
 #undef ORBX_PAIR
-            if (dark | bright) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)q;
         }
     }
     __syncthreads();
     const int nsurv = s_nsurv;
+    // ---- pass 2 ----
     for (int i = tid; i < nsurv; i += 256) {
         const int q = surv[i];
         const int y = q / iw, x = q - y * iw;
-        const int m = fast_m(tile + (y + 3) * tile_pitch + shift + x + 3, tile_pitch);
+        const int m = fast_m(tile + (y + 3) * tile_pitch + x + 3, tile_pitch);
         mt[(y + 1) * m_pitch + x + 1] = (uint8_t)m;
     }
     __syncthreads();
-    // NMS at both thresholds -> flags (bit0: keypoint at iniTh, bit1: at minTh), kept in the (now free) image tile
-    uint8_t* flags = tile;
-    int local_ini = 0;
-    for (int q = tid; q < n_int; q += 256) {
+    // ---- pass 3 ----
+    for (int i = tid; i < nsurv; i += 256) {
+        const int q = surv[i];
         const int y = q / iw, x = q - y * iw;
         const uint8_t* p = mt + (y + 1) * m_pitch + x + 1;
         const int m = p[0];
-        int f = 0;
         if (m > min_th) {
             const int n0 = p[-m_pitch - 1], n1 = p[-m_pitch], n2 = p[-m_pitch + 1], n3 = p[-1], n4 = p[1],
                       n5 = p[m_pitch - 1], n6 = p[m_pitch], n7 = p[m_pitch + 1];
@@ -188,44 +225,44 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 #define ORBX_NB(n, t) (((n) > (t)) ? (n)-1 : 0)
 #define ORBX_PASS(t) (s > ORBX_NB(n0, t) && s > ORBX_NB(n1, t) && s > ORBX_NB(n2, t) && s > ORBX_NB(n3, t) && \
                       s > ORBX_NB(n4, t) && s > ORBX_NB(n5, t) && s > ORBX_NB(n6, t) && s > ORBX_NB(n7, t))
-            if (m > ini_th && ORBX_PASS(ini_th)) f |= 1;
-            if (ORBX_PASS(min_th)) f |= 2;
+            if (m > ini_th && ORBX_PASS(ini_th)) atomicOr(&bits_ini[q >> 5], 1u << (q & 31));
+            if (ORBX_PASS(min_th)) atomicOr(&bits_min[q >> 5], 1u << (q & 31));
 #undef ORBX_PASS
 #undef ORBX_NB
         }
-        local_ini += f & 1;
-        flags[q] = (uint8_t)f;      // q < iw*ih <= tile bytes
     }
-    // the flags alias the image tile: all score reads finished at the barrier above
-    if (local_ini) atomicAdd(&s_ini_total, local_ini);
     __syncthreads();
-    const int bit = (s_ini_total > 0) ? 1 : 2;      // per-cell fallback to minThFAST only when iniThFAST found nothing (:843)
-    // ordered (row-major) compaction
+    // ---- pass 4: which threshold, then exclusive prefix of the word popcounts (n_int <= 8192 -> <= 256 words) ----
+    const int nwords = (n_int + 31) >> 5;
+    const int ini_any = __syncthreads_or(tid < nwords && bits_ini[tid] != 0);
+    const uint32_t* bits = ini_any ? bits_ini : bits_min;
+    const int my = (tid < nwords) ? __popc(bits[tid]) : 0;
+    int incl = my;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < wave; w++) wave_base += s_wave_tot[w];
+    wbase[tid] = (uint32_t)(wave_base + incl - my);
+    const int total = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    __syncthreads();
+    // ---- pass 5 ----
     uint32_t* out = cand + (size_t)frame * cand_frame_stride + c.slot_off;
-    const int lane = tid & 63, wave = tid >> 6;
-    int base = 0;
-    for (int q0 = 0; q0 < n_int; q0 += 256) {
-        const int q = q0 + tid;
-        const bool on = (q < n_int) && (flags[q] & bit);
-        const unsigned long long mask = __ballot(on);
-        if (lane == 0) s_wave_cnt[wave] = __popcll(mask);
-        __syncthreads();
-        int wave_base = base;
-        for (int w = 0; w < wave; w++) wave_base += s_wave_cnt[w];
-        const int total = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
-        if (on) {
-            const int rank = wave_base + __popcll(mask & ((1ull << lane) - 1ull));
+    for (int i = tid; i < nsurv; i += 256) {
+        const int q = surv[i];
+        const uint32_t wd = bits[q >> 5];
+        if ((wd >> (q & 31)) & 1u) {
+            const int rank = (int)wbase[q >> 5] + __popc(wd & ((1u << (q & 31)) - 1u));
             const int y = q / iw, x = q - y * iw;
             const int m = mt[(y + 1) * m_pitch + x + 1];
             // coordinates relative to minBorder (= level coordinates - 16), as vToDistributeKeys holds them (:865-866)
             const uint32_t px = (uint32_t)(c.x0 + 3 + x - 16), py = (uint32_t)(c.y0 + 3 + y - 16);
             if (rank < c.slot_cap) out[rank] = pack_key(px, py, (uint32_t)(m - 1));
         }
-        base += total;
-        __syncthreads();
     }
-    if (tid == 0) cell_count[(size_t)frame * n_cells + blockIdx.x] = min(base, c.slot_cap);
+    if (tid == 0) cell_count[(size_t)frame * n_cells + cell_idx] = min(total, c.slot_cap);
 }
+#undef ORBX_B
 
 // ------------------------------------------------------------------------------------------------
 // E3: DistributeOctTree.  One wave per (frame, level).  The std::list of nodes is an index-linked list
@@ -542,12 +579,14 @@ __device__ __forceinline__ int reflect101(int p, int len)
 constexpr int kBlurTW = 64, kBlurTH = 32;
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t frame_stride,
-                                              const LevelDesc* __restrict__ levels, const TileDesc* __restrict__ tiles,
+                                              const LevelDesc* __restrict__ levels, const TileDesc* __restrict__ tiles, int n_tiles,
                                               int t0, int t1, int t2, int t3)
 {
     __shared__ __align__(16) uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
     __shared__ __align__(16) uint16_t s_h[(kBlurTH + 6) * kBlurTW];
-    const TileDesc T = tiles[blockIdx.x];
+    const int tile_idx = xcd_remap(blockIdx.x, blockIdx.y);     // contiguous tile range per XCD (see k_fast_cells)
+    if (tile_idx >= n_tiles) return;
+    const TileDesc T = tiles[tile_idx];
     const LevelDesc L = levels[T.level];
     const uint8_t* img = pyr + (size_t)blockIdx.y * frame_stride + L.off;
     uint8_t* dst = blur + (size_t)blockIdx.y * frame_stride + L.off;

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Everything measured on the GPU box in one gpurun call: parity tests, bench, rocprofv3 kernel stats, PMC traffic.
+# usage (from the repo root on the box):  bash tools/gpu_round.sh <tag>
+set -o pipefail
+TAG=${1:-rXX}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+timeout -k 10 420 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?
+tail -3 $OUT/pytest_gpu.log
+if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out: stopping"; exit 1; fi
+timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_prof.json 2> $OUT/bench_prof.err || { echo "rocprof stats failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu --no-lba > /dev/null 2> $OUT/pmc_fetch.err || { echo "pmc fetch failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu --no-lba > /dev/null 2> $OUT/pmc_write.err || { echo "pmc write failed"; exit 1; }
+python tools/collect_pmc.py $OUT/pmc_fetch $OUT/pmc_write 256 > $OUT/pmc_traffic.log && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+cp $(ls $OUT/prof/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+python - <<PY
+import json
+d = json.load(open("$OUT/bench.json"))
+print("frames/s %.0f  x%.0f vs cpu  roofline %s frac %.4f" % (d["value"], d.get("speedup_vs_cpu_1core", 0), d["roofline"]["kernel"], d["roofline"]["frac"]))
+print({k: round(v, 3) for k, v in d["roofline"]["stage_ms"].items()})
+print("lba iters/s %.0f  x%.1f vs cpu  call_ms %.2f" % (d["lba"]["value"], d["lba"].get("speedup_vs_cpu_1core", 0), d["lba"]["lba_solve_call_ms_incl_upload"]))
+t = json.load(open("$OUT/pmc_traffic.json"))
+print("traffic MB/launch", {k: round(v / 1e6, 1) for k, v in t.items() if not k.startswith("_")})
+PY
