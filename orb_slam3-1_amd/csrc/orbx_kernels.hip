@@ -22,7 +22,7 @@
 
 namespace orbx {
 
-__device__ const signed char d_pattern[1024] = {
+__device__ __align__(16) const signed char d_pattern[1024] = {
 #include "orb_pattern_31.inc"
 };
 
@@ -46,35 +46,59 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x4 = (tx * 64 + (threadIdx.x & 63)) * 4;
     const int dy = ty * 4 + (threadIdx.x >> 6);
-    if (x4 >= dst.w || dy >= dst.h) return;
     const uint8_t* sbase = pyr + (size_t)blockIdx.y * frame_stride + src.off;
     uint8_t* dbase = pyr + (size_t)blockIdx.y * frame_stride + dst.off;
+    // stage the source window of this 256 x 4 destination tile in LDS with coalesced dword loads (source rows are 64-B
+    // aligned); the bilinear taps then come from LDS instead of 16 scattered global byte loads per thread
+    constexpr int kPitch = 352, kRows = 8;          // 256 * 1.34 + slack; 4 dst rows need at most 7 source rows at scale >= 1
+    __shared__ __align__(16) uint8_t s_win[kRows * kPitch];
+    const int dx_first = tx * 256, dx_last = min(dx_first + 255, dst.w - 1);
+    const int dy_first = ty * 4, dy_last = min(dy_first + 3, dst.h - 1);
+    const int sy_lo = min(max(yofs[dy_first], 0), src.h - 1);
+    const int sy_hi = min(max(yofs[dy_last] + 1, 0), src.h - 1);
+    const int xa = xofs[dx_first] & ~3;
+    const int x_hi = min(xofs[dx_last] + 1, src.w - 1);
+    const int ndw = ((x_hi - xa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;
+    const bool staged = (ndw * 4 <= kPitch) && (nrows <= kRows);      // always true for scale factors >= 1.0
+    if (staged) {
+        for (int i = threadIdx.x; i < nrows * ndw; i += 256) {
+            const int r = i / ndw, q = i - r * ndw;
+            *(uint32_t*)(s_win + r * kPitch + 4 * q) = *(const uint32_t*)(sbase + (size_t)(sy_lo + r) * src.stride + xa + 4 * q);
+        }
+    }
+    __syncthreads();
+    if (x4 >= dst.w || dy >= dst.h) return;
     int sy0 = yofs[dy], sy1 = sy0 + 1;
     sy0 = min(max(sy0, 0), src.h - 1);
     sy1 = min(max(sy1, 0), src.h - 1);
-    const uint8_t* S0 = sbase + (size_t)sy0 * src.stride;
-    const uint8_t* S1 = sbase + (size_t)sy1 * src.stride;
     const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
-    uint32_t packed = 0;
     // the coefficient tables are padded to a multiple of 4 entries: one 16-B load each instead of 12 scalar ones
     const int4 sx4 = *(const int4*)(xofs + x4);
     const uint4 al4 = *(const uint4*)(ialpha + 2 * x4);
     const int sxs[4] = {sx4.x, sx4.y, sx4.z, sx4.w};
     const uint32_t als[4] = {al4.x, al4.y, al4.z, al4.w};
+    // inlined twice so that each call site keeps its address space (LDS reads vs global loads, no flat accesses)
+    auto taps = [&](const uint8_t* S0, const uint8_t* S1) -> uint32_t {
+        uint32_t packed = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int dx = x4 + k;
-        if (dx < dst.w) {
-            const int sx = sxs[k];
-            const int sx1 = min(sx + 1, src.w - 1);
-            const int a0 = (int)(short)(als[k] & 0xFFFFu), a1 = (int)(short)(als[k] >> 16);
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            packed |= (uint32_t)v << (8 * k);
+        for (int k = 0; k < 4; k++) {
+            const int dx = x4 + k;
+            if (dx < dst.w) {
+                const int sx = sxs[k];
+                const int sx1 = min(sx + 1, src.w - 1);
+                const int a0 = (int)(short)(als[k] & 0xFFFFu), a1 = (int)(short)(als[k] >> 16);
+                const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+                const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+                int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                packed |= (uint32_t)v << (8 * k);
+            }
         }
-    }
+        return packed;
+    };
+    uint32_t packed;
+    if (staged) packed = taps(s_win + (sy0 - sy_lo) * kPitch - xa, s_win + (sy1 - sy_lo) * kPitch - xa);
+    else packed = taps(sbase + (size_t)sy0 * src.stride, sbase + (size_t)sy1 * src.stride);
     *(uint32_t*)(dbase + (size_t)dy * dst.stride + x4) = packed;    // stride is a multiple of 64: in-row padding exists
 }
 
@@ -708,8 +732,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
     unsigned long long w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const signed char* pt = d_pattern + 4 * (lane + 64 * q);
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const uint32_t pw = ((const uint32_t*)d_pattern)[lane + 64 * q];       // one dword = (x0, y0, x1, y1) as int8
+        const float x0 = (float)(signed char)(pw & 0xFF), y0 = (float)(signed char)((pw >> 8) & 0xFF);
+        const float x1 = (float)(signed char)((pw >> 16) & 0xFF), y1 = (float)(signed char)(pw >> 24);
         const int t0 = bimg[cv_round_f(x0 * b + y0 * a) * L.stride + cv_round_f(x0 * a - y0 * b)];
         const int t1 = bimg[cv_round_f(x1 * b + y1 * a) * L.stride + cv_round_f(x1 * a - y1 * b)];
         w[q] = __ballot(t0 < t1);
