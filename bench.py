@@ -99,12 +99,18 @@ def main():
         log("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    local_rank %= torch.cuda.device_count()      # rehearsals with more ranks than GPUs (gloo) share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        import datetime
+        backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
     pkg = importlib.import_module("orb_slam3-1_amd")
     synth = importlib.import_module("orb_slam3-1_amd.synth")
@@ -247,6 +253,17 @@ def main():
 
     # ---- sharded global BA with one RCCL all-reduce per LM trial (N>1) ----
     if world > 1 and not args.no_lba:
+        # watchdog: the headline number must survive even if this extra leg ever stalled inside a collective
+        import threading
+
+        def _bail():
+            if rank == 0:
+                out["gba"] = {"error": "watchdog: sharded global BA leg exceeded 150 s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        wd = threading.Timer(150.0, _bail)
+        wd.daemon = True
+        wd.start()
         try:
             wg = synth.make_ba_window(3, n_opt=190, n_fixed=10, n_points=8000, obs_per_point=10)
             loc, _, _ = dmod.partition_landmarks(wg, rank, world)
@@ -266,13 +283,17 @@ def main():
         except Exception as e:     # the frame-sharded headline number stands on its own
             if rank == 0:
                 out["gba"] = {"error": repr(e)}
+        wd.cancel()
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     plan.close(); matcher.close(); ex.close()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":
