@@ -687,38 +687,42 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
                                                      OrbxKeyPoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap,
                                                      OrbxKeyPoint* __restrict__ lvl_kps /* optional: per-level keypoints, level coords */)
 {
-    const int frame = blockIdx.y;
+    // grid = (keypoint quads of a level, level, frame): the level is known without a search and its descriptor is one
+    // scalar load; all loads that do not depend on the angle (selection record, output row, 16 IC rows, 4 pattern dwords)
+    // are issued up front so that a wave sees three dependent memory round trips instead of six.
+    const int frame = blockIdx.z, level = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);       // index into the per-frame sel buffer (level-major slots)
-    if (slot >= sel_frame_stride) return;
-    // which level does this slot belong to?
-    int level = -1;
-    LevelDesc L;
-    for (int l = 0; l < n_levels; l++) {
-        const LevelDesc t = levels[l];
-        if (slot >= t.sel_off && slot < t.sel_off + t.sel_cap) { level = l; L = t; }
-    }
-    if (level < 0) return;
-    const int k = slot - L.sel_off;
-    if (k >= sel_count[(size_t)frame * n_levels + level]) return;
+    const LevelDesc L = levels[level];
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= L.sel_cap || k >= sel_count[(size_t)frame * n_levels + level]) return;
+    const int slot = L.sel_off + k;
     const uint32_t e = sel[(size_t)frame * sel_frame_stride + slot];
+    const int row = kp_dst[(size_t)frame * kp_frame_stride + slot];
+    uint32_t pw[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) pw[q] = ((const uint32_t*)d_pattern)[lane + 64 * q];       // one dword = (x0, y0, x1, y1) as int8
     const int px = (int)key_x(e) + 16, py = (int)key_y(e) + 16;     // level coordinates (:885-886)
 
-    // ---- IC_Angle: lanes 0..30 take column u = lane-15 of row +v, lanes 32..62 the same column of row -v... two rows per step
+    // ---- IC_Angle: lanes 0..30 take column u = lane-15 of rows v = 0..15, lanes 32..62 the same column of rows -1..-15
     const uint8_t* img = pyr + (size_t)frame * frame_stride + L.off + (size_t)py * L.stride + px;
-    const int half = lane >> 5;             // 0: rows v = 0..15 stepping, 1: rows v = -1..-15
-    const int u = (lane & 31) - 15;
+    const int half = lane >> 5;
+    const int u = (lane & 31) - 15, au = u < 0 ? -u : u;
+    const unsigned long long kUmax = 0x3689ABCDDEEEFFFFull;     // umax[v] of the radius-15 disc (:453-468), 4 bits each
     int m10 = 0, m01 = 0;
     if ((lane & 31) < 31) {
+        int vals[16];
+#pragma unroll
         for (int vi = 0; vi < 16; vi++) {
             const int v = half ? -(vi + 1) : vi;
-            if (half && vi == 15) break;    // rows -1..-15 only
-            const int av = v < 0 ? -v : v;
-            if (u >= -d_umax[av] && u <= d_umax[av]) {
-                const int val = img[v * L.stride + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
+            const int av = half ? vi + 1 : vi;
+            const bool in = (av <= 15) && (au <= (int)((kUmax >> (4 * (av & 15))) & 15));
+            vals[vi] = in ? (int)img[v * L.stride + u] : 0;
+        }
+#pragma unroll
+        for (int vi = 0; vi < 16; vi++) {
+            const int v = half ? -(vi + 1) : vi;
+            m10 += u * vals[vi];
+            m01 += v * vals[vi];
         }
     }
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
@@ -730,16 +734,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
     sincos_f32(angle * factorPI, &a, &b);
     const uint8_t* bimg = blur + (size_t)frame * frame_stride + L.off + (size_t)py * L.stride + px;
     unsigned long long w[4];
+    int t0s[4], t1s[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const uint32_t pw = ((const uint32_t*)d_pattern)[lane + 64 * q];       // one dword = (x0, y0, x1, y1) as int8
-        const float x0 = (float)(signed char)(pw & 0xFF), y0 = (float)(signed char)((pw >> 8) & 0xFF);
-        const float x1 = (float)(signed char)((pw >> 16) & 0xFF), y1 = (float)(signed char)(pw >> 24);
-        const int t0 = bimg[cv_round_f(x0 * b + y0 * a) * L.stride + cv_round_f(x0 * a - y0 * b)];
-        const int t1 = bimg[cv_round_f(x1 * b + y1 * a) * L.stride + cv_round_f(x1 * a - y1 * b)];
-        w[q] = __ballot(t0 < t1);
+        const float x0 = (float)(signed char)(pw[q] & 0xFF), y0 = (float)(signed char)((pw[q] >> 8) & 0xFF);
+        const float x1 = (float)(signed char)((pw[q] >> 16) & 0xFF), y1 = (float)(signed char)(pw[q] >> 24);
+        t0s[q] = bimg[cv_round_f(x0 * b + y0 * a) * L.stride + cv_round_f(x0 * a - y0 * b)];
+        t1s[q] = bimg[cv_round_f(x1 * b + y1 * a) * L.stride + cv_round_f(x1 * a - y1 * b)];
     }
-    const int row = kp_dst[(size_t)frame * kp_frame_stride + slot];
+#pragma unroll
+    for (int q = 0; q < 4; q++) w[q] = __ballot(t0s[q] < t1s[q]);
     if (lane == 0) {
         OrbxKeyPoint kp;
         kp.x = (float)px; kp.y = (float)py;

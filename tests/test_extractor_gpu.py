@@ -56,6 +56,13 @@ def test_stagewise_640x480(pkg, oracle, synth, gpu_ex, seed):
     ((480, 752), (1200, 1.2, 8, 20, 7), (100, 400)),     # fisheye style overlap bounds
     ((97, 131), (150, 1.5, 3, 15, 5), (0, 1000)),
     ((480, 640), (5000, 1.2, 8, 20, 7), (0, 1000)),      # mono initialisation extractor (5 x nFeatures)
+    ((376, 1241), (2000, 1.2, 8, 20, 7), (0, 1000)),     # KITTI aspect: nIni = round(w/h) = 4 octree roots (:559)
+    ((300, 1000), (800, 1.2, 6, 20, 7), (0, 0)),         # nIni = 3
+    ((640, 480), (1000, 1.2, 8, 20, 7), (0, 1000)),      # portrait: nIni = round(0.73) = 1
+    ((900, 400), (600, 1.2, 4, 20, 7), (0, 1000)),       # nIni = round(0.42) = 0: the reference would divide by zero; both sides yield no keypoints
+    ((80, 90), (100, 1.2, 3, 20, 7), (0, 1000)),         # upper levels too small for a single 35-px cell
+    ((480, 640), (1000, 2.0, 4, 20, 7), (0, 1000)),      # scale factor 2
+    ((480, 640), (1000, 1.2, 8, 40, 12), (0, 1000)),     # other FAST thresholds
 ])
 def test_end_to_end_shapes(pkg, oracle, synth, shape, params, lap):
     h, w = shape
