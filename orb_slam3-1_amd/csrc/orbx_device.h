@@ -12,6 +12,7 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD   (reference src/ORBextract
 constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE  (:72)
 constexpr int kPatch = 31;         // PATCH_SIZE       (:71)
 constexpr int kMaxLevels = 16;
+constexpr int kOctLogFactor = 6;     // octree push log capacity = 6 x node pool (<= 4 pushes per alive node between compactions)
 
 // One pyramid level of one frame inside the per-frame pyramid buffer.
 struct LevelDesc {

@@ -285,7 +285,7 @@ int orbx_extractor::setup_geometry(int w, int h)
     if (oct_pool > 16000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree", max_nfeat);
     const char* env = getenv("ORBX_OCT_LDS_KEYS");
     oct_lds_keys = env ? atoi(env) : 0;      // measured on MI355X: L2-resident HBM scratch + more resident waves beats LDS keys
-    const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 16) + (size_t)((oct_pool + 15) & ~15);
+    const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 14 + 2 * kOctLogFactor) + (size_t)((oct_pool + 15) & ~15);
     if (node_bytes + 8 * (size_t)oct_lds_keys > 150 * 1024) oct_lds_keys = (int)((150 * 1024 - node_bytes) / 8);
     if (oct_lds_keys < 0) oct_lds_keys = 0;
     oct_lds = node_bytes + 8 * (size_t)oct_lds_keys + 16;

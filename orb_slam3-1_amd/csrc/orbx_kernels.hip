@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 struct OctLds {
     short* ulx; short* uly; short* brx; short* bry;
     int* beg; int* cnt;
-    short* prev; short* next; short* freelist; short* order;
+    short* pidx; short* freelist; short* order;
+    short* plog;            // push log: the std::list order is the REVERSE of this array without its tombstones (-1)
     uint8_t* flg;           // bit0: bNoMore, bit1: keys live in buffer 1
     SortNode* ex[2];
 };
@@ -326,8 +327,9 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
         S.cnt = (int*)p; p += 4 * pool;
         S.ulx = (short*)p; p += 2 * pool;  S.uly = (short*)p; p += 2 * pool;
         S.brx = (short*)p; p += 2 * pool;  S.bry = (short*)p; p += 2 * pool;
-        S.prev = (short*)p; p += 2 * pool; S.next = (short*)p; p += 2 * pool;
+        S.pidx = (short*)p; p += 2 * pool;
         S.freelist = (short*)p; p += 2 * pool; S.order = (short*)p; p += 2 * pool;
+        S.plog = (short*)p; p += 2 * kOctLogFactor * pool;
         S.flg = p; p += (pool + 15) & ~15;
         // keys follow
         uint32_t* lds_keys = (uint32_t*)p;
@@ -347,12 +349,17 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
             uint32_t* g = scratch + (size_t)frame * scratch_frame_stride + 2 * (size_t)L.cand_off;
             keys[0] = g; keys[1] = g + L.cand_cap;
         }
+        // one lane per cell: in-wave exclusive prefix of the cell counts gives each cell its place in the ordered list
         int run = 0;
-        for (int ci = 0; ci < L.cell_count; ci++) {
-            const CellDesc c = cells[L.cell_begin + ci];
-            const int n = cc[L.cell_begin + ci];
-            for (int k = lane; k < n; k += 64) keys[0][run + k] = fc[c.slot_off + k];
-            run += n;
+        for (int c0 = 0; c0 < L.cell_count; c0 += 64) {
+            const int ci = c0 + lane;
+            int n = 0, slot_off = 0;
+            if (ci < L.cell_count) { n = cc[L.cell_begin + ci]; slot_off = cells[L.cell_begin + ci].slot_off; }
+            int incl = n;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            const int base = run + incl - n;
+            for (int k = 0; k < n; k++) keys[0][base + k] = fc[slot_off + k];
+            run += __shfl(incl, 63);
         }
         __syncthreads();
 
@@ -369,28 +376,32 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
         }
 
         // ---- list primitives (wave-uniform: every lane runs them on identical values) ----
-        int head = -1, tail = -1, size = 0, nfree = pool;
+        // std::list<ExtractorNode> with push_front / erase only needs an append-only push log: iterating the list from
+        // begin() is walking the log backwards, erase() leaves a tombstone, and nodes pushed while a pass is running sit
+        // behind its start index exactly like nodes pushed in front of a running list iterator.  This keeps the
+        // dependent LDS round trips per DivideNode to a handful (no prev/next pointer chasing).
+        const int plog_cap = kOctLogFactor * pool;
+        int np = 0, size = 0, nfree = pool;
         for (int i = lane; i < pool; i += 64) S.freelist[i] = (short)(pool - 1 - i);
         __syncthreads();
         bool overflow = false;
-        auto alloc = [&]() -> int { if (nfree <= 0) { overflow = true; return 0; } return S.freelist[--nfree]; };
-        auto release = [&](int i) { S.freelist[nfree++] = (short)i; };
-        auto push_front = [&](int i) {
-            S.prev[i] = -1; S.next[i] = (short)head;
-            if (head >= 0) S.prev[head] = (short)i; else tail = i;
-            head = i; size++;
+        auto push = [&](int i) {
+            if (np >= plog_cap) { overflow = true; return; }
+            S.plog[np] = (short)i; S.pidx[i] = (short)np;
+            np++; size++;
         };
-        auto push_back = [&](int i) {
-            S.next[i] = -1; S.prev[i] = (short)tail;
-            if (tail >= 0) S.next[tail] = (short)i; else head = i;
-            tail = i; size++;
-        };
-        auto erase = [&](int i) {
-            const int p0 = S.prev[i], n0 = S.next[i];
-            if (p0 >= 0) S.next[p0] = (short)n0; else head = n0;
-            if (n0 >= 0) S.prev[n0] = (short)p0; else tail = p0;
-            size--;
-            release(i);
+        auto kill = [&](int i) { S.plog[S.pidx[i]] = -1; S.freelist[nfree++] = (short)i; size--; };
+        auto compact = [&]() {          // drop tombstones, order preserved (wave-parallel, in place)
+            int w = 0;
+            for (int i0 = 0; i0 < np; i0 += 64) {
+                const int i = i0 + lane;
+                const int id = (i < np) ? (int)S.plog[i] : -1;
+                const unsigned long long m = __ballot(id >= 0);
+                if (id >= 0) { const int pos = w + __popcll(m & ((1ull << lane) - 1ull)); S.plog[pos] = (short)id; S.pidx[id] = (short)pos; }
+                w += __popcll(m);
+            }
+            np = w;
+            __syncthreads();
         };
 
         // ---- root nodes (:564-586): nIni vertical strips of width hX
@@ -410,16 +421,19 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                     if (in) keys[1][strip_beg + cnt + __popcll(m & ((1ull << lane) - 1ull))] = e;
                     cnt += __popcll(m);
                 }
+                int id = -1;
                 if (cnt > 0) {      // empty roots are erased (:595-596)
-                    const int id = alloc();
+                    id = S.freelist[--nfree];
                     S.ulx[id] = (short)(int)(hX * (float)s);       S.uly[id] = 0;
                     S.brx[id] = (short)(int)(hX * (float)(s + 1)); S.bry[id] = (short)height;
                     S.beg[id] = strip_beg; S.cnt[id] = cnt;
                     S.flg[id] = (uint8_t)(2 | (cnt == 1 ? 1 : 0));
-                    push_back(id);
                 }
+                S.order[s] = (short)id;
                 strip_beg += cnt;
             }
+            // the reference push_back()s the roots in strip order; in push-log terms the first strip is pushed last
+            for (int s = nIni - 1; s >= 0; s--) { const int id = S.order[s]; if (id >= 0) push(id); }
             __syncthreads();
         }
 
@@ -434,42 +448,59 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
             const int midx = ulx + halfX, midy = uly + halfY;
             const uint32_t* kin = keys[src];
             uint32_t* kout = keys[src ^ 1];
-            // pass 1: child sizes
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int k0 = 0; k0 < cnt; k0 += 64) {
-                const int k = k0 + lane;
-                int cls = -1;
-                if (k < cnt) { const uint32_t e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
-                c0 += __popcll(__ballot(cls == 0)); c1 += __popcll(__ballot(cls == 1));
-                c2 += __popcll(__ballot(cls == 2)); c3 += __popcll(__ballot(cls == 3));
-            }
-            const int b0 = beg, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2;
-            // pass 2: stable scatter into the other buffer
-            int w0 = b0, w1 = b1, w2 = b2, w3 = b3;
             const unsigned long long lt = (1ull << lane) - 1ull;
-            for (int k0 = 0; k0 < cnt; k0 += 64) {
-                const int k = k0 + lane;
+            if (cnt <= 64) {
+                // the common case after the first passes: one load, four ballots, one store
                 int cls = -1;
                 uint32_t e = 0;
-                if (k < cnt) { e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
+                if (lane < cnt) { e = kin[beg + lane]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
                 const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
-                if (cls == 0) kout[w0 + __popcll(m0 & lt)] = e;
-                else if (cls == 1) kout[w1 + __popcll(m1 & lt)] = e;
-                else if (cls == 2) kout[w2 + __popcll(m2 & lt)] = e;
-                else if (cls == 3) kout[w3 + __popcll(m3 & lt)] = e;
-                w0 += __popcll(m0); w1 += __popcll(m1); w2 += __popcll(m2); w3 += __popcll(m3);
+                c0 = __popcll(m0); c1 = __popcll(m1); c2 = __popcll(m2); c3 = __popcll(m3);
+                if (cls == 0) kout[beg + __popcll(m0 & lt)] = e;
+                else if (cls == 1) kout[beg + c0 + __popcll(m1 & lt)] = e;
+                else if (cls == 2) kout[beg + c0 + c1 + __popcll(m2 & lt)] = e;
+                else if (cls == 3) kout[beg + c0 + c1 + c2 + __popcll(m3 & lt)] = e;
+            } else {
+                // pass 1: child sizes
+                for (int k0 = 0; k0 < cnt; k0 += 64) {
+                    const int k = k0 + lane;
+                    int cls = -1;
+                    if (k < cnt) { const uint32_t e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
+                    c0 += __popcll(__ballot(cls == 0)); c1 += __popcll(__ballot(cls == 1));
+                    c2 += __popcll(__ballot(cls == 2)); c3 += __popcll(__ballot(cls == 3));
+                }
+                // pass 2: stable scatter into the other buffer
+                int w0 = beg, w1 = beg + c0, w2 = beg + c0 + c1, w3 = beg + c0 + c1 + c2;
+                for (int k0 = 0; k0 < cnt; k0 += 64) {
+                    const int k = k0 + lane;
+                    int cls = -1;
+                    uint32_t e = 0;
+                    if (k < cnt) { e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
+                    const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+                    if (cls == 0) kout[w0 + __popcll(m0 & lt)] = e;
+                    else if (cls == 1) kout[w1 + __popcll(m1 & lt)] = e;
+                    else if (cls == 2) kout[w2 + __popcll(m2 & lt)] = e;
+                    else if (cls == 3) kout[w3 + __popcll(m3 & lt)] = e;
+                    w0 += __popcll(m0); w1 += __popcll(m1); w2 += __popcll(m2); w3 += __popcll(m3);
+                }
             }
+            const int b0 = beg, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2;
             const int cb[4] = {b0, b1, b2, b3}, cn[4] = {c0, c1, c2, c3};
             const int cux[4] = {ulx, midx, ulx, midx}, cuy[4] = {uly, uly, midy, midy};
             const int cbx[4] = {midx, brx, midx, brx}, cby[4] = {midy, midy, bry, bry};
+            if (nfree < 4) { overflow = true; return; }
+            const int fs[4] = {S.freelist[nfree - 1], S.freelist[nfree - 2], S.freelist[nfree - 3], S.freelist[nfree - 4]};    // independent reads
+            int used = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 if (cn[c] > 0) {
-                    const int ch = alloc();
+                    const int ch = used == 0 ? fs[0] : used == 1 ? fs[1] : used == 2 ? fs[2] : fs[3];
+                    used++;
                     S.ulx[ch] = (short)cux[c]; S.uly[ch] = (short)cuy[c]; S.brx[ch] = (short)cbx[c]; S.bry[ch] = (short)cby[c];
                     S.beg[ch] = cb[c]; S.cnt[ch] = cn[c];
                     S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn[c] == 1 ? 1 : 0));
-                    push_front(ch);
+                    push(ch);
                     if (cn[c] > 1) {
                         n_to_expand++;
                         SortNode sn; sn.count = cn[c]; sn.ulx = cux[c]; sn.node = ch;
@@ -478,7 +509,8 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                     }
                 }
             }
-            erase(id);
+            nfree -= used;
+            kill(id);
             __syncthreads();        // key scatter visible to every lane before the children are read
         };
 
@@ -488,11 +520,10 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
             const int prev_size = size;
             int n_to_expand = 0;
             n_ex = 0;
-            int cur = head;
-            while (cur >= 0 && !overflow) {
-                const int nxt = S.next[cur];
-                if (!(S.flg[cur] & 1)) divide(cur, n_to_expand);
-                cur = nxt;
+            compact();
+            for (int idx = np - 1; idx >= 0 && !overflow; idx--) {      // children pushed by this pass land behind idx
+                const int cur = S.plog[idx];
+                if (cur >= 0 && !(S.flg[cur] & 1)) divide(cur, n_to_expand);
             }
             if (size >= N || size == prev_size) {
                 finish = true;
@@ -500,6 +531,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                 int guard2 = 0;
                 while (!finish && !overflow && guard2++ < 4096) {
                     const int prev_size2 = size;
+                    compact();
                     const int n_prev = min(n_ex, pool);
                     SortNode* pv = S.ex[cur_ex];
                     if (lane == 0) introsort_nodes(pv, n_prev);     // std::sort(..., compareNodes) (:700)
@@ -521,10 +553,8 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
         }
 
         // ---- final list order, then the best-response key of every node, first wins ties (:758-776)
-        {
-            int cur = head, k = 0;
-            while (cur >= 0 && k < pool) { S.order[k++] = (short)cur; cur = S.next[cur]; }
-        }
+        compact();
+        for (int k = lane; k < np && k < pool; k += 64) S.order[k] = S.plog[np - 1 - k];
         __syncthreads();
         const int n_out = min(size, L.sel_cap);
         for (int k = lane; k < n_out; k += 64) {
