@@ -132,6 +132,9 @@ struct orbx_extractor {
     hipEvent_t prof_ev[kProfEvents] = {};
     int prof_marks = 0;
     hipStream_t prof_stream = nullptr;
+    // side stream for the blur (runs beside the latency-bound octree)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     int setup_geometry(int w, int h);
     int ensure_batch(int batch);
@@ -360,6 +363,17 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(n_cells), B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
                            ini_th, min_th, tile_pitch, tile_rows, m_pitch, surv_off, bits_off, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
     mark();
+    // The octree is latency-bound (one wave per frame and level) and leaves most of the chip idle, while the blur only
+    // needs the pyramid: run the blur on a side stream next to octree + index and join before the descriptors.
+    // (Per-stage profiling keeps everything on one stream so that each stage is timed alone.)
+    const bool overlap = !profile && side_stream != nullptr;
+    if (overlap) {
+        ORBX_HIP(hipEventRecord(ev_fork, st));
+        ORBX_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, side_stream, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
+                           (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
+        ORBX_HIP(hipEventRecord(ev_join, side_stream));
+    }
     hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), oct_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
                        d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, oct_lds_keys,
                        d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status);
@@ -367,8 +381,10 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,
                        lap0, lap1, cap, d_kp_dst.p, sel_frame_entries, o_n, o_mono, o_status);
     mark();
-    hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
-                       (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
+    if (overlap) ORBX_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    else
+        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
+                           (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
     mark();
     int max_sel_cap = 0;
     for (const LevelDesc& lv : levels) max_sel_cap = std::max(max_sel_cap, lv.sel_cap);
@@ -436,6 +452,9 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
     e->scale_factor_f = scale_factor; e->scale_factor_d = (double)scale_factor;
     build_tables(e);
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(ORBX_ERR_HIP, "stream create failed"); }
+    if (hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
     *out = e;
     return ORBX_OK;
 }
@@ -445,6 +464,9 @@ void orbx_destroy(orbx_extractor* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     e->d_levels.release(); e->d_cells.release(); e->d_tiles.release();
     for (auto& b : e->d_xofs) b.release();
     for (auto& b : e->d_yofs) b.release();
