@@ -269,6 +269,39 @@ int lba_shard_reset(lba_shard* s);     /* back to the initial estimates (benchma
 /* estimates of the accepted state; chi2_per_edge = e->chi2() of the last computed errors, depth_positive = isDepthPositive() */
 int lba_shard_download(lba_shard* s, double* pose_q, double* pose_t, double* points, double* chi2_per_edge, uint8_t* depth_positive);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Motion-only BA.  Replaces  int Optimizer::PoseOptimization(Frame* pFrame)
+ * (reference include/Optimizer.h:66, src/Optimizer.cc:814-1115) for the pinhole mono / stereo edges
+ * (EdgeSE3ProjectXYZOnlyPose src/OptimizableTypes.cpp:49-63, g2o::EdgeStereoSE3ProjectXYZOnlyPose
+ * Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp:338-395).  The caller flattens the frame: one edge per feature i that
+ * holds a MapPoint (pFrame->mvpMapPoints[i]), in feature order; after the call it writes outlier[] back to
+ * pFrame->mvbOutlier[i], the pose to pFrame->SetPose() and returns `inliers` (= nInitialCorrespondences - nBad).
+ * The whole 4-round Levenberg optimisation of a frame is one workgroup of one kernel launch; a batch is one launch. */
+typedef struct PoseProblem {
+    double q[4], t[3];              /* pFrame->GetPose() as Tcw: qx qy qz qw, t (normalised on entry like g2o::SE3Quat) */
+    int32_t n;                      /* edges */
+    const double* Xw;               /* n x 3 MapPoint::GetWorldPos() */
+    const double* obs;              /* n x 3: kpUn.pt.x, kpUn.pt.y, mvuRight (ignored for mono edges) */
+    const double* inv_sigma2;       /* n: pFrame->mvInvLevelSigma2[kpUn.octave] */
+    const uint8_t* stereo;          /* n: 1 = stereo edge (mvuRight[i] >= 0) */
+    double fx, fy, cx, cy, bf;      /* pinhole intrinsics, pFrame->mbf */
+    double huber_mono, huber_stereo;/* deltaMono = sqrt(5.991), deltaStereo = sqrt(7.815) (:838-839) */
+} PoseProblem;
+
+typedef struct PoseResult {
+    double q[4], t[3];              /* optimised Tcw */
+    int32_t inliers;                /* the function's return value; 0 when n < 3 (:998-999) */
+    int32_t n_bad;
+} PoseResult;
+
+typedef struct pose_solver pose_solver;
+int  pose_create(int device, pose_solver** out);
+void pose_destroy(pose_solver* s);
+/* outlier: n bytes (may be NULL) */
+int  pose_optimize(pose_solver* s, const PoseProblem* problem, PoseResult* result, uint8_t* outlier);
+/* frames are independent: one workgroup each; outlier_out may be NULL or hold NULL entries */
+int  pose_optimize_batch(pose_solver* s, const PoseProblem* problems, int n_problems, PoseResult* results, uint8_t* const* outlier_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -718,3 +718,191 @@ void lba_oracle_shard_download(void* h, double* q, double* t, double* pts, doubl
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Optimizer::PoseOptimization (reference src/Optimizer.cc:814-1115): motion-only BA of one frame.  Unary edges
+// EdgeSE3ProjectXYZOnlyPose (src/OptimizableTypes.cpp:49-63, include/OptimizableTypes.h:35-54) and
+// g2o::EdgeStereoSE3ProjectXYZOnlyPose (types_six_dof_expmap.cpp:338-395), BaseUnaryEdge::constructQuadraticForm
+// (core/base_unary_edge.hpp:44-73), LinearSolverDense on the single 6x6 block, the same Levenberg loop as above,
+// 4 rounds x optimize(10) restarting from the frame pose, outlier re-classification with float chi2 (:1016-1100),
+// robust kernel removed after the third round, early exit when fewer than 10 edges exist.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct PoseOpt {
+    const OraclePoseProblem* p;
+    Pose T;
+    std::vector<double> err;            // 3 per edge: edge._error as last computed
+    std::vector<uint8_t> active;        // level 0
+    bool robust;
+    double dsqr_mono, dsqr_stereo;
+    double H[36], b[6], x[6];
+
+    void compute_error(int e, const Pose& P)
+    {
+        double Xc[3];
+        pose_map(P, p->Xw + 3 * (size_t)e, Xc);
+        const double* obs = p->obs + 3 * (size_t)e;
+        double* r = &err[3 * (size_t)e];
+        if (!p->stereo[e]) {
+            r[0] = obs[0] - (p->fx * Xc[0] / Xc[2] + p->cx);
+            r[1] = obs[1] - (p->fy * Xc[1] / Xc[2] + p->cy);
+            r[2] = 0;
+        } else {
+            const float invz = 1.0f / Xc[2];
+            const double u = Xc[0] * invz * p->fx + p->cx;
+            const double v = Xc[1] * invz * p->fy + p->cy;
+            r[0] = obs[0] - u; r[1] = obs[1] - v; r[2] = obs[2] - (u - p->bf * invz);     // double bf * float invz here
+        }
+    }
+    double chi2(int e) const
+    {
+        const double* r = &err[3 * (size_t)e];
+        const double w = p->inv_sigma2[e];
+        double c = r[0] * (w * r[0]) + r[1] * (w * r[1]);
+        if (p->stereo[e]) c += r[2] * (w * r[2]);
+        return c;
+    }
+    void robustify(int e, double chi, double rho[2]) const
+    {
+        const double delta = p->stereo[e] ? p->huber_stereo : p->huber_mono;
+        const double dsqr = p->stereo[e] ? dsqr_stereo : dsqr_mono;
+        if (!robust || chi <= dsqr) { rho[0] = chi; rho[1] = 1.; }
+        else { const double s = std::sqrt(chi); rho[0] = 2 * s * delta - dsqr; rho[1] = delta / s; }
+    }
+    void active_errors() { for (int e = 0; e < p->n; e++) if (active[e]) compute_error(e, T); }
+    double active_robust_chi2() const
+    {
+        double c = 0, rho[2];
+        for (int e = 0; e < p->n; e++) if (active[e]) { robustify(e, chi2(e), rho); c += rho[0]; }
+        return c;
+    }
+    void build()
+    {
+        std::memset(H, 0, sizeof(H)); std::memset(b, 0, sizeof(b));
+        for (int e = 0; e < p->n; e++) {
+            if (!active[e]) continue;
+            double Xc[3], J[18];
+            pose_map(T, p->Xw + 3 * (size_t)e, Xc);
+            const double xx = Xc[0], yy = Xc[1], zz = Xc[2];
+            const int D = p->stereo[e] ? 3 : 2;
+            if (!p->stereo[e]) {
+                const double pj[6] = {-(p->fx / zz), -0.0, -(-p->fx * xx / (zz * zz)), -0.0, -(p->fy / zz), -(-p->fy * yy / (zz * zz))};
+                const double S[18] = {0, zz, -yy, 1, 0, 0, -zz, 0, xx, 0, 1, 0, yy, -xx, 0, 0, 0, 1};
+                for (int r = 0; r < 2; r++)
+                    for (int c = 0; c < 6; c++) J[r * 6 + c] = pj[r * 3] * S[c] + pj[r * 3 + 1] * S[6 + c] + pj[r * 3 + 2] * S[12 + c];
+            } else {
+                const double invz = 1.0 / zz, invz_2 = invz * invz, fx = p->fx, fy = p->fy, bf = p->bf;
+                J[0] = xx * yy * invz_2 * fx; J[1] = -(1 + (xx * xx * invz_2)) * fx; J[2] = yy * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = xx * invz_2 * fx;
+                J[6] = (1 + yy * yy * invz_2) * fy; J[7] = -xx * yy * invz_2 * fy; J[8] = -xx * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = yy * invz_2 * fy;
+                J[12] = J[0] - bf * yy * invz_2; J[13] = J[1] + bf * xx * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2;
+            }
+            const double w = p->inv_sigma2[e];
+            const double* r = &err[3 * (size_t)e];
+            double rho[2];
+            robustify(e, chi2(e), rho);
+            for (int a = 0; a < 6; a++) {
+                double s = 0;
+                for (int d = 0; d < D; d++) s += J[d * 6 + a] * (w * r[d]);
+                b[a] -= rho[1] * s;
+                for (int c = 0; c < 6; c++) {
+                    double h = 0;
+                    for (int d = 0; d < D; d++) h += J[d * 6 + a] * (rho[1] * w) * J[d * 6 + c];
+                    H[a * 6 + c] += h;
+                }
+            }
+        }
+    }
+    // g2o optimize(iters) with Levenberg on the single pose vertex
+    void optimize(int iters)
+    {
+        int n_active = 0;
+        for (int e = 0; e < p->n; e++) n_active += active[e];
+        if (n_active == 0) return;
+        double lambda = -1, ni = 2;
+        int nBad = 0;
+        for (int it = 0; it < iters; it++) {
+            active_errors();
+            double currentChi = active_robust_chi2(), tempChi = currentChi;
+            const double iniChi = currentChi;
+            build();
+            if (it == 0) {
+                double m = 0;
+                for (int j = 0; j < 6; j++) m = std::max(std::fabs(H[j * 7]), m);
+                lambda = 1e-5 * m; ni = 2; nBad = 0;
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                const Pose backup = T;
+                std::vector<double> A(H, H + 36);
+                for (int j = 0; j < 6; j++) A[j * 7] += lambda;
+                const bool ok2 = ldlt_solve(A, 6, b, x);
+                if (ok2) T = pose_mul(se3_exp(x), T);
+                active_errors();
+                tempChi = active_robust_chi2();
+                if (!ok2) tempChi = std::numeric_limits<double>::max();
+                rho = currentChi - tempChi;
+                double scale = 0;
+                for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                scale += 1e-3;
+                rho /= scale;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1. - std::pow((2 * rho - 1), 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                } else {
+                    lambda *= ni; ni *= 2;
+                    T = backup;
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int pose_oracle_optimize(const OraclePoseProblem* p, double* q_out, double* t_out, uint8_t* outlier_out, int* n_bad_out)
+{
+    PoseOpt s;
+    s.p = p;
+    s.err.assign(3 * (size_t)std::max(p->n, 1), 0.0);
+    s.active.assign(std::max(p->n, 1), 1);
+    s.robust = true;
+    s.dsqr_mono = p->huber_mono * p->huber_mono; s.dsqr_stereo = p->huber_stereo * p->huber_stereo;
+    Pose T0;
+    T0.q.x = p->q[0]; T0.q.y = p->q[1]; T0.q.z = p->q[2]; T0.q.w = p->q[3];
+    for (int k = 0; k < 3; k++) T0.t[k] = p->t[k];
+    quat_normalize(T0.q);
+    s.T = T0;
+    std::vector<uint8_t> outlier(std::max(p->n, 1), 0);
+    int nBad = 0;
+    const int nInitial = p->n;
+    if (nInitial >= 3) {
+        const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+        for (int it = 0; it < 4; it++) {
+            s.T = T0;                               // vSE3->setEstimate(pFrame->GetPose()) every round (:1007-1008)
+            s.optimize(10);
+            nBad = 0;
+            for (int e = 0; e < p->n; e++) {
+                if (outlier[e]) s.compute_error(e, s.T);
+                const float chi2 = (float)s.chi2(e);
+                if (chi2 > (p->stereo[e] ? chi2Stereo : chi2Mono)) { outlier[e] = 1; s.active[e] = 0; nBad++; }
+                else { outlier[e] = 0; s.active[e] = 1; }
+            }
+            if (it == 2) s.robust = false;          // setRobustKernel(0) for the last round
+            if (p->n < 10) break;
+        }
+    }
+    q_out[0] = s.T.q.x; q_out[1] = s.T.q.y; q_out[2] = s.T.q.z; q_out[3] = s.T.q.w;
+    for (int k = 0; k < 3; k++) t_out[k] = s.T.t[k];
+    if (outlier_out) std::memcpy(outlier_out, outlier.data(), p->n);
+    if (n_bad_out) *n_bad_out = nBad;
+    return nInitial < 3 ? 0 : nInitial - nBad;
+}

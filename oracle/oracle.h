@@ -142,6 +142,19 @@ typedef struct OracleLbaStats {
     double chi2_trace[16];
 } OracleLbaStats;
 
+/* Optimizer::PoseOptimization (reference src/Optimizer.cc:814-1115): one frame pose, unary reprojection edges. */
+typedef struct OraclePoseProblem {
+    double q[4], t[3];              /* frame pose Tcw: qx qy qz qw, t */
+    int32_t n;                      /* edges = features holding a MapPoint */
+    const double* Xw;               /* n x 3 world positions */
+    const double* obs;              /* n x 3: u, v, u_right */
+    const double* inv_sigma2;       /* n */
+    const uint8_t* stereo;          /* n */
+    double fx, fy, cx, cy, bf;
+    double huber_mono, huber_stereo;
+} OraclePoseProblem;
+int   pose_oracle_optimize(const OraclePoseProblem* p, double* q_out, double* t_out, uint8_t* outlier_out, int* n_bad_out);
+
 int   lba_oracle_solve(const OracleLbaProblem* p, const volatile uint8_t* stop_flag, int max_iters, double lambda_init,
                        double* poses_q_out, double* poses_t_out, double* points_out,
                        double* chi2_per_edge, uint8_t* depth_positive, OracleLbaStats* stats);

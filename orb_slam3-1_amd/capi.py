@@ -509,3 +509,69 @@ class LbaShard:
         chi2 = np.zeros(len(k["edge_point"])); dpos = np.zeros(len(k["edge_point"]), np.uint8)
         _check(lib.lba_shard_download(self._h, _p(q), _p(t), _p(pts), _p(chi2), _p(dpos)))
         return dict(pose_q=q, pose_t=t, points=pts, chi2=chi2, depth_positive=dpos)
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("inliers", C.c_int32), ("n_bad", C.c_int32)]
+
+
+def _pose_problem(w, pr):
+    keep = [np.ascontiguousarray(w["Xw"], np.float64), np.ascontiguousarray(w["obs"], np.float64),
+            np.ascontiguousarray(w["inv_sigma2"], np.float64), np.ascontiguousarray(w["stereo"], np.uint8)]
+    pr.q[:] = [float(v) for v in w["q"]]
+    pr.t[:] = [float(v) for v in w["t"]]
+    pr.n = len(keep[0])
+    pr.Xw, pr.obs, pr.inv_sigma2, pr.stereo = (a.ctypes.data for a in keep)
+    for k in ("fx", "fy", "cx", "cy", "bf", "huber_mono", "huber_stereo"):
+        setattr(pr, k, float(w[k]))
+    return keep
+
+
+class PoseSolver:
+    """Optimizer::PoseOptimization (reference src/Optimizer.cc:814-1115): motion-only BA, one workgroup per frame."""
+
+    def __init__(self, device=0):
+        lib.pose_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.pose_destroy.argtypes = [C.c_void_p]
+        lib.pose_optimize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        h = C.c_void_p()
+        _check(lib.pose_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.pose_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prepare(self, problems):
+        """flatten a list of frames once (benchmarks re-run the same batch)"""
+        n = len(problems)
+        prs = (PoseProblem * n)()
+        keep = [_pose_problem(w, prs[i]) for i, w in enumerate(problems)]
+        outl = [np.zeros(max(prs[i].n, 1), np.uint8) for i in range(n)]
+        ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outl])
+        return dict(n=n, prs=prs, keep=keep, outl=outl, ptrs=ptrs, res=(PoseResult * n)())
+
+    def run(self, prep):
+        _check(lib.pose_optimize_batch(self._h, prep["prs"], prep["n"], prep["res"], prep["ptrs"]))
+        return [dict(q=np.array(r.q[:]), t=np.array(r.t[:]), inliers=r.inliers, n_bad=r.n_bad,
+                     outlier=prep["outl"][i][:prep["prs"][i].n].copy()) for i, r in enumerate(prep["res"])]
+
+    def optimize_batch(self, problems):
+        return self.run(self.prepare(problems))
+
+    def optimize(self, w):
+        return self.optimize_batch([w])[0]

@@ -213,3 +213,34 @@ def make_ba_window(seed, n_opt=50, n_fixed=10, n_points=2000, obs_per_point=10, 
                 edge_stereo=np.asarray(e_st, np.uint8), fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
                 huber_mono=th_mono, huber_stereo=th_stereo,
                 true_R=Rs, true_t=ts, true_points=pts)
+
+
+# ---------------------------------------------------------------- motion-only BA (PoseOptimization)
+def make_pose_problem(seed, n=300, outlier_frac=0.1, stereo_frac=0.0):
+    """One frame for Optimizer::PoseOptimization (reference src/Optimizer.cc:814-1115): n features holding map points,
+    EuRoC pinhole intrinsics, pixel noise by octave, gross outliers, initial pose a few degrees / centimetres off."""
+    rs = np.random.RandomState(5151 + seed)
+    fx, fy, cx, cy = [float(np.float32(v)) for v in (458.654, 457.296, 367.215, 248.375)]
+    bf = float(np.float32(47.90639384423901))
+    R = _rodrigues(rs.normal(0, 0.2, 3))
+    t = rs.normal(0, 0.5, 3)
+    Xc = np.stack([rs.uniform(-4, 4, n), rs.uniform(-2.5, 2.5, n), rs.uniform(2, 14, n)], 1)
+    Xw = (Xc - t) @ R            # R^T (Xc - t)
+    scale2 = 1.2 ** (2 * np.arange(8))
+    octv = rs.randint(0, 8, n)
+    sig = np.sqrt(scale2[octv])
+    u = fx * Xc[:, 0] / Xc[:, 2] + cx + rs.normal(0, 1, n) * sig
+    v = fy * Xc[:, 1] / Xc[:, 2] + cy + rs.normal(0, 1, n) * sig
+    out = rs.uniform(size=n) < outlier_frac
+    u[out] += rs.choice([-40.0, 40.0], out.sum())
+    v[out] += rs.choice([-25.0, 25.0], out.sum())
+    st = (rs.uniform(size=n) < stereo_frac)
+    ur = np.where(st, u - bf / Xc[:, 2] + rs.normal(0, 1, n) * sig, -1.0)
+    dR = _rodrigues(rs.normal(0, np.deg2rad(2.0) / np.sqrt(3), 3))
+    q0 = _quat_from_R(dR @ R).astype(np.float32).astype(np.float64)
+    t0 = (dR @ t + rs.normal(0, 0.05 / np.sqrt(3), 3)).astype(np.float32).astype(np.float64)
+    obs = np.stack([u, v, ur], 1).astype(np.float32).astype(np.float64)
+    return dict(q=q0, t=t0, Xw=np.ascontiguousarray(Xw.astype(np.float32).astype(np.float64)), obs=np.ascontiguousarray(obs),
+                inv_sigma2=(1.0 / scale2[octv]).astype(np.float32).astype(np.float64), stereo=st.astype(np.uint8),
+                fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, huber_mono=float(np.float32(np.sqrt(5.991))),
+                huber_stereo=float(np.float32(np.sqrt(7.815))), true_R=R, true_t=t, is_outlier=out)

@@ -287,3 +287,35 @@ class OracleExtractor:
         out = np.zeros(cap, KP_DTYPE)
         n = self.L.orb_oracle_level_keypoints(self.h, l, _p(out), cap)
         return out[:n].copy()
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p),
+                ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
+def pose_problem_struct(w, cls=PoseProblem):
+    keep = {k: np.ascontiguousarray(w[k]) for k in ("Xw", "obs", "inv_sigma2", "stereo")}
+    pr = cls()
+    for i in range(4):
+        pr.q[i] = float(w["q"][i])
+    for i in range(3):
+        pr.t[i] = float(w["t"][i])
+    pr.n = len(keep["Xw"])
+    pr.Xw, pr.obs, pr.inv_sigma2, pr.stereo = (keep[k].ctypes.data for k in ("Xw", "obs", "inv_sigma2", "stereo"))
+    for k in ("fx", "fy", "cx", "cy", "bf", "huber_mono", "huber_stereo"):
+        setattr(pr, k, float(w[k]))
+    pr._keep = keep
+    return pr
+
+
+def oracle_pose_optimize(orc, w):
+    """Optimizer::PoseOptimization restatement: returns dict(q, t, outlier, n_bad, inliers)."""
+    L = orc.lib
+    L.pose_oracle_optimize.argtypes = [C.POINTER(PoseProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    pr = pose_problem_struct(w)
+    q = np.zeros(4); t = np.zeros(3); outl = np.zeros(max(pr.n, 1), np.uint8); nb = C.c_int()
+    r = L.pose_oracle_optimize(C.byref(pr), _p(q), _p(t), _p(outl), C.byref(nb))
+    return dict(q=q, t=t, outlier=outl[:pr.n], n_bad=nb.value, inliers=r)

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from oracle_api import Oracle, build_oracle  # noqa: E402
+from oracle_api import Oracle, build_oracle, oracle_pose_optimize  # noqa: E402
 
 synth = importlib.import_module("orb_slam3-1_amd.synth")
 sm = importlib.import_module("orb_slam3-1_amd.synth_match")
@@ -36,6 +36,10 @@ def main():
     gr, dF, angF, scale, mp, assign, occ = sm.make_projection_case(1, n=300, n_mp=250)
     n = o.search_by_projection(gr, dF, scale, mp, 3.0, 0.8, assign, occ)
     np.savez_compressed(os.path.join(OUT, "proj_300.npz"), n=n, assign=assign, occupied=occ)
+    for name, kw in (("pose_mono_300", dict(seed=2, n=300, outlier_frac=0.1, stereo_frac=0.0)),
+                     ("pose_stereo_200", dict(seed=3, n=200, outlier_frac=0.15, stereo_frac=0.5))):
+        r = oracle_pose_optimize(o, synth.make_pose_problem(**kw))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), q=r["q"], t=r["t"], outlier=r["outlier"], n_bad=r["n_bad"], inliers=r["inliers"])
     print("golden fixtures written to", OUT)
 
 
