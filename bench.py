@@ -236,6 +236,27 @@ def main():
                           "lba_solve_call_ms_incl_upload": 1e3 * dt_call, "chi2_initial": stats["chi2_initial"], "chi2_final": stats["chi2_final"]}
             sh.close(); solver.close()
 
+            # ---- PoseOptimization leg: one workgroup per frame, a batch is one launch ----
+            pose_ws = [synth.make_pose_problem(i, n=300, outlier_frac=0.1, stereo_frac=0.0) for i in range(64)] * 4
+            ps = pkg.PoseSolver(device=local_rank)
+            prep = ps.prepare(pose_ws)
+            ps.run(prep)
+            t0 = time.perf_counter(); kms = 0.0
+            for _ in range(10):
+                ps.launch(prep); kms += ps.last_kernel_ms()
+            dtp = (time.perf_counter() - t0) / 10
+            prep1 = ps.prepare(pose_ws[:1]); ps.run(prep1)
+            t0 = time.perf_counter(); kms1 = 0.0
+            for _ in range(20):
+                ps.launch(prep1); kms1 += ps.last_kernel_ms()
+            dt1 = (time.perf_counter() - t0) / 20
+            out["pose"] = {"metric": "PoseOptimization frames/s", "value": len(pose_ws) / dtp, "unit": "frames/s", "dtype": "f64",
+                           "workload": "%d frames x 300 mono edges, 10%% gross outliers, 4 rounds x optimize(10); one C call = upload + "
+                                       "one launch (a workgroup per frame) + download" % len(pose_ws),
+                           "ms_per_batch": 1e3 * dtp, "kernel_ms_per_batch": kms / 10,
+                           "single_frame_call_ms": 1e3 * dt1, "single_frame_kernel_ms": kms1 / 20}
+            ps.close()
+
         # ---- CPU baseline leg (N=1 only, rank 0) ----
         if not args.no_cpu and world == 1:
             o, cb = cpu_baseline(synth, host_imgs, match_sets)
@@ -268,6 +289,15 @@ def main():
                 out["lba"]["cpu_baseline"] = {"value": it / dtc, "unit": "iters/s", "cores": 1, "kind": "port",
                                               "sample": "3 solves of the same window, %d iterations" % it}
                 out["lba"]["speedup_vs_cpu_1core"] = out["lba"]["value"] / (it / dtc)
+            if "pose" in out:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from oracle_api import oracle_pose_optimize
+                t0 = time.perf_counter()
+                for wp in pose_ws[:64]:
+                    oracle_pose_optimize(o, wp)
+                dtc = time.perf_counter() - t0
+                out["pose"]["cpu_baseline"] = {"value": 64 / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "64 frames"}
+                out["pose"]["speedup_vs_cpu_1core"] = out["pose"]["value"] / (64 / dtc)
 
     # ---- sharded global BA with one RCCL all-reduce per LM trial (N>1) ----
     if world > 1 and not args.no_lba:

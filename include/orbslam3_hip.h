@@ -292,6 +292,8 @@ typedef struct PoseResult {
     double q[4], t[3];              /* optimised Tcw */
     int32_t inliers;                /* the function's return value; 0 when n < 3 (:998-999) */
     int32_t n_bad;
+    int32_t iterations[4], trials[4];   /* per round of optimize(10): outer iterations and Levenberg trials executed */
+    double chi2[4];                 /* per round: activeRobustChi2 after the last trial */
 } PoseResult;
 
 typedef struct pose_solver pose_solver;
@@ -301,6 +303,8 @@ void pose_destroy(pose_solver* s);
 int  pose_optimize(pose_solver* s, const PoseProblem* problem, PoseResult* result, uint8_t* outlier);
 /* frames are independent: one workgroup each; outlier_out may be NULL or hold NULL entries */
 int  pose_optimize_batch(pose_solver* s, const PoseProblem* problems, int n_problems, PoseResult* results, uint8_t* const* outlier_out);
+/* device time of the kernel of the LAST call (HIP events on the solver's stream), milliseconds */
+float pose_last_kernel_ms(const pose_solver* s);
 
 #ifdef __cplusplus
 }

@@ -813,9 +813,12 @@ struct PoseOpt {
             }
         }
     }
+    int iters_done = 0, trials_done = 0;
+    double last_chi = 0;
     // g2o optimize(iters) with Levenberg on the single pose vertex
     void optimize(int iters)
     {
+        iters_done = 0; trials_done = 0; last_chi = 0;
         int n_active = 0;
         for (int e = 0; e < p->n; e++) n_active += active[e];
         if (n_active == 0) return;
@@ -859,6 +862,7 @@ struct PoseOpt {
                 }
                 qmax++;
             } while (rho < 0 && qmax < 10);
+            iters_done++; trials_done += qmax; last_chi = currentChi;
             if (qmax == 10 || rho == 0) break;
             if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
             if (nBad >= 3) break;
@@ -868,8 +872,10 @@ struct PoseOpt {
 
 }  // namespace
 
-extern "C" int pose_oracle_optimize(const OraclePoseProblem* p, double* q_out, double* t_out, uint8_t* outlier_out, int* n_bad_out)
+extern "C" int pose_oracle_optimize(const OraclePoseProblem* p, double* q_out, double* t_out, uint8_t* outlier_out, int* n_bad_out,
+                                    OraclePoseStats* stats)
 {
+    if (stats) std::memset(stats, 0, sizeof(*stats));
     PoseOpt s;
     s.p = p;
     s.err.assign(3 * (size_t)std::max(p->n, 1), 0.0);
@@ -889,6 +895,7 @@ extern "C" int pose_oracle_optimize(const OraclePoseProblem* p, double* q_out, d
         for (int it = 0; it < 4; it++) {
             s.T = T0;                               // vSE3->setEstimate(pFrame->GetPose()) every round (:1007-1008)
             s.optimize(10);
+            if (stats) { stats->iterations[it] = s.iters_done; stats->trials[it] = s.trials_done; stats->chi2[it] = s.last_chi; }
             nBad = 0;
             for (int e = 0; e < p->n; e++) {
                 if (outlier[e]) s.compute_error(e, s.T);

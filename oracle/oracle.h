@@ -153,7 +153,12 @@ typedef struct OraclePoseProblem {
     double fx, fy, cx, cy, bf;
     double huber_mono, huber_stereo;
 } OraclePoseProblem;
-int   pose_oracle_optimize(const OraclePoseProblem* p, double* q_out, double* t_out, uint8_t* outlier_out, int* n_bad_out);
+typedef struct OraclePoseStats {        /* per round of optimize(10): outer iterations, LM trials, robust chi2 after the last trial */
+    int32_t iterations[4], trials[4];
+    double chi2[4];
+} OraclePoseStats;
+int   pose_oracle_optimize(const OraclePoseProblem* p, double* q_out, double* t_out, uint8_t* outlier_out, int* n_bad_out,
+                           OraclePoseStats* stats /* may be NULL */);
 
 int   lba_oracle_solve(const OracleLbaProblem* p, const volatile uint8_t* stop_flag, int max_iters, double lambda_init,
                        double* poses_q_out, double* poses_t_out, double* points_out,

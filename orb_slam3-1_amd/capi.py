@@ -519,7 +519,8 @@ class PoseProblem(C.Structure):
 
 
 class PoseResult(C.Structure):
-    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("inliers", C.c_int32), ("n_bad", C.c_int32)]
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("inliers", C.c_int32), ("n_bad", C.c_int32),
+                ("iterations", C.c_int32 * 4), ("trials", C.c_int32 * 4), ("chi2", C.c_double * 4)]
 
 
 def _pose_problem(w, pr):
@@ -565,10 +566,23 @@ class PoseSolver:
         ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outl])
         return dict(n=n, prs=prs, keep=keep, outl=outl, ptrs=ptrs, res=(PoseResult * n)())
 
-    def run(self, prep):
+    def launch(self, prep):
+        """the C call alone: upload, one kernel launch, download"""
         _check(lib.pose_optimize_batch(self._h, prep["prs"], prep["n"], prep["res"], prep["ptrs"]))
+
+    def results(self, prep):
         return [dict(q=np.array(r.q[:]), t=np.array(r.t[:]), inliers=r.inliers, n_bad=r.n_bad,
+                     iterations=list(r.iterations), trials=list(r.trials), chi2=list(r.chi2),
                      outlier=prep["outl"][i][:prep["prs"][i].n].copy()) for i, r in enumerate(prep["res"])]
+
+    def run(self, prep):
+        self.launch(prep)
+        return self.results(prep)
+
+    def last_kernel_ms(self):
+        lib.pose_last_kernel_ms.restype = C.c_float
+        lib.pose_last_kernel_ms.argtypes = [C.c_void_p]
+        return float(lib.pose_last_kernel_ms(self._h))
 
     def optimize_batch(self, problems):
         return self.run(self.prepare(problems))

@@ -72,7 +72,7 @@ __device__ __forceinline__ void edge_residual(const Cam& c, const double* Xc, co
         r[1] = obs[1] - (c.fy * Xc[1] / Xc[2] + c.cy);
         r[2] = 0;
     } else {
-        const float invz = 1.0f / (float)Xc[2];          // float quirk (types_six_dof_expmap.cpp:191)
+        const float invz = (float)(1.0 / Xc[2]);         // 1.0f/double rounded to float (types_six_dof_expmap.cpp:191)
         const double u = Xc[0] * (double)invz * c.fx + c.cx;
         const double v = Xc[1] * (double)invz * c.fy + c.cy;
         const double ur = u - (double)((float)c.bf * invz);
@@ -152,7 +152,6 @@ __global__ __launch_bounds__(64) void k_lin_landmarks(Dev d, const double* __res
             const int ip = d.e_pose[e];
             const double* T = poses + 7 * (size_t)ip;
             const int st = d.e_stereo[e];
-            const int D = st ? 3 : 2;
             double Xc[3], Ji[9], Jj[18];
             pose_map(T, X, Xc);
             edge_jacobians(d.cam, T, Xc, st, Ji, Jj);
@@ -165,24 +164,30 @@ __global__ __launch_bounds__(64) void k_lin_landmarks(Dev d, const double* __res
             const double wr = rho1 * w;
             double orr[3];
             for (int q = 0; q < 3; q++) orr[q] = (-(w * r[q])) * rho1;
-            int idx = 0;
-            for (int a = 0; a < 3; a++)
-                for (int c = a; c < 3; c++, idx++) {
-                    double h = 0;
-                    for (int q = 0; q < D; q++) h += Ji[q * 3 + a] * wr * Ji[q * 3 + c];
-                    acc[idx] += h;
-                }
+            // fixed trip counts (row 2 of a mono edge is zero, so its terms add +0) keep Ji/Jj in registers
+#pragma unroll
             for (int a = 0; a < 3; a++) {
+#pragma unroll
+                for (int c = a; c < 3; c++) {
+                    double h = 0;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) h += Ji[q * 3 + a] * wr * Ji[q * 3 + c];
+                    acc[a * 3 - (a * (a - 1)) / 2 + (c - a)] += h;
+                }
                 double sv = 0;
-                for (int q = 0; q < D; q++) sv += Ji[q * 3 + a] * orr[q];
+#pragma unroll
+                for (int q = 0; q < 3; q++) sv += Ji[q * 3 + a] * orr[q];
                 acc[6 + a] += sv;
             }
             if (d.pose_col[ip] >= 0) {
                 double* W = d.W + 18 * (size_t)e;
+#pragma unroll
                 for (int a = 0; a < 6; a++)
+#pragma unroll
                     for (int c = 0; c < 3; c++) {
                         double h = 0;
-                        for (int q = 0; q < D; q++) h += Jj[q * 6 + a] * wr * Ji[q * 3 + c];
+#pragma unroll
+                        for (int q = 0; q < 3; q++) h += Jj[q * 6 + a] * wr * Ji[q * 3 + c];
                         W[a * 3 + c] = h;
                     }
             }
@@ -211,7 +216,6 @@ __global__ __launch_bounds__(256) void k_lin_poses(Dev d, const double* __restri
     for (int k = d.p_off[col] + tid; k < d.p_off[col + 1]; k += 256) {
         const int e = d.p_edge[k];
         const int st = d.e_stereo[e];
-        const int D = st ? 3 : 2;
         double Xc[3], Ji[9], Jj[18];
         pose_map(T, pts + 3 * (size_t)d.e_point[e], Xc);
         edge_jacobians(d.cam, T, Xc, st, Ji, Jj);
@@ -222,16 +226,19 @@ __global__ __launch_bounds__(256) void k_lin_poses(Dev d, const double* __restri
         double rho0, rho1;
         huber(d.cam, st, chi, rho0, rho1);
         const double wr = rho1 * w;
-        int idx = 0;
-        for (int a = 0; a < 6; a++)
-            for (int c = a; c < 6; c++, idx++) {
-                double h = 0;
-                for (int q = 0; q < D; q++) h += Jj[q * 6 + a] * wr * Jj[q * 6 + c];
-                acc[idx] += h;
-            }
+        const double orr[3] = {(-(w * r[0])) * rho1, (-(w * r[1])) * rho1, (-(w * r[2])) * rho1};
+#pragma unroll
         for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int c = a; c < 6; c++) {
+                double h = 0;
+#pragma unroll
+                for (int q = 0; q < 3; q++) h += Jj[q * 6 + a] * wr * Jj[q * 6 + c];
+                acc[a * 6 - (a * (a - 1)) / 2 + (c - a)] += h;
+            }
             double sv = 0;
-            for (int q = 0; q < D; q++) sv += Jj[q * 6 + a] * ((-(w * r[q])) * rho1);
+#pragma unroll
+            for (int q = 0; q < 3; q++) sv += Jj[q * 6 + a] * orr[q];
             acc[21 + a] += sv;
         }
     }

@@ -33,11 +33,27 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R)
     R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
+// RECIP = one reciprocal and multiplications instead of a division per component (<= 1 ulp apart): for code where the
+// call sits on a serial critical path (pose_solver.hip); the default divides exactly like Eigen does.
+template <bool RECIP = false>
 __device__ __forceinline__ void quat_normalize(double* q)       // SE3Quat::normalizeRotation
 {
     if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    if (RECIP) { const double in = 1.0 / n; q[0] *= in; q[1] *= in; q[2] *= in; q[3] *= in; }
+    else { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+}
+
+template <int I>
+__device__ inline void quat_from_R_case(const double* R, double* q)   // compile-time indices: no private-memory array
+{
+    constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+    double t = sqrt(R[I * 3 + I] - R[J * 3 + J] - R[K * 3 + K] + 1.0);
+    q[I] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[K * 3 + J] - R[J * 3 + K]) * t;
+    q[J] = (R[J * 3 + I] + R[I * 3 + J]) * t;
+    q[K] = (R[K * 3 + I] + R[I * 3 + K]) * t;
 }
 
 __device__ inline void quat_from_R(const double* R, double* q)   // Eigen Quaternion(Matrix3d)
@@ -48,23 +64,17 @@ __device__ inline void quat_from_R(const double* R, double* q)   // Eigen Quater
         q[3] = 0.5 * t;
         t = 0.5 / t;
         q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else if (R[8] > (R[4] > R[0] ? R[4] : R[0])) {
+        quat_from_R_case<2>(R, q);
+    } else if (R[4] > R[0]) {
+        quat_from_R_case<1>(R, q);
     } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-        double v[3];
-        v[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+        quat_from_R_case<0>(R, q);
     }
 }
 
 // VertexSE3Expmap::oplusImpl: est <- SE3Quat::exp(update) * est, update = (omega, upsilon)
+template <bool RECIP = false>
 __device__ inline void pose_oplus(const double* T, const double* u, double* out)
 {
     const double om[3] = {u[0], u[1], u[2]};
@@ -77,9 +87,17 @@ __device__ inline void pose_oplus(const double* T, const double* u, double* out)
     if (theta < 0.00001) {
         for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }   // se3quat.h:237-243 quirk
     } else {
-        const double a = sin(theta) / theta;
-        const double b = (1 - cos(theta)) / (theta * theta);
-        const double c = (theta - sin(theta)) / (theta * theta * theta);
+        double sn, cs;
+        sincos(theta, &sn, &cs);                // one argument reduction for both
+        double a, b, c;
+        if (RECIP) {
+            const double it = 1.0 / theta, it2 = it * it;
+            a = sn * it; b = (1 - cs) * it2; c = (theta - sn) * (it2 * it);
+        } else {
+            a = sn / theta;
+            b = (1 - cs) / (theta * theta);
+            c = (theta - sn) / (theta * theta * theta);
+        }
         for (int i = 0; i < 9; i++) {
             const double I = (i % 4 == 0) ? 1.0 : 0.0;
             R[i] = I + a * O[i] + b * O2[i];
@@ -88,7 +106,7 @@ __device__ inline void pose_oplus(const double* T, const double* u, double* out)
     }
     double dq[4], dt[3];
     quat_from_R(R, dq);
-    quat_normalize(dq);
+    quat_normalize<RECIP>(dq);
     for (int i = 0; i < 3; i++) dt[i] = V[i * 3] * u[3] + V[i * 3 + 1] * u[4] + V[i * 3 + 2] * u[5];
     // result = exp * T
     double rt[3];
@@ -98,7 +116,7 @@ __device__ inline void pose_oplus(const double* T, const double* u, double* out)
     out[0] = dq[3] * T[0] + dq[0] * T[3] + dq[1] * T[2] - dq[2] * T[1];
     out[1] = dq[3] * T[1] + dq[1] * T[3] + dq[2] * T[0] - dq[0] * T[2];
     out[2] = dq[3] * T[2] + dq[2] * T[3] + dq[0] * T[1] - dq[1] * T[0];
-    quat_normalize(out);
+    quat_normalize<RECIP>(out);
 }
 
 }  // namespace se3

@@ -296,6 +296,10 @@ class PoseProblem(C.Structure):
                 ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
 
 
+class PoseStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32 * 4), ("trials", C.c_int32 * 4), ("chi2", C.c_double * 4)]
+
+
 def pose_problem_struct(w, cls=PoseProblem):
     keep = {k: np.ascontiguousarray(w[k]) for k in ("Xw", "obs", "inv_sigma2", "stereo")}
     pr = cls()
@@ -314,8 +318,10 @@ def pose_problem_struct(w, cls=PoseProblem):
 def oracle_pose_optimize(orc, w):
     """Optimizer::PoseOptimization restatement: returns dict(q, t, outlier, n_bad, inliers)."""
     L = orc.lib
-    L.pose_oracle_optimize.argtypes = [C.POINTER(PoseProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.pose_oracle_optimize.argtypes = [C.POINTER(PoseProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
     pr = pose_problem_struct(w)
     q = np.zeros(4); t = np.zeros(3); outl = np.zeros(max(pr.n, 1), np.uint8); nb = C.c_int()
-    r = L.pose_oracle_optimize(C.byref(pr), _p(q), _p(t), _p(outl), C.byref(nb))
-    return dict(q=q, t=t, outlier=outl[:pr.n], n_bad=nb.value, inliers=r)
+    st = PoseStats()
+    r = L.pose_oracle_optimize(C.byref(pr), _p(q), _p(t), _p(outl), C.byref(nb), C.byref(st))
+    return dict(q=q, t=t, outlier=outl[:pr.n], n_bad=nb.value, inliers=r,
+                iterations=list(st.iterations), trials=list(st.trials), chi2=list(st.chi2))

@@ -15,6 +15,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def _check(w, r, g):
     np.testing.assert_array_equal(r["outlier"], g["outlier"])
     assert (r["n_bad"], r["inliers"]) == (int(g["n_bad"]), int(g["inliers"]))
+    # (Levenberg trial counts are NOT compared: at convergence the sign of rho is rounding noise on both sides)
     q0 = np.asarray(w["q"]) / np.linalg.norm(w["q"])
     dq = np.abs(np.asarray(g["q"]) - q0).max(); dt = np.abs(np.asarray(g["t"]) - w["t"]).max()
     assert np.abs(r["q"] - g["q"]).max() <= 1e-4 * dq + 1e-12
