@@ -661,4 +661,15 @@ int orbx_debug_introsort(int32_t* count, int32_t* ulx, int32_t* node, int n)
 float orbx_debug_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 void orbx_debug_sincos(float a, float* c, float* s) { sincos_f32(a, c, s); }
 
+#ifdef ORBX_FAST_TIMING
+// reads and clears the cycle sums of k_fast_cells (timing builds only; not part of include/orbslam3_hip.h)
+int orbx_debug_fast_prof(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(d_fast_prof), sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_fast_prof), z, sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    return ORBX_OK;
+}
+#endif
+
 }  // extern "C"

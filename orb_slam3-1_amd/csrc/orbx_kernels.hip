@@ -145,6 +145,12 @@ __device__ __forceinline__ int fast_m(const uint8_t* __restrict__ t, int pitch)
 // pass 4  per-cell fallback to minThFAST only when iniThFAST found nothing (:843); word popcount prefix sums.
 // pass 5  ordered (row-major) compaction: rank = prefix[word] + popcount(lower bits).
 #define ORBX_B(w, j) (((w)[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
+#ifdef ORBX_FAST_TIMING      // section-wise cycle sums over all workgroups (tools/fast_timing.py); never defined in the product build
+__device__ unsigned long long d_fast_prof[8];
+#define ORBX_FTICK(k) if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {      /* 1 workgroup in 64: the atomics must not perturb the run */ const long long t_now = clock64(); atomicAdd(&d_fast_prof[k], (unsigned long long)(t_now - t_prev)); t_prev = t_now; }
+#else
+#define ORBX_FTICK(k)
+#endif
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t frame_stride,
                                                     const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
                                                     int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch, int surv_off, int bits_off,
@@ -176,6 +182,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     const int shift = c.x0 - xa;
     const int row_dw = (tw + 8) >> 2;                   // LDS dwords per tile row (covers the 12-byte windows of pass 1)
 
+#ifdef ORBX_FAST_TIMING
+    long long t_prev = clock64();
+#endif
     if (tid == 0) s_nsurv = 0;
     // tile load: coalesced dword loads (rows are 64-B aligned in HBM), byte-realigned so that LDS column k = image column x0 + k
     for (int i = tid; i < th * row_dw; i += 256) {
@@ -189,6 +198,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     for (int i = tid; i < (ih + 2) * m_pitch / 4; i += 256) ((uint32_t*)mt)[i] = 0;
     for (int i = tid; i < 512; i += 256) bits_ini[i] = 0;       // both masks
     __syncthreads();
+    ORBX_FTICK(0)
 
     // ---- pass 1 ----
     const int ngx = (iw + 3) >> 2;
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         }
     }
     __syncthreads();
+    ORBX_FTICK(1)
     const int nsurv = s_nsurv;
     // ---- pass 2 ----
     for (int i = tid; i < nsurv; i += 256) {
@@ -236,6 +247,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         mt[(y + 1) * m_pitch + x + 1] = (uint8_t)m;
     }
     __syncthreads();
+    ORBX_FTICK(2)
     // ---- pass 3 ----
     for (int i = tid; i < nsurv; i += 256) {
         const int q = surv[i];
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         }
     }
     __syncthreads();
+    ORBX_FTICK(3)
     // ---- pass 4: which threshold, then exclusive prefix of the word popcounts (n_int <= 8192 -> <= 256 words) ----
     const int nwords = (n_int + 31) >> 5;
     const int ini_any = __syncthreads_or(tid < nwords && bits_ini[tid] != 0);
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     wbase[tid] = (uint32_t)(wave_base + incl - my);
     const int total = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
     __syncthreads();
+    ORBX_FTICK(4)
     // ---- pass 5 ----
     uint32_t* out = cand + (size_t)frame * cand_frame_stride + c.slot_off;
     for (int i = tid; i < nsurv; i += 256) {
@@ -285,6 +299,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         }
     }
     if (tid == 0) cell_count[(size_t)frame * n_cells + cell_idx] = min(total, c.slot_cap);
+    ORBX_FTICK(5)
+#ifdef ORBX_FAST_TIMING
+    if (tid == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&d_fast_prof[6], (unsigned long long)nsurv); atomicAdd(&d_fast_prof[7], 1ull); }
+#endif
 }
 #undef ORBX_B
 
