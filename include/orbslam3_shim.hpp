@@ -394,6 +394,53 @@ inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap,
     pMap->IncreaseChangeIndex();
 }
 
+// int Optimizer::PoseOptimization(Frame* pFrame) (src/Optimizer.cc:814-1115), conventional (non-rigid-body) cameras:
+// one PoseProblem edge per feature holding a MapPoint, in feature order (= g2o's addEdge order).
+inline int PoseOptimizationHIP(Frame* pFrame)
+{
+    if (pFrame->mpCamera2) return Optimizer::PoseOptimization(pFrame);              // rigid-body stereo-fisheye rig: not on this path
+    const int N = pFrame->N;
+    std::vector<double> Xw, obs, w;
+    std::vector<uint8_t> stereo;
+    std::vector<int> feat;
+    {
+        std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);                  // :857
+        for (int i = 0; i < N; i++) {
+            MapPoint* pMP = pFrame->mvpMapPoints[i];
+            if (!pMP) continue;
+            pFrame->mvbOutlier[i] = false;                                          // :870, :898
+            const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
+            const float ur = pFrame->mvuRight[i];
+            const Eigen::Vector3d X = pMP->GetWorldPos().cast<double>();
+            Xw.push_back(X.x()); Xw.push_back(X.y()); Xw.push_back(X.z());
+            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(ur < 0 ? -1.0 : (double)ur);
+            w.push_back((double)pFrame->mvInvLevelSigma2[kpUn.octave]);
+            stereo.push_back(ur < 0 ? 0 : 1);
+            feat.push_back(i);
+        }
+    }
+    PoseProblem pr;
+    const Sophus::SE3<float> Tcw = pFrame->GetPose();
+    const Eigen::Quaterniond qd = Tcw.unit_quaternion().cast<double>();
+    const Eigen::Vector3d td = Tcw.translation().cast<double>();
+    pr.q[0] = qd.x(); pr.q[1] = qd.y(); pr.q[2] = qd.z(); pr.q[3] = qd.w();
+    pr.t[0] = td.x(); pr.t[1] = td.y(); pr.t[2] = td.z();
+    pr.n = (int)feat.size(); pr.Xw = Xw.data(); pr.obs = obs.data(); pr.inv_sigma2 = w.data(); pr.stereo = stereo.data();
+    pr.fx = pFrame->fx; pr.fy = pFrame->fy; pr.cx = pFrame->cx; pr.cy = pFrame->cy; pr.bf = pFrame->mbf;
+    const float deltaMono = sqrt(5.991), deltaStereo = sqrt(7.815);                 // :838-839 (through float)
+    pr.huber_mono = deltaMono; pr.huber_stereo = deltaStereo;
+    static thread_local pose_solver* solver = nullptr;
+    if (!solver) orbslam3_hip::check(pose_create(0, &solver));
+    PoseResult res;
+    std::vector<uint8_t> outlier(feat.size() + 1);
+    orbslam3_hip::check(pose_optimize(solver, &pr, &res, outlier.data()));
+    if (pr.n < 3) return 0;                                                         // :998-999 (pose untouched)
+    for (size_t k = 0; k < feat.size(); k++) pFrame->mvbOutlier[feat[k]] = outlier[k] != 0;
+    const Eigen::Quaterniond qo(res.q[3], res.q[0], res.q[1], res.q[2]);
+    pFrame->SetPose(Sophus::SE3f(qo.cast<float>(), Eigen::Vector3d(res.t[0], res.t[1], res.t[2]).cast<float>()));   // :1107-1110
+    return res.inliers;
+}
+
 }  // namespace ORB_SLAM3
 
 #endif  // ORBSLAM3_HIP_WITH_REFERENCE
