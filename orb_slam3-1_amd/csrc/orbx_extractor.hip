@@ -386,9 +386,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
                            (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
     mark();
-    int max_sel_cap = 0;
-    for (const LevelDesc& lv : levels) max_sel_cap = std::max(max_sel_cap, lv.sel_cap);
-    hipLaunchKernelGGL(k_orient_desc, dim3((max_sel_cap + 3) / 4, nlevels, B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
+    hipLaunchKernelGGL(k_orient_desc, dim3((sel_frame_entries + 3) / 4, B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
                        d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p, d_kp_dst.p, sel_frame_entries,
                        o_kps, o_desc, cap, d_lvl_kps.p);
     mark();

@@ -735,42 +735,62 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
                                                      OrbxKeyPoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap,
                                                      OrbxKeyPoint* __restrict__ lvl_kps /* optional: per-level keypoints, level coords */)
 {
-    // grid = (keypoint quads of a level, level, frame): the level is known without a search and its descriptor is one
-    // scalar load; all loads that do not depend on the angle (selection record, output row, 16 IC rows, 4 pattern dwords)
-    // are issued up front so that a wave sees three dependent memory round trips instead of six.
-    const int frame = blockIdx.z, level = blockIdx.y;
-    const int lane = threadIdx.x & 63;
+    // grid = (quads of selection slots, frame).  Both patches a keypoint needs -- the 31x31 disc of the unblurred level (IC_Angle) and the 37x37 window
+    // of the blurred level that the rotated pattern can reach (|coordinate| <= 18 < EDGE_THRESHOLD) -- are fetched up front
+    // with aligned dword loads into a wave-private LDS window, so a wave sees two dependent memory round trips (selection
+    // record, patches) instead of four, and 11 dword requests per lane instead of 24 byte requests.
+    constexpr int kBR = 18, kBW = 10, kPR = 15, kPW = 9;        // blur: 37 rows x 10 dwords; pyr: 31 rows x 9 dwords
+    __shared__ uint32_t s_patch[4][(2 * kBR + 1) * kBW + (2 * kPR + 1) * kPW];
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the selection slots of all levels are one flat range [0, sel_frame_stride): a wave takes slot s and finds its level
+    // from the level offsets (scalar loads), so no workgroup is launched for slots a level does not have
+    const int s_flat = blockIdx.x * 4 + wave;
+    int level = 0;
+    for (int l = 1; l < n_levels; l++) level = (s_flat >= levels[l].sel_off) ? l : level;
     const LevelDesc L = levels[level];
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= L.sel_cap || k >= sel_count[(size_t)frame * n_levels + level]) return;
-    const int slot = L.sel_off + k;
-    const uint32_t e = sel[(size_t)frame * sel_frame_stride + slot];
-    const int row = kp_dst[(size_t)frame * kp_frame_stride + slot];
+    const int k = s_flat - L.sel_off;
+    const bool live = s_flat < sel_frame_stride && k < L.sel_cap && k < sel_count[(size_t)frame * n_levels + level];
+    const int slot = L.sel_off + (live ? k : 0);
+    const uint32_t e = live ? sel[(size_t)frame * sel_frame_stride + slot] : 0u;
+    const int row = live ? kp_dst[(size_t)frame * kp_frame_stride + slot] : -1;
     uint32_t pw[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) pw[q] = ((const uint32_t*)d_pattern)[lane + 64 * q];       // one dword = (x0, y0, x1, y1) as int8
     const int px = (int)key_x(e) + 16, py = (int)key_y(e) + 16;     // level coordinates (:885-886)
+    uint32_t* sb = s_patch[wave];
+    uint32_t* sp = sb + (2 * kBR + 1) * kBW;
+    const int xb = (px - kBR) & ~3, xp = (px - kPR) & ~3;           // dword-aligned window starts (rows are 64-B aligned)
+    if (live) {
+        const uint8_t* bbase = blur + (size_t)frame * frame_stride + L.off + (size_t)(py - kBR) * L.stride + xb;
+        const uint8_t* pbase = pyr + (size_t)frame * frame_stride + L.off + (size_t)(py - kPR) * L.stride + xp;
+        for (int i = lane; i < (2 * kBR + 1) * kBW; i += 64) {
+            const int r = i / kBW, c = i - r * kBW;
+            sb[i] = *(const uint32_t*)(bbase + (size_t)r * L.stride + 4 * c);
+        }
+        for (int i = lane; i < (2 * kPR + 1) * kPW; i += 64) {
+            const int r = i / kPW, c = i - r * kPW;
+            sp[i] = *(const uint32_t*)(pbase + (size_t)r * L.stride + 4 * c);
+        }
+    }
+    __syncthreads();
+    if (!live) return;
 
     // ---- IC_Angle: lanes 0..30 take column u = lane-15 of rows v = 0..15, lanes 32..62 the same column of rows -1..-15
-    const uint8_t* img = pyr + (size_t)frame * frame_stride + L.off + (size_t)py * L.stride + px;
+    const uint8_t* img = (const uint8_t*)sp + kPR * (4 * kPW) + (px - xp);      // patch centre
     const int half = lane >> 5;
     const int u = (lane & 31) - 15, au = u < 0 ? -u : u;
     const unsigned long long kUmax = 0x3689ABCDDEEEFFFFull;     // umax[v] of the radius-15 disc (:453-468), 4 bits each
     int m10 = 0, m01 = 0;
     if ((lane & 31) < 31) {
-        int vals[16];
 #pragma unroll
         for (int vi = 0; vi < 16; vi++) {
             const int v = half ? -(vi + 1) : vi;
             const int av = half ? vi + 1 : vi;
             const bool in = (av <= 15) && (au <= (int)((kUmax >> (4 * (av & 15))) & 15));
-            vals[vi] = in ? (int)img[v * L.stride + u] : 0;
-        }
-#pragma unroll
-        for (int vi = 0; vi < 16; vi++) {
-            const int v = half ? -(vi + 1) : vi;
-            m10 += u * vals[vi];
-            m01 += v * vals[vi];
+            const int val = in ? (int)img[v * (4 * kPW) + u] : 0;
+            m10 += u * val;
+            m01 += v * val;
         }
     }
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
@@ -780,15 +800,15 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
     float a, b;
     sincos_f32(angle * factorPI, &a, &b);
-    const uint8_t* bimg = blur + (size_t)frame * frame_stride + L.off + (size_t)py * L.stride + px;
+    const uint8_t* bimg = (const uint8_t*)sb + kBR * (4 * kBW) + (px - xb);
     unsigned long long w[4];
     int t0s[4], t1s[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float x0 = (float)(signed char)(pw[q] & 0xFF), y0 = (float)(signed char)((pw[q] >> 8) & 0xFF);
         const float x1 = (float)(signed char)((pw[q] >> 16) & 0xFF), y1 = (float)(signed char)(pw[q] >> 24);
-        t0s[q] = bimg[cv_round_f(x0 * b + y0 * a) * L.stride + cv_round_f(x0 * a - y0 * b)];
-        t1s[q] = bimg[cv_round_f(x1 * b + y1 * a) * L.stride + cv_round_f(x1 * a - y1 * b)];
+        t0s[q] = bimg[cv_round_f(x0 * b + y0 * a) * (4 * kBW) + cv_round_f(x0 * a - y0 * b)];
+        t1s[q] = bimg[cv_round_f(x1 * b + y1 * a) * (4 * kBW) + cv_round_f(x1 * a - y1 * b)];
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) w[q] = __ballot(t0s[q] < t1s[q]);
