@@ -188,6 +188,38 @@ int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
                                    float th, int check_orientation,
                                    int32_t* assign, uint8_t* occupied);
 
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, float th,
+ *                                    int ORBdist) (src/ORBmatcher.cc:1889-2010; Tracking::Relocalization).
+ * One entry per pKF->GetMapPointMatches()[i]: valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP) && dist3D inside
+ * [GetMinDistanceInvariance, GetMaxDistanceInvariance]; proj_u/v = mpCamera->project(Tcw*x3Dw) (the image-bounds test
+ * :1917-1920 is done on the device); pred_level = PredictScale(dist3D, &CurrentFrame); kf_angle[i] = pKF->mvKeysUn[i].angle.
+ * occupied[n] (in/out) = CurrentFrame.mvpMapPoints[i2] != NULL; assign[n] as above.  Returns nmatches. */
+int orbm_search_by_projection_kf(orbm_matcher* m, const OrbmFrame* cur,
+                                 int n_pts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                 const int32_t* pred_level, const float* kf_angle, const uint8_t* desc_mp,
+                                 float th, int orb_dist, int check_orientation, int32_t* assign, uint8_t* occupied);
+
+/* int ORBmatcher::SearchByProjection(KeyFrame* pKF, Sim3f& Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>&
+ *     vpMatched, int th, float ratioHamming) (:427-532) and the overload that also records the points' key frames
+ * (:534-646; the caller maps assign[] through vpPointsKFs).  `kf` describes pKF (its grid is the same 64x48 CSR);
+ * valid[i] = the prelude :447-487 passed; occupied[n] (in/out) = vpMatched[idx] != NULL. */
+int orbm_search_by_projection_sim3(orbm_matcher* m, const OrbmFrame* kf,
+                                   int n_pts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                   const int32_t* pred_level, const uint8_t* desc_mp, int th, float ratio_hamming,
+                                   int32_t* assign, uint8_t* occupied);
+
+/* Search core of int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, float th, bool bRight=false)
+ * (:1148-1338, chi2_check = 1) and Fuse(KeyFrame*, Sim3f& Scw, vpPoints, th, vpReplacePoint) (:1340-1455, chi2_check = 0).
+ * The candidate points do not interact, so the device returns, per point, the most similar key point of the window
+ * (best_idx[i] or -1, best_dist[i]); the caller then runs the reference's `if(bestDist<=TH_LOW)` pointer surgery
+ * (Replace / AddObservation / AddMapPoint) in order.  valid[i] = prelude passed (:1176-1239); proj_ur = u - bf*invz;
+ * u_right = pKF->mvuRight, inv_level_sigma2 = pKF->mvInvLevelSigma2 (both may be NULL when chi2_check = 0).
+ * One wave per candidate point: LocalMapping::SearchInNeighbors fuses thousands of points per key frame. */
+int orbm_fuse_search(orbm_matcher* m, const OrbmFrame* kf, const float* u_right, const float* inv_level_sigma2,
+                     int n_pts, const uint8_t* valid, const float* proj_u, const float* proj_v, const float* proj_ur,
+                     const int32_t* pred_level, const uint8_t* desc_mp, float th, int chi2_check,
+                     int32_t* best_idx, int32_t* best_dist);
+
 /* ------------------------------------------------------------------------------------------------
  * Local bundle adjustment -- replaces the numerical core of
  * Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&)

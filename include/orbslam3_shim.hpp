@@ -108,6 +108,7 @@ struct FlatFeatVec {
 #include <list>
 #include <map>
 #include <mutex>
+#include <set>
 #include <opencv2/core/core.hpp>
 
 #include "Frame.h"
@@ -247,6 +248,98 @@ public:
             else if (assign[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint*>(NULL);
         }
         return n;
+    }
+
+    // SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist) (src/ORBmatcher.cc:1889-2010)
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist)
+    {
+        const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+        const Eigen::Vector3f Ow = Tcw.inverse().translation();
+        const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+        const int nP = (int)vpMPs.size(), nF = CurrentFrame.N;
+        std::vector<uint8_t> valid(nP, 0), desc((size_t)nP * 32, 0), occ(nF);
+        std::vector<float> u(nP, 0.f), v(nP, 0.f), ang(nP, 0.f);
+        std::vector<int32_t> lvl(nP, 0), assign(nF, -2);
+        for (int i = 0; i < nP; i++) {
+            MapPoint* pMP = vpMPs[i];
+            if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+            const Eigen::Vector3f x3Dw = pMP->GetWorldPos();                   // :1911-1935, the reference's float expressions
+            const Eigen::Vector3f x3Dc = Tcw * x3Dw;
+            const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
+            const float dist3D = (x3Dw - Ow).norm();
+            if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+            valid[i] = 1; u[i] = uv(0); v[i] = uv(1);                         // the image-bounds test runs on the device
+            lvl[i] = pMP->PredictScale(dist3D, &CurrentFrame); ang[i] = pKF->mvKeysUn[i].angle;
+            const cv::Mat d = pMP->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        OrbmFrame f = frameView(CurrentFrame, occ);
+        for (int i = 0; i < nF; i++) occ[i] = CurrentFrame.mvpMapPoints[i] != NULL;   // :1953 tests the pointer only
+        const int n = orbslam3_hip::check(orbm_search_by_projection_kf(m_, &f, nP, valid.data(), u.data(), v.data(), lvl.data(), ang.data(),
+                                                                        desc.data(), th, ORBdist, mbCheckOrientation, assign.data(), occ.data()));
+        for (int i = 0; i < nF; i++) {
+            if (assign[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[assign[i]];
+            else if (assign[i] == -1) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint*>(NULL);
+        }
+        return n;
+    }
+
+    // Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight = false) (src/ORBmatcher.cc:1148-1338), conventional cameras
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0, const bool bRight = false)
+    {
+        if (bRight || pKF->NLeft != -1) return ORBmatcher(mfNNratio, mbCheckOrientation).Fuse(pKF, vpMapPoints, th, bRight);
+        const Sophus::SE3f Tcw = pKF->GetPose();
+        const Eigen::Vector3f Ow = pKF->GetCameraCenter();
+        const float bf = pKF->mbf;
+        const int nMPs = (int)vpMapPoints.size(), nK = pKF->N;
+        std::vector<uint8_t> valid(nMPs, 0), desc((size_t)nMPs * 32, 0);
+        std::vector<float> u(nMPs, 0.f), v(nMPs, 0.f), ur(nMPs, 0.f);
+        std::vector<int32_t> lvl(nMPs, 0), bestIdx(std::max(nMPs, 1)), bestDist(std::max(nMPs, 1));
+        for (int i = 0; i < nMPs; i++) {                                          // prelude :1176-1239
+            MapPoint* pMP = vpMapPoints[i];
+            if (!pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+            const Eigen::Vector3f p3Dw = pMP->GetWorldPos();
+            const Eigen::Vector3f p3Dc = Tcw * p3Dw;
+            if (p3Dc(2) < 0.0f) continue;
+            const float invz = 1 / p3Dc(2);
+            const Eigen::Vector2f uv = pKF->mpCamera->project(p3Dc);
+            if (!pKF->IsInImage(uv(0), uv(1))) continue;
+            const Eigen::Vector3f PO = p3Dw - Ow;
+            const float dist3D = PO.norm();
+            if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+            if (PO.dot(pMP->GetNormal()) < 0.5 * dist3D) continue;
+            valid[i] = 1; u[i] = uv(0); v[i] = uv(1); ur[i] = uv(0) - bf * invz;
+            lvl[i] = pMP->PredictScale(dist3D, pKF);
+            const cv::Mat d = pMP->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.data, 32);
+        }
+        x_.resize(nK); y_.resize(nK); o_.resize(nK);
+        for (int i = 0; i < nK; i++) { x_[i] = pKF->mvKeysUn[i].pt.x; y_[i] = pKF->mvKeysUn[i].pt.y; o_[i] = pKF->mvKeysUn[i].octave; }
+        OrbmFrame f;
+        f.n = nK; f.x = x_.data(); f.y = y_.data(); f.octave = o_.data(); f.angle = NULL; f.desc = pKF->mDescriptors.data;
+        f.min_x = pKF->mnMinX; f.min_y = pKF->mnMinY; f.max_x = pKF->mnMaxX; f.max_y = pKF->mnMaxY;
+        f.grid_cols = pKF->mnGridCols; f.grid_rows = pKF->mnGridRows;
+        f.scale_factors = pKF->mvScaleFactors.data(); f.n_levels = (int)pKF->mvScaleFactors.size();
+        orbslam3_hip::check(orbm_fuse_search(m_, &f, pKF->mvuRight.data(), pKF->mvInvLevelSigma2.data(), nMPs, valid.data(), u.data(), v.data(),
+                                             ur.data(), lvl.data(), desc.data(), th, 1, bestIdx.data(), bestDist.data()));
+        int nFused = 0;
+        for (int i = 0; i < nMPs; i++) {                                          // :1311-1333, in order
+            if (!valid[i] || bestIdx[i] < 0 || bestDist[i] > 50 /* TH_LOW */) continue;
+            MapPoint* pMP = vpMapPoints[i];
+            if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;    // :1187-1196 see the surgery of earlier iterations (duplicates, Replace)
+            MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                    else pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, bestIdx[i]);
+                pKF->AddMapPoint(pMP, bestIdx[i]);
+            }
+            nFused++;
+        }
+        return nFused;
     }
 
 private:

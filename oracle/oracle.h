@@ -112,6 +112,23 @@ int   orbm_oracle_search_by_projection_last(const OracleFrameGrid* g, const uint
                                             float th, int checkOri,
                                             int32_t* assign, uint8_t* occupied);
 
+/* SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1889-2010), relocalisation. */
+int   orbm_oracle_search_by_projection_kf(const OracleFrameGrid* g, const uint8_t* dF, const float* angF, const float* scale_factors,
+                                          int nPts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                          const int32_t* pred_level, const float* kf_angle, const uint8_t* dMP,
+                                          float th, int ORBdist, int checkOri, int32_t* assign, uint8_t* occupied);
+/* SearchByProjection(KeyFrame*, Sim3f&, vpPoints[, vpPointsKFs], vpMatched[, vpMatchedKF], th, ratioHamming) (:427-646). */
+int   orbm_oracle_search_by_projection_sim3(const OracleFrameGrid* g, const uint8_t* dKF, const float* scale_factors,
+                                            int nPts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                            const int32_t* pred_level, const uint8_t* dMP, int th, float ratioHamming,
+                                            int32_t* assign, uint8_t* occupied);
+/* search core of both ORBmatcher::Fuse overloads (:1148-1338 with the chi2 gate, :1340-1455 without). */
+void  orbm_oracle_fuse_search(const OracleFrameGrid* g, const uint8_t* dKF, const float* scale_factors,
+                              const float* u_right, const float* inv_level_sigma2,
+                              int nPts, const uint8_t* valid, const float* proj_u, const float* proj_v, const float* proj_ur,
+                              const int32_t* pred_level, const uint8_t* dMP, float th, int chi2_check,
+                              int32_t* best_idx, int32_t* best_dist);
+
 void  orbm_oracle_three_maxima(const int* hist_counts, int L, int* ind1, int* ind2, int* ind3); /* :2012-2053 */
 
 /* ---------------- local BA (reference src/Optimizer.cc:1116-1498 + g2o) ---------------- */

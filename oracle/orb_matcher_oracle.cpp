@@ -339,4 +339,140 @@ int orbm_oracle_search_by_projection_last(const OracleFrameGrid* g, const uint8_
     return nmatches;
 }
 
+// SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (:1889-2010),
+// used by Tracking::Relocalization.  The caller flattens pKF->GetMapPointMatches(): valid[i] = pMP && !isBad() &&
+// !sAlreadyFound.count(pMP) && dist3D inside [min,max]DistanceInvariance; (u,v) = project(Tcw*x3Dw); pred_level =
+// PredictScale; kf_angle[i] = pKF->mvKeysUn[i].angle.  occupied[nF]: CurrentFrame.mvpMapPoints[i2] != NULL (in/out).
+int orbm_oracle_search_by_projection_kf(const OracleFrameGrid* g, const uint8_t* dF, const float* angF, const float* scale_factors,
+                                        int nPts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                        const int32_t* pred_level, const float* kf_angle, const uint8_t* dMP,
+                                        float th, int ORBdist, int checkOri, int32_t* assign, uint8_t* occupied)
+{
+    Grid grid(g);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    std::vector<int> idxs;
+    for (int i = 0; i < nPts; i++) {
+        if (!valid[i]) continue;
+        const float u = proj_u[i], v = proj_v[i];
+        if (u < g->min_x || u > g->max_x) continue;                         // :1917-1920
+        if (v < g->min_y || v > g->max_y) continue;
+        const int lvl = pred_level[i];
+        const float radius = th * scale_factors[lvl];                      // :1938
+        grid.in_area(u, v, radius, lvl - 1, lvl + 1, idxs);                  // :1940
+        if (idxs.empty()) continue;
+        const uint8_t* dmp = dMP + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t c = 0; c < idxs.size(); c++) {
+            const int i2 = idxs[c];
+            if (occupied[i2]) continue;                                      // :1953
+            const int dist = hamming256(dmp, dF + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {                                           // :1967
+            assign[bestIdx2] = i;
+            occupied[bestIdx2] = 1;
+            nmatches++;
+            if (checkOri) rotHist[rot_bin(kf_angle[i], angF[bestIdx2])].push_back(bestIdx2);
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                assign[rotHist[i][j]] = -1;                                  // :2003
+                occupied[rotHist[i][j]] = 0;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// SearchByProjection(KeyFrame* pKF, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (:427-532) and its twin with
+// vpPointsKFs / vpMatchedKF (:534-646), loop closing.  The caller does the prelude (:447-487: bad / already found /
+// depth / IsInImage / distance invariance / viewing angle / PredictScale); occupied[nKF] = vpMatched[idx] != NULL.
+int orbm_oracle_search_by_projection_sim3(const OracleFrameGrid* g, const uint8_t* dKF, const float* scale_factors,
+                                          int nPts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                          const int32_t* pred_level, const uint8_t* dMP, int th, float ratioHamming,
+                                          int32_t* assign, uint8_t* occupied)
+{
+    Grid grid(g);
+    int nmatches = 0;
+    std::vector<int> idxs;
+    for (int i = 0; i < nPts; i++) {
+        if (!valid[i]) continue;
+        const int lvl = pred_level[i];
+        const float radius = th * scale_factors[lvl];                      // :489 (int * float)
+        grid.in_area(proj_u[i], proj_v[i], radius, -1, -1, idxs);            // KeyFrame::GetFeaturesInArea: no level filter
+        if (idxs.empty()) continue;
+        const uint8_t* dmp = dMP + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t c = 0; c < idxs.size(); c++) {
+            const int idx = idxs[c];
+            if (occupied[idx]) continue;                                     // :504
+            const int kpLevel = g->octave[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;                // :509
+            const int dist = hamming256(dmp, dKF + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW * ratioHamming) {                             // :522 (int <= float)
+            assign[bestIdx] = i;
+            occupied[bestIdx] = 1;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// Search core of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th, bRight=false) (:1148-1338, chi2_check=1) and of
+// Fuse(KeyFrame*, Sim3f& Scw, vpPoints, th, vpReplacePoint) (:1340-1455, chi2_check=0): for every candidate map point
+// the most similar keypoint in the window.  Points are independent (the pointer surgery that follows -- Replace /
+// AddObservation / AddMapPoint -- never feeds back into the search), so the result is two arrays: best_idx[i] (or -1)
+// and best_dist[i].  The caller does the prelude (:1176-1239) and passes (u, v, ur = u - bf*invz, predicted level).
+void orbm_oracle_fuse_search(const OracleFrameGrid* g, const uint8_t* dKF, const float* scale_factors,
+                             const float* u_right /* mvuRight */, const float* inv_level_sigma2,
+                             int nPts, const uint8_t* valid, const float* proj_u, const float* proj_v, const float* proj_ur,
+                             const int32_t* pred_level, const uint8_t* dMP, float th, int chi2_check,
+                             int32_t* best_idx, int32_t* best_dist)
+{
+    Grid grid(g);
+    std::vector<int> idxs;
+    for (int i = 0; i < nPts; i++) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        if (!valid[i]) continue;
+        const int lvl = pred_level[i];
+        const float u = proj_u[i], v = proj_v[i];
+        const float radius = th * scale_factors[lvl];                      // :1242
+        grid.in_area(u, v, radius, -1, -1, idxs);
+        const uint8_t* dmp = dMP + (size_t)i * 32;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t c = 0; c < idxs.size(); c++) {
+            const int idx = idxs[c];
+            const int kpLevel = g->octave[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;                // :1265
+            if (chi2_check) {
+                const float kpx = g->x[idx], kpy = g->y[idx];
+                if (u_right[idx] >= 0) {                                     // stereo keypoint (:1268-1281)
+                    const float kpr = u_right[idx];
+                    const float ex = u - kpx, ey = v - kpy, er = proj_ur[i] - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kpx, ey = v - kpy;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = hamming256(dmp, dKF + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+    }
+}
+
 }  // extern "C"

@@ -343,6 +343,29 @@ class Matcher:
             self._h, C.byref(f), len(last["u"]), _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last["octave"]),
             _p(last["angle"]), _p(last["desc"]), _p(last["has_obs"]), th, int(self.check_ori), _p(assign), _p(occupied)))
 
+    def SearchByProjection_kf(self, g, dF, angF, scale_factors, pts, th, orb_dist, assign, occupied):
+        """SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (relocalisation)."""
+        f = self._frame(g, dF, scale_factors, angF)
+        return _check(lib.orbm_search_by_projection_kf(
+            self._h, C.byref(f), len(pts["u"]), _p(pts["valid"]), _p(pts["u"]), _p(pts["v"]), _p(pts["level"]),
+            _p(pts["angle"]), _p(pts["desc"]), C.c_float(th), int(orb_dist), int(self.check_ori), _p(assign), _p(occupied)))
+
+    def SearchByProjection_sim3(self, g, dKF, scale_factors, pts, th, ratio_hamming, assign, occupied):
+        """SearchByProjection(KeyFrame* pKF, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (loop closing)."""
+        f = self._frame(g, dKF, scale_factors)
+        return _check(lib.orbm_search_by_projection_sim3(
+            self._h, C.byref(f), len(pts["u"]), _p(pts["valid"]), _p(pts["u"]), _p(pts["v"]), _p(pts["level"]),
+            _p(pts["desc"]), int(th), C.c_float(ratio_hamming), _p(assign), _p(occupied)))
+
+    def FuseSearch(self, g, dKF, scale_factors, u_right, inv_sigma2, pts, th, chi2_check=True):
+        """search core of both ORBmatcher::Fuse overloads: (best_idx, best_dist) per candidate map point"""
+        f = self._frame(g, dKF, scale_factors)
+        n = len(pts["u"])
+        bi = np.full(max(n, 1), -1, np.int32); bd = np.full(max(n, 1), 256, np.int32)
+        _check(lib.orbm_fuse_search(self._h, C.byref(f), _p(u_right), _p(inv_sigma2), n, _p(pts["valid"]), _p(pts["u"]), _p(pts["v"]),
+                                    _p(pts["ur"]), _p(pts["level"]), _p(pts["desc"]), C.c_float(th), int(chi2_check), _p(bi), _p(bd)))
+        return bi[:n], bd[:n]
+
 
 class BowPlan:
     def __init__(self, matcher, sets):

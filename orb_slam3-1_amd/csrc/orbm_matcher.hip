@@ -241,8 +241,10 @@ struct ProjArgs {
     const float* view_cos; const float* depth; const uint8_t* bad;      // M4 only
     const float* angle;         // M5: last frame keypoint angle
     const uint8_t* desc; const uint8_t* has_obs;
-    float th, th_far, nnratio;
-    int32_t far_points, check_ori, last_frame_mode;
+    float th, th_far, nnratio, dist_th;
+    int32_t far_points, check_ori;
+    int32_t last_frame_mode;    // 0: Frame x map points (:43); 1: window around a projected feature, levels l-1..l+1, image-bounds
+                                // check, rotation histogram (:1676 last frame, :1889 key frame); 2: Sim3 key-frame search (:427, :534)
     int32_t* assign; uint8_t* occupied;
     int32_t* log_feat; int32_t* log_bin;     // M5 rotation log, capacity n_pts
     int32_t* n_matches;
@@ -271,18 +273,22 @@ __global__ __launch_bounds__(64) void k_proj(ProjArgs A)
             if (bFactor) r *= A.th;
             r = r * F.scale_factors[lvl];
             minLevel = lvl - 1; maxLevel = lvl;
-        } else {
-            if (x < F.min_x || x > F.max_x) continue;                  // :1711-1714
+        } else if (A.last_frame_mode == 1) {
+            if (x < F.min_x || x > F.max_x) continue;                  // :1711-1714, :1917-1920
             if (y < F.min_y || y > F.max_y) continue;
             const int oct = A.level[i];
             r = A.th * F.scale_factors[oct];
             minLevel = oct - 1; maxLevel = oct + 1;
+        } else {
+            const int lvl = A.level[i];
+            r = A.th * F.scale_factors[lvl];                          // :489
+            minLevel = lvl - 1; maxLevel = lvl;                        // :509 (KeyFrame::GetFeaturesInArea itself does not filter)
         }
         unsigned long long kb, ks;
         search_window(F, s_occ, x, y, r, minLevel, maxLevel, A.desc + (size_t)i * 32, lane, kb, ks);
         if (kb == kNoKey) continue;
         const int bestDist = key_dist(kb), bestIdx = key_idx(kb);
-        if (bestDist > TH_HIGH) continue;
+        if ((float)bestDist > A.dist_th) continue;                    // TH_HIGH (:122, :1844), ORBdist (:1967), TH_LOW*ratioHamming (:522)
         if (!A.last_frame_mode) {
             const int bestDist2 = (ks == kNoKey) ? 256 : key_dist(ks);
             const int bestLevel = F.octave[bestIdx];
@@ -291,8 +297,8 @@ __global__ __launch_bounds__(64) void k_proj(ProjArgs A)
         }
         if (lane == 0) {
             A.assign[bestIdx] = i;
-            s_occ[bestIdx] = A.has_obs[i];
-            if (A.last_frame_mode && A.check_ori) {
+            s_occ[bestIdx] = A.has_obs ? A.has_obs[i] : (uint8_t)1;
+            if (A.last_frame_mode == 1 && A.check_ori) {
                 const int bin = rot_bin(A.angle[i], F.angle[bestIdx]);
                 A.log_feat[nlog] = bestIdx; A.log_bin[nlog] = bin;
                 s_hist[bin]++;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(64) void k_proj(ProjArgs A)
         __syncthreads();        // the occupancy update must be seen by the next point's window search
     }
     __syncthreads();
-    if (A.last_frame_mode && A.check_ori && lane == 0) {
+    if (A.last_frame_mode == 1 && A.check_ori && lane == 0) {
         int i1, i2, i3;
         three_maxima(s_hist, HISTO_LENGTH, i1, i2, i3);
         for (int k = 0; k < nlog; k++) {
@@ -318,6 +324,79 @@ __global__ __launch_bounds__(64) void k_proj(ProjArgs A)
     __syncthreads();
     for (int i = lane; i < F.n; i += 64) A.occupied[i] = s_occ[i];
     if (lane == 0) *A.n_matches = nmatches;
+}
+
+// ---- search core of ORBmatcher::Fuse (src/ORBmatcher.cc:1148-1338 and :1340-1455) ------------------------------
+// The candidate map points are independent of each other (nothing the loop writes feeds back into the search), so this
+// is one wave per map point: 64 lanes walk the cells of the window, the first-minimum in visiting order comes out of the
+// same lexicographic key reduction the sequential searches use.
+struct FuseArgs {
+    ProjFrameDev F;
+    const float* u_right;           // pKF->mvuRight
+    const float* inv_sigma2;        // pKF->mvInvLevelSigma2
+    int32_t n_pts;
+    const uint8_t* valid;
+    const float* u; const float* v; const float* ur;
+    const int32_t* level;
+    const uint8_t* desc;
+    float th;
+    int32_t chi2_check;
+    int32_t* best_idx; int32_t* best_dist;
+};
+
+__global__ __launch_bounds__(256) void k_fuse(FuseArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A.n_pts) return;
+    const ProjFrameDev& F = A.F;
+    unsigned long long k1 = kNoKey;
+    if (A.valid[i]) {
+        const int lvl = A.level[i];
+        const float x = A.u[i], y = A.v[i];
+        const float r = A.th * F.scale_factors[lvl];                  // :1242
+        const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.winv));
+        const int nMaxCellX = min(F.cols - 1, (int)ceilf((x - F.min_x + r) * F.winv));
+        const int nMinCellY = max(0, (int)floorf((y - F.min_y - r) * F.hinv));
+        const int nMaxCellY = min(F.rows - 1, (int)ceilf((y - F.min_y + r) * F.hinv));
+        if (nMinCellX < F.cols && nMaxCellX >= 0 && nMinCellY < F.rows && nMaxCellY >= 0) {
+            const uint8_t* dmp = A.desc + (size_t)i * 32;
+            const int ny = nMaxCellY - nMinCellY + 1, nx = nMaxCellX - nMinCellX + 1;
+            for (int c = lane; c < nx * ny; c += 64) {
+                const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;
+                const int cell = ix * F.rows + iy;
+                const int e0 = F.cell_off[cell], e1 = F.cell_off[cell + 1];
+                for (int e = e0; e < e1; e++) {
+                    const int idx = F.cell_feat[e];
+                    const float kpx = F.x[idx], kpy = F.y[idx];
+                    const float distx = kpx - x, disty = kpy - y;
+                    if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;   // KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:704-748)
+                    const int kpLevel = F.octave[idx];
+                    if (kpLevel < lvl - 1 || kpLevel > lvl) continue;        // :1265
+                    if (A.chi2_check) {
+                        const float kpr = A.u_right[idx];
+                        const float ex = x - kpx, ey = y - kpy;
+                        if (kpr >= 0) {
+                            const float er = A.ur[i] - kpr;
+                            const float e2 = ex * ex + ey * ey + er * er;
+                            if ((double)(e2 * A.inv_sigma2[kpLevel]) > 7.8) continue;     // :1278
+                        } else {
+                            const float e2 = ex * ex + ey * ey;
+                            if ((double)(e2 * A.inv_sigma2[kpLevel]) > 5.99) continue;    // :1289
+                        }
+                    }
+                    const int dist = hamming256(dmp, F.desc + (size_t)idx * 32);
+                    if (dist >= 256) continue;
+                    k1 = min(k1, make_key(dist, c, e - e0, idx));
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) k1 = min(k1, (unsigned long long)__shfl_xor(k1, o));
+    if (lane == 0) {
+        A.best_idx[i] = (k1 == kNoKey) ? -1 : key_idx(k1);
+        A.best_dist[i] = (k1 == kNoKey) ? 256 : key_dist(k1);
+    }
 }
 
 }  // namespace orbm
@@ -493,12 +572,13 @@ static int run_projection(orbm_matcher* m, const OrbmFrame* f, int last_mode, in
                           const float* u, const float* v, const int32_t* level, const float* view_cos, const float* depth,
                           const uint8_t* bad, const float* angle, const uint8_t* desc, const uint8_t* has_obs,
                           float th, int far_points, float th_far, float nnratio, int check_ori,
-                          int32_t* assign, uint8_t* occupied)
+                          int32_t* assign, uint8_t* occupied, float dist_th = (float)orbm::TH_HIGH)
 {
     if (!m) return fail(ORBX_ERR_ARG, "NULL matcher");
-    if (n_pts < 0 || (n_pts > 0 && (!valid || !u || !v || !level || !desc || !has_obs))) return fail(ORBX_ERR_ARG, "NULL point arrays");
+    if (n_pts < 0 || (n_pts > 0 && (!valid || !u || !v || !level || !desc))) return fail(ORBX_ERR_ARG, "NULL point arrays");
+    if (last_mode == 0 && n_pts > 0 && !has_obs) return fail(ORBX_ERR_ARG, "NULL has_obs");
     if (!last_mode && n_pts > 0 && (!view_cos || !depth || !bad)) return fail(ORBX_ERR_ARG, "NULL map point arrays");
-    if (last_mode && check_ori && n_pts > 0 && (!angle || !f->angle)) return fail(ORBX_ERR_ARG, "NULL angle arrays");
+    if (last_mode == 1 && check_ori && n_pts > 0 && (!angle || !f->angle)) return fail(ORBX_ERR_ARG, "NULL angle arrays");
     if (!assign || !occupied) return fail(ORBX_ERR_ARG, "NULL assign/occupied");
     std::vector<int32_t> cell_off, cell_feat;
     float winv, hinv;
@@ -521,7 +601,7 @@ static int run_projection(orbm_matcher* m, const OrbmFrame* f, int last_mode, in
     const size_t olevel = blob.put(level, sizeof(int32_t) * n_pts);
     const size_t ovc = blob.put(view_cos, view_cos ? sizeof(float) * n_pts : 0), odep = blob.put(depth, depth ? sizeof(float) * n_pts : 0);
     const size_t obad = blob.put(bad, bad ? n_pts : 0), oangl = blob.put(angle, angle ? sizeof(float) * n_pts : 0);
-    const size_t odmp = blob.put(desc, (size_t)n_pts * 32), oobs = blob.put(has_obs, n_pts);
+    const size_t odmp = blob.put(desc, (size_t)n_pts * 32), oobs = blob.put(has_obs, has_obs ? n_pts : 0);
     const size_t oassign = blob.put(assign, sizeof(int32_t) * n), oocc = blob.put(occupied, n);
     const size_t ologf = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1)), ologb = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1));
     const size_t onm = blob.reserve(sizeof(int32_t));
@@ -536,7 +616,8 @@ static int run_projection(orbm_matcher* m, const OrbmFrame* f, int last_mode, in
     A.F.n = n; A.F.cols = f->grid_cols; A.F.rows = f->grid_rows;
     A.n_pts = n_pts; A.valid = base + ovalid; A.u = (const float*)(base + ou); A.v = (const float*)(base + ov);
     A.level = (const int32_t*)(base + olevel); A.view_cos = (const float*)(base + ovc); A.depth = (const float*)(base + odep);
-    A.bad = base + obad; A.angle = (const float*)(base + oangl); A.desc = base + odmp; A.has_obs = base + oobs;
+    A.bad = base + obad; A.angle = (const float*)(base + oangl); A.desc = base + odmp; A.has_obs = has_obs ? base + oobs : nullptr;
+    A.dist_th = dist_th;
     A.th = th; A.th_far = th_far; A.nnratio = nnratio; A.far_points = far_points; A.check_ori = check_ori; A.last_frame_mode = last_mode;
     A.assign = (int32_t*)(base + oassign); A.occupied = base + oocc;
     A.log_feat = (int32_t*)(base + ologf); A.log_bin = (int32_t*)(base + ologb); A.n_matches = (int32_t*)(base + onm);
@@ -750,8 +831,79 @@ int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
                                    float th, int check_orientation,
                                    int32_t* assign, uint8_t* occupied)
 {
+    if (n_last > 0 && !mp_has_obs) return fail(ORBX_ERR_ARG, "NULL mp_has_obs");
     return run_projection(m, cur, 1, n_last, last_valid, proj_u, proj_v, last_octave, nullptr, nullptr, nullptr, last_angle,
                           desc_mp, mp_has_obs, th, 0, 0.f, 0.f, check_orientation, assign, occupied);
+}
+
+int orbm_search_by_projection_kf(orbm_matcher* m, const OrbmFrame* cur,
+                                 int n_pts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                 const int32_t* pred_level, const float* kf_angle, const uint8_t* desc_mp,
+                                 float th, int orb_dist, int check_orientation, int32_t* assign, uint8_t* occupied)
+{
+    return run_projection(m, cur, 1, n_pts, valid, proj_u, proj_v, pred_level, nullptr, nullptr, nullptr, kf_angle,
+                          desc_mp, nullptr, th, 0, 0.f, 0.f, check_orientation, assign, occupied, (float)orb_dist);
+}
+
+int orbm_search_by_projection_sim3(orbm_matcher* m, const OrbmFrame* kf,
+                                   int n_pts, const uint8_t* valid, const float* proj_u, const float* proj_v,
+                                   const int32_t* pred_level, const uint8_t* desc_mp, int th, float ratio_hamming,
+                                   int32_t* assign, uint8_t* occupied)
+{
+    return run_projection(m, kf, 2, n_pts, valid, proj_u, proj_v, pred_level, nullptr, nullptr, nullptr, nullptr,
+                          desc_mp, nullptr, (float)th, 0, 0.f, 0.f, 0, assign, occupied, (float)orbm::TH_LOW * ratio_hamming);
+}
+
+int orbm_fuse_search(orbm_matcher* m, const OrbmFrame* kf, const float* u_right, const float* inv_level_sigma2,
+                     int n_pts, const uint8_t* valid, const float* proj_u, const float* proj_v, const float* proj_ur,
+                     const int32_t* pred_level, const uint8_t* desc_mp, float th, int chi2_check,
+                     int32_t* best_idx, int32_t* best_dist)
+{
+    if (!m) return fail(ORBX_ERR_ARG, "NULL matcher");
+    if (n_pts < 0 || (n_pts > 0 && (!valid || !proj_u || !proj_v || !pred_level || !desc_mp || !best_idx || !best_dist)))
+        return fail(ORBX_ERR_ARG, "NULL point arrays");
+    if (chi2_check && (!u_right || !inv_level_sigma2 || (n_pts > 0 && !proj_ur))) return fail(ORBX_ERR_ARG, "NULL stereo / sigma arrays");
+    std::vector<int32_t> cell_off, cell_feat;
+    float winv, hinv;
+    int r = build_grid(kf, cell_off, cell_feat, winv, hinv);
+    if (r) return r;
+    for (int i = 0; i < n_pts; i++)
+        if (valid[i] && (pred_level[i] < 0 || pred_level[i] >= kf->n_levels)) return fail(ORBX_ERR_ARG, "point %d: level %d out of range", i, pred_level[i]);
+    if (n_pts == 0) return ORBX_OK;
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    const int n = kf->n;
+    const size_t ox = blob.put(kf->x, sizeof(float) * n), oy = blob.put(kf->y, sizeof(float) * n);
+    const size_t ooct = blob.put(kf->octave, sizeof(int32_t) * n), odesc = blob.put(kf->desc, (size_t)n * 32);
+    const size_t ocoff = blob.put(cell_off.data(), sizeof(int32_t) * cell_off.size());
+    const size_t ocfeat = blob.put(cell_feat.data(), sizeof(int32_t) * cell_feat.size());
+    const size_t osf = blob.put(kf->scale_factors, sizeof(float) * kf->n_levels);
+    const size_t our = blob.put(u_right, chi2_check ? sizeof(float) * n : 0);
+    const size_t osig = blob.put(inv_level_sigma2, chi2_check ? sizeof(float) * kf->n_levels : 0);
+    const size_t ovalid = blob.put(valid, n_pts), ou = blob.put(proj_u, sizeof(float) * n_pts), ov = blob.put(proj_v, sizeof(float) * n_pts);
+    const size_t opr = blob.put(proj_ur, (chi2_check && proj_ur) ? sizeof(float) * n_pts : 0);
+    const size_t olevel = blob.put(pred_level, sizeof(int32_t) * n_pts), odmp = blob.put(desc_mp, (size_t)n_pts * 32);
+    const size_t obi = blob.reserve(sizeof(int32_t) * n_pts), obd = blob.reserve(sizeof(int32_t) * n_pts);
+    if ((r = m->ensure(m->h_blob.size()))) return r;
+    uint8_t* base = m->d_blob;
+    orbm::FuseArgs A;
+    A.F.x = (const float*)(base + ox); A.F.y = (const float*)(base + oy); A.F.octave = (const int32_t*)(base + ooct);
+    A.F.angle = nullptr; A.F.desc = base + odesc;
+    A.F.cell_off = (const int32_t*)(base + ocoff); A.F.cell_feat = (const int32_t*)(base + ocfeat);
+    A.F.scale_factors = (const float*)(base + osf);
+    A.F.min_x = kf->min_x; A.F.min_y = kf->min_y; A.F.max_x = kf->max_x; A.F.max_y = kf->max_y; A.F.winv = winv; A.F.hinv = hinv;
+    A.F.n = n; A.F.cols = kf->grid_cols; A.F.rows = kf->grid_rows;
+    A.u_right = (const float*)(base + our); A.inv_sigma2 = (const float*)(base + osig);
+    A.n_pts = n_pts; A.valid = base + ovalid; A.u = (const float*)(base + ou); A.v = (const float*)(base + ov); A.ur = (const float*)(base + opr);
+    A.level = (const int32_t*)(base + olevel); A.desc = base + odmp; A.th = th; A.chi2_check = chi2_check;
+    A.best_idx = (int32_t*)(base + obi); A.best_dist = (int32_t*)(base + obd);
+    ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), obi, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(orbm::k_fuse, dim3((n_pts + 3) / 4), dim3(256), 0, m->stream, A);
+    ORBM_HIP(hipGetLastError());
+    ORBM_HIP(hipMemcpyAsync(best_idx, base + obi, sizeof(int32_t) * n_pts, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipMemcpyAsync(best_dist, base + obd, sizeof(int32_t) * n_pts, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
 }
 
 }  // extern "C"

@@ -73,3 +73,35 @@ def make_last_frame_case(seed, n=1000, n_last=900, nlevels=8):
     occupied = np.zeros(n, np.uint8)
     assign = np.full(n, -1, np.int32)
     return g, dF, angF, scale, last, assign, occupied
+
+
+def make_kf_projection_case(seed, n=1000, n_pts=900, nlevels=8):
+    """Inputs of SearchByProjection(Frame& cur, KeyFrame*, sAlreadyFound, th, ORBdist) (reference src/ORBmatcher.cc:1889-2010):
+    the last-frame case with predicted levels, some features of the current frame already holding a map point."""
+    g, dF, angF, scale, last, assign, occupied = make_last_frame_case(seed + 7, n, n_pts, nlevels)
+    rs = np.random.RandomState(4242 + seed)
+    occupied = (rs.uniform(size=n) < 0.15).astype(np.uint8)
+    assign = np.where(occupied > 0, 100000 + np.arange(n), -1).astype(np.int32)
+    pts = dict(u=last["u"], v=last["v"], level=last["octave"], angle=last["angle"], valid=last["valid"], desc=last["desc"])
+    return g, dF, angF, scale, pts, assign, occupied
+
+
+def make_fuse_case(seed, n=1000, n_pts=3000, nlevels=8, stereo_frac=0.4):
+    """Inputs of the search core of ORBmatcher::Fuse (reference src/ORBmatcher.cc:1148-1338 / :1340-1455): a key frame
+    (features, mvuRight, mvInvLevelSigma2) and candidate map points projected near some of its features."""
+    rs = np.random.RandomState(5150 + seed)
+    g, dKF, angKF, scale = make_frame_features(seed + 90, n, nlevels=nlevels)
+    u_right = np.where(rs.uniform(size=n) < stereo_frac, g["x"] - rs.uniform(2, 40, n), -1.0).astype(np.float32)
+    inv_sigma2 = (1.0 / (scale.astype(np.float64) ** 2)).astype(np.float32)
+    tgt = rs.randint(0, n, n_pts)
+    # mostly sub-pixel .. few-pixel reprojection errors so that the chi2 gate (5.99 / 7.8 sigma^2) cuts both ways
+    err = rs.normal(0, 1.0, (n_pts, 3)) * np.where(rs.uniform(size=n_pts) < 0.7, 1.0, 4.0)[:, None]
+    u = g["x"][tgt] + err[:, 0]; v = g["y"][tgt] + err[:, 1]
+    ur = np.where(u_right[tgt] >= 0, u_right[tgt] + err[:, 2], u - rs.uniform(2, 40, n_pts))
+    level = np.clip(g["octave"][tgt] + rs.randint(0, 2, n_pts), 0, nlevels - 1).astype(np.int32)
+    desc = _flip(rs, dKF[tgt], np.where(rs.uniform(size=n_pts) < 0.6, 0.04, 0.25)[:, None])
+    dup = rs.uniform(size=n_pts) < 0.05
+    desc[dup] = dKF[tgt[dup]]
+    pts = dict(u=u.astype(np.float32), v=v.astype(np.float32), ur=ur.astype(np.float32), level=level,
+               valid=(rs.uniform(size=n_pts) < 0.9).astype(np.uint8), desc=np.ascontiguousarray(desc))
+    return g, dKF, scale, u_right, inv_sigma2, pts

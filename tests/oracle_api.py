@@ -148,6 +148,27 @@ class Oracle:
             _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last["octave"]), _p(last["angle"]),
             _p(last["desc"]), _p(last["has_obs"]), th, int(check_ori), _p(assign), _p(occupied))
 
+    def search_by_projection_kf(self, g, dF, angF, scale_factors, pts, th, orb_dist, check_ori, assign, occupied):
+        s = self._grid(g)
+        return self.lib.orbm_oracle_search_by_projection_kf(
+            C.byref(s), _p(dF), _p(angF), _p(scale_factors), len(pts["u"]), _p(pts["valid"]), _p(pts["u"]), _p(pts["v"]),
+            _p(pts["level"]), _p(pts["angle"]), _p(pts["desc"]), C.c_float(th), int(orb_dist), int(check_ori), _p(assign), _p(occupied))
+
+    def search_by_projection_sim3(self, g, dKF, scale_factors, pts, th, ratio_hamming, assign, occupied):
+        s = self._grid(g)
+        return self.lib.orbm_oracle_search_by_projection_sim3(
+            C.byref(s), _p(dKF), _p(scale_factors), len(pts["u"]), _p(pts["valid"]), _p(pts["u"]), _p(pts["v"]),
+            _p(pts["level"]), _p(pts["desc"]), int(th), C.c_float(ratio_hamming), _p(assign), _p(occupied))
+
+    def fuse_search(self, g, dKF, scale_factors, u_right, inv_sigma2, pts, th, chi2_check=True):
+        s = self._grid(g)
+        n = len(pts["u"])
+        bi = np.full(max(n, 1), -1, np.int32); bd = np.full(max(n, 1), 256, np.int32)
+        self.lib.orbm_oracle_fuse_search(C.byref(s), _p(dKF), _p(scale_factors), _p(u_right), _p(inv_sigma2), n, _p(pts["valid"]),
+                                         _p(pts["u"]), _p(pts["v"]), _p(pts["ur"]), _p(pts["level"]), _p(pts["desc"]),
+                                         C.c_float(th), int(chi2_check), _p(bi), _p(bd))
+        return bi[:n], bd[:n]
+
     # ---- LBA
     def lba_solve(self, w, max_iters=10, lambda_init=0.0, stop_flag=None):
         keep = {k: np.ascontiguousarray(w[k]) for k in ("pose_q", "pose_t", "pose_fixed", "points", "edge_point",

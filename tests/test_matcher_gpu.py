@@ -117,3 +117,57 @@ def test_search_by_projection_last_frame(pkg, oracle, sm, seed, th, ori):
     assert n1 == n0 and n0 > 100
     np.testing.assert_array_equal(a1, a0)
     np.testing.assert_array_equal(o1, o0)
+
+
+@pytest.mark.parametrize("seed,th,dist,ori", [(0, 10.0, 100, True), (1, 3.0, 64, True), (2, 10.0, 100, False)])
+def test_search_by_projection_keyframe(pkg, oracle, sm, seed, th, dist, ori):
+    """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1889-2010): relocalisation calls it with
+    (10, 100) and (3, 64) (src/Tracking.cc:3791,3804)."""
+    g, dF, angF, scale, pts, assign, occ = sm.make_kf_projection_case(seed)
+    a0, o0 = assign.copy(), occ.copy()
+    n0 = oracle.search_by_projection_kf(g, dF, angF, scale, pts, th, dist, ori, a0, o0)
+    m = pkg.Matcher(0.9, ori)
+    try:
+        a1, o1 = assign.copy(), occ.copy()
+        n1 = m.SearchByProjection_kf(g, dF, angF, scale, pts, th, dist, a1, o1)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 50
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(o1, o0)
+
+
+@pytest.mark.parametrize("seed,th,ratio", [(0, 8, 1.5), (1, 3, 1.0), (2, 30, 1.0)])
+def test_search_by_projection_sim3(pkg, oracle, sm, seed, th, ratio):
+    """SearchByProjection(KeyFrame*, Sim3f&, vpPoints, vpMatched, th, ratioHamming) (:427-532): loop closing calls it with
+    (8, 1.5), (3..5, 1.0) and (30, 1.0) (src/LoopClosing.cc)."""
+    g, dKF, angKF, scale, pts, assign, occ = sm.make_kf_projection_case(seed + 10)
+    a0, o0 = assign.copy(), occ.copy()
+    n0 = oracle.search_by_projection_sim3(g, dKF, scale, pts, th, ratio, a0, o0)
+    m = pkg.Matcher(0.75, True)
+    try:
+        a1, o1 = assign.copy(), occ.copy()
+        n1 = m.SearchByProjection_sim3(g, dKF, scale, pts, th, ratio, a1, o1)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 50
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(o1, o0)
+
+
+@pytest.mark.parametrize("seed,th,chi2,npts", [(0, 3.0, True, 3000), (1, 3.0, False, 3000), (2, 4.0, True, 1), (3, 2.5, True, 0),
+                                               (4, 3.0, True, 20000)])
+def test_fuse_search(pkg, oracle, sm, seed, th, chi2, npts):
+    """search core of both ORBmatcher::Fuse overloads: best key point per candidate map point, one wave per point"""
+    g, dKF, scale, u_right, inv_s2, pts = sm.make_fuse_case(seed, n_pts=npts)
+    bi0, bd0 = oracle.fuse_search(g, dKF, scale, u_right, inv_s2, pts, th, chi2)
+    m = pkg.Matcher(0.6, True)
+    try:
+        bi1, bd1 = m.FuseSearch(g, dKF, scale, u_right, inv_s2, pts, th, chi2)
+    finally:
+        m.close()
+    np.testing.assert_array_equal(bi1, bi0)
+    np.testing.assert_array_equal(bd1, bd0)
+    if npts >= 3000:
+        assert (bd0 <= 50).sum() > 0.2 * npts          # plenty of fusable points (TH_LOW) ...
+        assert (bi0 < 0).sum() > 0                     # ... and some with an empty window / all candidates gated out
