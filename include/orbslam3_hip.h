@@ -338,6 +338,38 @@ int  pose_optimize_batch(pose_solver* s, const PoseProblem* problems, int n_prob
 /* device time of the kernel of the LAST call (HIP events on the solver's stream), milliseconds */
 float pose_last_kernel_ms(const pose_solver* s);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Vocabulary transform.  Replaces, for FORB descriptors with TF_IDF weights and L1 scoring (what
+ * ORBvoc.txt declares),  void TemplatedVocabulary::transform(const vector<TDescriptor>& features, BowVector& v,
+ * FeatureVector& fv, int levelsup) const  (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1193, per-feature descent
+ * :1216-1259), as called by Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:825-832, src/KeyFrame.cc:253-265) with
+ * levelsup = 4.  The tree is handed over flattened; loading ORBvoc.txt stays with the reference's loader.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct OrbvVocabulary {     /* TemplatedVocabulary::m_nodes (:162-197), node 0 = root */
+    int32_t n_nodes, L;             /* m_nodes.size(), m_L */
+    const int32_t* child_off;       /* [n_nodes + 1]: children of node i are child_id[child_off[i] .. child_off[i+1]) */
+    const uint32_t* child_id;       /* m_nodes[i].children, in order */
+    const uint8_t* desc;            /* n_nodes x 32: m_nodes[i].descriptor */
+    const double* weight;           /* m_nodes[i].weight */
+    const int32_t* word_id;         /* m_nodes[i].word_id for leaves, -1 otherwise */
+} OrbvVocabulary;
+
+typedef struct orbv_vocab orbv_vocab;
+int  orbv_create(int device, const OrbvVocabulary* voc, orbv_vocab** out);     /* uploads the tree (35 MB for ORBvoc) once */
+void orbv_destroy(orbv_vocab* v);
+/* transform(feature, word_id, weight, &nid, levelsup) for n features (host buffers). */
+int  orbv_transform_features(orbv_vocab* v, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node);
+/* transform(features, v, fv, levelsup) of one frame, host buffers of n entries (fv_off: n + 1).  BowVector = ascending
+ * (bow_id, bow_val) pairs, L1-normalised, values bit-identical to the reference's order of double additions; FeatureVector
+ * = CSR with ascending node ids and feature indices in insertion order.  Returns the number of features in fv or <0. */
+int  orbv_transform(orbv_vocab* v, const uint8_t* desc, int n, int levelsup, uint32_t* bow_id, double* bow_val, int32_t* n_bow,
+                    uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int32_t* n_fv_nodes);
+/* Device-resident batch: d_desc is the extractor's descriptor output [batch][cap][32] with d_n[batch] live rows per frame;
+ * every output is a device array with `cap` entries per frame (d_fv_off: cap + 1).  Only enqueues on `stream`. */
+int  orbv_transform_batch_device(orbv_vocab* v, const uint8_t* d_desc, const int32_t* d_n, int batch, int cap, int levelsup,
+                                 uint32_t* d_bow_id, double* d_bow_val, int32_t* d_n_bow,
+                                 uint32_t* d_fv_node, int32_t* d_fv_off, uint32_t* d_fv_feat, int32_t* d_n_fv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

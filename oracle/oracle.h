@@ -159,6 +159,25 @@ typedef struct OracleLbaStats {
     double chi2_trace[16];
 } OracleLbaStats;
 
+/* DBoW2 vocabulary tree, flattened (TemplatedVocabulary::m_nodes, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:162-197):
+ * node 0 is the root; children of node i are child_id[child_off[i] .. child_off[i+1]) in m_nodes[i].children order. */
+typedef struct OracleVocab {
+    int32_t n_nodes, L;             /* m_L: depth levels */
+    const int32_t* child_off;       /* [n_nodes + 1] */
+    const uint32_t* child_id;
+    const uint8_t* desc;            /* n_nodes x 32 (the root's is unused) */
+    const double* weight;           /* node weight (idf for words) */
+    const int32_t* word_id;         /* word id of a leaf, -1 for inner nodes */
+} OracleVocab;
+/* per feature: word id, word weight, node id `levelsup` levels above the leaves (TemplatedVocabulary.h:1216-1259) */
+void  dbow_oracle_transform_features(const OracleVocab* V, const uint8_t* desc, int n, int levelsup,
+                                     uint32_t* word, double* weight, uint32_t* node);
+/* transform(features, BowVector&, FeatureVector&, levelsup), TF_IDF + L1 (:1127-1193): BowVector as ascending (id, value)
+ * pairs, FeatureVector as CSR (ascending node ids; feature indices in insertion order).  Returns the CSR length. */
+int   dbow_oracle_transform(const OracleVocab* V, const uint8_t* desc, int n, int levelsup,
+                            uint32_t* bow_id, double* bow_val, int32_t* n_bow,
+                            uint32_t* fv_node, int32_t* fv_off, uint32_t* fv_feat, int32_t* n_fv_nodes);
+
 /* Optimizer::PoseOptimization (reference src/Optimizer.cc:814-1115): one frame pose, unary reprojection edges. */
 typedef struct OraclePoseProblem {
     double q[4], t[3];              /* frame pose Tcw: qx qy qz qw, t */

@@ -612,3 +612,62 @@ class PoseSolver:
 
     def optimize(self, w):
         return self.optimize_batch([w])[0]
+
+
+class OrbvVocabulary(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("L", C.c_int32), ("child_off", C.c_void_p), ("child_id", C.c_void_p),
+                ("desc", C.c_void_p), ("weight", C.c_void_p), ("word_id", C.c_void_p)]
+
+
+def vocabulary_struct(voc, cls=OrbvVocabulary):
+    keep = [np.ascontiguousarray(voc["child_off"], np.int32), np.ascontiguousarray(voc["child_id"], np.uint32),
+            np.ascontiguousarray(voc["desc"], np.uint8), np.ascontiguousarray(voc["weight"], np.float64),
+            np.ascontiguousarray(voc["word_id"], np.int32)]
+    s = cls(int(voc["n_nodes"]), int(voc["L"]), *[a.ctypes.data for a in keep])
+    s._keep = keep
+    return s
+
+
+class Vocabulary:
+    """DBoW2 TemplatedVocabulary::transform for ORB descriptors (TF_IDF, L1) on a device-resident tree."""
+
+    def __init__(self, voc, device=0):
+        s = vocabulary_struct(voc)
+        h = C.c_void_p()
+        _check(lib.orbv_create(device, C.byref(s), C.byref(h)))
+        self._h = h
+        lib.orbv_destroy.argtypes = [C.c_void_p]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.orbv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transform_features(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        word = np.zeros(max(n, 1), np.uint32); weight = np.zeros(max(n, 1)); node = np.zeros(max(n, 1), np.uint32)
+        _check(lib.orbv_transform_features(self._h, _p(desc), n, int(levelsup), _p(word), _p(weight), _p(node)))
+        return word[:n], weight[:n], node[:n]
+
+    def transform(self, desc, levelsup=4):
+        """returns (bow_id, bow_val), (fv_node, fv_off, fv_feat)"""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        m = max(n, 1)
+        bi = np.zeros(m, np.uint32); bv = np.zeros(m); fn = np.zeros(m, np.uint32); fo = np.zeros(m + 1, np.int32); ff = np.zeros(m, np.uint32)
+        nb, nf = C.c_int32(), C.c_int32()
+        used = _check(lib.orbv_transform(self._h, _p(desc), n, int(levelsup), _p(bi), _p(bv), C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf)))
+        return (bi[:nb.value], bv[:nb.value]), (fn[:nf.value], fo[:nf.value + 1], ff[:used])
+
+    def transform_batch_device(self, d_desc, d_n, batch, cap, levelsup, d_bow_id, d_bow_val, d_n_bow, d_fv_node, d_fv_off, d_fv_feat,
+                               d_n_fv, stream=None):
+        _check(lib.orbv_transform_batch_device(self._h, C.c_void_p(d_desc), C.c_void_p(d_n), int(batch), int(cap), int(levelsup),
+                                               C.c_void_p(d_bow_id), C.c_void_p(d_bow_val), C.c_void_p(d_n_bow), C.c_void_p(d_fv_node),
+                                               C.c_void_p(d_fv_off), C.c_void_p(d_fv_feat), C.c_void_p(d_n_fv), C.c_void_p(stream or 0)))

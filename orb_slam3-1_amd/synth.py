@@ -244,3 +244,70 @@ def make_pose_problem(seed, n=300, outlier_frac=0.1, stereo_frac=0.0):
                 inv_sigma2=(1.0 / scale2[octv]).astype(np.float32).astype(np.float64), stereo=st.astype(np.uint8),
                 fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, huber_mono=float(np.float32(np.sqrt(5.991))),
                 huber_stereo=float(np.float32(np.sqrt(7.815))), true_R=R, true_t=t, is_outlier=out)
+
+
+def make_vocabulary(seed, k=10, L=3, ragged=True, tie_frac=0.05, stop_frac=0.02, shuffle_ids=False):
+    """Synthetic DBoW2 vocabulary tree in the flattened form of include/orbslam3_hip.h (stand-in for ORBvoc.txt: k=10, L=6,
+    which the reference does not ship).  Children are noisy copies of their parent (what hierarchical k-medians produces);
+    `ragged` removes some children and ends some branches early; `tie_frac` duplicates sibling centroids (first-minimum
+    tie-break); `stop_frac` gives some words weight 0 (stopped words are skipped by transform)."""
+    rs = np.random.RandomState(8191 + seed)
+    parents = [0]
+    desc = [np.zeros(32, np.uint8)]
+    depth = [0]
+    children = [[]]
+    frontier = [0]
+    for d in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            if ragged and d >= 2 and rs.uniform() < 0.04:
+                continue                                        # early leaf
+            nc = k if not ragged else int(rs.randint(max(1, k - 3), k + 1))
+            base = np.unpackbits(desc[p])
+            for c in range(nc):
+                fl = (rs.uniform(size=256) < (0.5 if d == 1 else 0.18)).astype(np.uint8)
+                dd = np.packbits(base ^ fl)
+                if c > 0 and rs.uniform() < tie_frac:
+                    dd = desc[children[p][-1]].copy()           # identical to the previous sibling
+                nid = len(desc)
+                desc.append(dd); parents.append(p); depth.append(d); children.append([])
+                children[p].append(nid)
+                nxt.append(nid)
+        frontier = nxt
+    n = len(desc)
+    perm = np.arange(n)
+    if shuffle_ids:                                             # node ids need not be in creation order
+        perm[1:] = 1 + rs.permutation(n - 1)
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)       # new id -> old id
+    child_off = np.zeros(n + 1, np.int32)
+    child_id = []
+    for new in range(n):
+        ch = [perm[c] for c in children[inv[new]]]
+        child_off[new + 1] = child_off[new] + len(ch)
+        child_id += ch
+    desc_a = np.stack(desc)[inv]
+    is_leaf = np.diff(child_off) == 0
+    word_id = np.full(n, -1, np.int32)
+    word_id[is_leaf] = np.arange(int(is_leaf.sum()))
+    weight = np.zeros(n, np.float64)
+    weight[is_leaf] = rs.uniform(0.3, 9.0, int(is_leaf.sum()))
+    stopped = is_leaf & (rs.uniform(size=n) < stop_frac)
+    weight[stopped] = 0.0
+    return dict(n_nodes=n, L=L, k=k, child_off=child_off, child_id=np.asarray(child_id, np.uint32),
+                desc=np.ascontiguousarray(desc_a), weight=weight, word_id=word_id)
+
+
+def make_vocabulary_fast(seed, k=10, L=6):
+    """Complete k-ary tree with random centroids, built with array operations only (the k=10, L=6 ORBvoc shape has
+    1 111 111 nodes / 35 MB of centroids): node ids in breadth-first order, children of node i are k*i+1 .. k*i+k."""
+    rs = np.random.RandomState(1021 + seed)
+    n = (k ** (L + 1) - 1) // (k - 1)
+    n_inner = (k ** L - 1) // (k - 1)
+    child_off = np.minimum(np.arange(n + 1, dtype=np.int64), n_inner) * k
+    child_id = np.arange(1, n, dtype=np.uint32)
+    desc = rs.randint(0, 256, size=(n, 32), dtype=np.uint8)
+    weight = np.zeros(n, np.float64)
+    weight[n_inner:] = rs.uniform(0.3, 9.0, n - n_inner)
+    word_id = np.full(n, -1, np.int32)
+    word_id[n_inner:] = np.arange(n - n_inner)
+    return dict(n_nodes=n, L=L, k=k, child_off=child_off.astype(np.int32), child_id=child_id, desc=desc, weight=weight, word_id=word_id)

@@ -346,3 +346,38 @@ def oracle_pose_optimize(orc, w):
     r = L.pose_oracle_optimize(C.byref(pr), _p(q), _p(t), _p(outl), C.byref(nb), C.byref(st))
     return dict(q=q, t=t, outlier=outl[:pr.n], n_bad=nb.value, inliers=r,
                 iterations=list(st.iterations), trials=list(st.trials), chi2=list(st.chi2))
+
+
+class OracleVocabStruct(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("L", C.c_int32), ("child_off", C.c_void_p), ("child_id", C.c_void_p),
+                ("desc", C.c_void_p), ("weight", C.c_void_p), ("word_id", C.c_void_p)]
+
+
+def _vocab_struct(voc):
+    keep = [np.ascontiguousarray(voc["child_off"], np.int32), np.ascontiguousarray(voc["child_id"], np.uint32),
+            np.ascontiguousarray(voc["desc"], np.uint8), np.ascontiguousarray(voc["weight"], np.float64),
+            np.ascontiguousarray(voc["word_id"], np.int32)]
+    s = OracleVocabStruct(int(voc["n_nodes"]), int(voc["L"]), *[a.ctypes.data for a in keep])
+    s._keep = keep
+    return s
+
+
+def oracle_transform_features(orc, voc, desc, levelsup=4):
+    """TemplatedVocabulary::transform(feature, word_id, weight, &nid, levelsup) for every row of desc."""
+    s = _vocab_struct(voc)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    word = np.zeros(max(n, 1), np.uint32); weight = np.zeros(max(n, 1)); node = np.zeros(max(n, 1), np.uint32)
+    orc.lib.dbow_oracle_transform_features(C.byref(s), _p(desc), n, int(levelsup), _p(word), _p(weight), _p(node))
+    return word[:n], weight[:n], node[:n]
+
+
+def oracle_transform(orc, voc, desc, levelsup=4):
+    """transform(features, BowVector&, FeatureVector&, levelsup): (bow_id, bow_val), (fv_node, fv_off, fv_feat)"""
+    s = _vocab_struct(voc)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc); m = max(n, 1)
+    bi = np.zeros(m, np.uint32); bv = np.zeros(m); fn = np.zeros(m, np.uint32); fo = np.zeros(m + 1, np.int32); ff = np.zeros(m, np.uint32)
+    nb, nf = C.c_int32(), C.c_int32()
+    used = orc.lib.dbow_oracle_transform(C.byref(s), _p(desc), n, int(levelsup), _p(bi), _p(bv), C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf))
+    return (bi[:nb.value], bv[:nb.value]), (fn[:nf.value], fo[:nf.value + 1], ff[:used])
