@@ -291,6 +291,27 @@ def main():
                            "single_frame_call_ms": 1e3 * dt1, "single_frame_kernel_ms": kms1 / 20}
             ps.close()
 
+        # ---- vocabulary transform leg: Frame::ComputeBoW for the batch, on the extractor's output ----
+        if not args.no_lba:
+            voc = synth.make_vocabulary_fast(0, k=10, L=6)           # ORBvoc.txt's shape: 1 111 111 nodes, 35 MB of centroids
+            vv = pkg.Vocabulary(voc, device=local_rank)
+            zb = lambda dt, m: torch.zeros(B * m, dtype=dt, device=dev)
+            v_bi, v_bv, v_nb = zb(torch.int32, cap), zb(torch.float64, cap), torch.zeros(B, dtype=torch.int32, device=dev)
+            v_fn, v_fo, v_ff, v_nf = zb(torch.int32, cap), zb(torch.int32, cap + 1), zb(torch.int32, cap), torch.zeros(B, dtype=torch.int32, device=dev)
+
+            def vstep():
+                vv.transform_batch_device(d_desc.data_ptr(), d_n.data_ptr(), B, cap, 4, v_bi.data_ptr(), v_bv.data_ptr(), v_nb.data_ptr(),
+                                          v_fn.data_ptr(), v_fo.data_ptr(), v_ff.data_ptr(), v_nf.data_ptr(), stream)
+            vstep(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                vstep()
+            torch.cuda.synchronize()
+            dtv = (time.perf_counter() - t0) / 10
+            out["vocab"] = {"metric": "DBoW2 transform frames/s", "value": B / dtv, "unit": "frames/s", "dtype": "u8/f64",
+                            "workload": "%d frames x %.0f descriptors through a k=10, L=6 tree (1.1 M nodes), levelsup 4, BowVector + FeatureVector" % (B, n_kp),
+                            "ms_per_batch": 1e3 * dtv, "words_per_frame": float(v_nb.float().mean().item())}
+
         # ---- CPU baseline leg (N=1 only, rank 0) ----
         if not args.no_cpu and world == 1:
             o, cb = cpu_baseline(synth, host_imgs, match_sets)
@@ -323,6 +344,16 @@ def main():
                 out["lba"]["cpu_baseline"] = {"value": it / dtc, "unit": "iters/s", "cores": 1, "kind": "port",
                                               "sample": "3 solves of the same window, %d iterations" % it}
                 out["lba"]["speedup_vs_cpu_1core"] = out["lba"]["value"] / (it / dtc)
+            if "vocab" in out:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from oracle_api import oracle_transform
+                hd = d_desc.cpu().numpy().reshape(B, cap, 32)
+                t0 = time.perf_counter()
+                for b_ in range(8):
+                    oracle_transform(o, voc, hd[b_, :int(nk[b_])], 4)
+                dtc = (time.perf_counter() - t0) / 8
+                out["vocab"]["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "8 frames"}
+                out["vocab"]["speedup_vs_cpu_1core"] = out["vocab"]["value"] * dtc
             if "pose" in out:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 from oracle_api import oracle_pose_optimize

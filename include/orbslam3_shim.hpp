@@ -487,6 +487,53 @@ inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap,
     pMap->IncreaseChangeIndex();
 }
 
+// void Frame::ComputeBoW() (src/Frame.cc:825-832): mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) on the device.
+// The tree is flattened once per vocabulary (TemplatedVocabulary::m_nodes is protected: reached through a derived type).
+class VocabularyHIP {
+public:
+    explicit VocabularyHIP(const ORBVocabulary& voc)
+    {
+        struct Access : ORBVocabulary { using ORBVocabulary::m_nodes; using ORBVocabulary::m_L; };
+        const Access& a = static_cast<const Access&>(voc);
+        const int n = (int)a.m_nodes.size();
+        std::vector<int32_t> off(n + 1, 0), word(n);
+        std::vector<uint32_t> child;
+        std::vector<uint8_t> desc((size_t)n * 32, 0);
+        std::vector<double> weight(n);
+        for (int i = 0; i < n; i++) {
+            for (DBoW2::NodeId c : a.m_nodes[i].children) child.push_back(c);
+            off[i + 1] = (int32_t)child.size();
+            if (!a.m_nodes[i].descriptor.empty()) std::memcpy(&desc[(size_t)i * 32], a.m_nodes[i].descriptor.data, 32);
+            weight[i] = a.m_nodes[i].weight;
+            word[i] = a.m_nodes[i].isLeaf() ? (int32_t)a.m_nodes[i].word_id : -1;
+        }
+        OrbvVocabulary v;
+        v.n_nodes = n; v.L = a.m_L; v.child_off = off.data(); v.child_id = child.data(); v.desc = desc.data();
+        v.weight = weight.data(); v.word_id = word.data();
+        orbslam3_hip::check(orbv_create(0, &v, &h_));
+    }
+    ~VocabularyHIP() { orbv_destroy(h_); }
+
+    void ComputeBoW(Frame& F) const
+    {
+        if (!F.mBowVec.empty()) return;                                             // :827
+        const int n = F.mDescriptors.rows;
+        std::vector<uint32_t> bi(n + 1), fn(n + 1), ff(n + 1);
+        std::vector<double> bv(n + 1);
+        std::vector<int32_t> fo(n + 2);
+        int32_t nb = 0, nf = 0;
+        orbslam3_hip::check(orbv_transform(h_, F.mDescriptors.data, n, 4, bi.data(), bv.data(), &nb, fn.data(), fo.data(), ff.data(), &nf));
+        DBoW2::BowVector::iterator bit = F.mBowVec.end();
+        for (int k = 0; k < nb; k++) bit = F.mBowVec.insert(F.mBowVec.end(), std::make_pair(bi[k], bv[k]));      // ascending ids: O(1) hinted inserts
+        for (int k = 0; k < nf; k++)
+            F.mFeatVec.insert(F.mFeatVec.end(), std::make_pair(fn[k], std::vector<unsigned int>(ff.begin() + fo[k], ff.begin() + fo[k + 1])));
+        (void)bit;
+    }
+
+private:
+    orbv_vocab* h_ = nullptr;
+};
+
 // int Optimizer::PoseOptimization(Frame* pFrame) (src/Optimizer.cc:814-1115), conventional (non-rigid-body) cameras:
 // one PoseProblem edge per feature holding a MapPoint, in feature order (= g2o's addEdge order).
 inline int PoseOptimizationHIP(Frame* pFrame)
