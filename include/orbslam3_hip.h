@@ -220,6 +220,32 @@ int orbm_fuse_search(orbm_matcher* m, const OrbmFrame* kf, const float* u_right,
                      const int32_t* pred_level, const uint8_t* desc_mp, float th, int chi2_check,
                      int32_t* best_idx, int32_t* best_dist);
 
+/* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pair<size_t,size_t>>& vMatchedPairs,
+ *                                        bool bOnlyStereo, bool bCoarse) (src/ORBmatcher.cc:907-1146; LocalMapping::
+ * CreateNewMapPoints), conventional cameras (mpCamera2 == NULL, NLeft == -1).  Per side: has_mp[i] = GetMapPoint(i) != NULL,
+ * stereo[i] = mvuRight[i] >= 0, x/y/octave/angle = mvKeysUn, fv = mFeatVec.  ep = mpCamera->project(T2w * Cw1) (:918-920);
+ * F12 = K1^-T [t12]x R12 K2^-1, row-major (Pinhole::epipolarConstrain, src/CameraModels/Pinhole.cpp:109-112);
+ * level_sigma2_2 / scale_factors_2 = pKF2->mvLevelSigma2 / mvScaleFactors.  match12[n1] = KF2 feature or -1 (the caller
+ * builds vMatchedPairs from it in index order, :1133-1143).  Returns nmatches.  Every KF1 feature is matched in parallel:
+ * the reference's loop never writes vbMatched2, so there is no order dependence. */
+typedef struct OrbmTriSide {
+    int32_t n;
+    const uint8_t* desc; const uint8_t* has_mp; const uint8_t* stereo;
+    const float* x; const float* y; const int32_t* octave; const float* angle;
+    OrbmFeatVec fv;
+} OrbmTriSide;
+int orbm_search_for_triangulation(orbm_matcher* m, const OrbmTriSide* kf1, const OrbmTriSide* kf2, float ep_x, float ep_y, const float* F12,
+                                  const float* level_sigma2_2, const float* scale_factors_2, int n_levels_2,
+                                  int only_stereo, int coarse, int check_orientation, int32_t* match12);
+
+/* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12,
+ *                                         int windowSize) (:648-763; monocular map initialisation).  prev_x/y = vbPrevMatched;
+ * f2 describes F2 (grid, descriptors, angles).  match12[n1] = vnMatches12; the caller then refreshes vbPrevMatched from
+ * it (:757-760).  Returns nmatches. */
+int orbm_search_for_initialization(orbm_matcher* m, const uint8_t* desc1, int n1, const int32_t* octave1, const float* angle1,
+                                   const float* prev_x, const float* prev_y, const OrbmFrame* f2,
+                                   int window_size, float nnratio, int check_orientation, int32_t* match12);
+
 /* ------------------------------------------------------------------------------------------------
  * Local bundle adjustment -- replaces the numerical core of
  * Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&)

@@ -342,6 +342,66 @@ public:
         return nFused;
     }
 
+    // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:648-763)
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10)
+    {
+        const int n1 = (int)F1.mvKeysUn.size(), n2 = F2.N;
+        std::vector<int32_t> oct1(n1), m12(std::max(n1, 1), -1);
+        std::vector<float> a1(n1), px(n1), py(n1);
+        for (int i = 0; i < n1; i++) { oct1[i] = F1.mvKeysUn[i].octave; a1[i] = F1.mvKeysUn[i].angle; px[i] = vbPrevMatched[i].x; py[i] = vbPrevMatched[i].y; }
+        std::vector<uint8_t> occ(n2);
+        OrbmFrame f2 = frameView(F2, occ);
+        const int n = orbslam3_hip::check(orbm_search_for_initialization(m_, F1.mDescriptors.data, n1, oct1.data(), a1.data(), px.data(), py.data(),
+                                                                          &f2, windowSize, mfNNratio, mbCheckOrientation, m12.data()));
+        vnMatches12.assign(m12.begin(), m12.begin() + n1);
+        for (int i = 0; i < n1; i++) if (vnMatches12[i] >= 0) vbPrevMatched[i] = F2.mvKeysUn[vnMatches12[i]].pt;     // :757-760
+        return n;
+    }
+
+    // SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:907-1146), conventional cameras
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                               const bool bOnlyStereo, const bool bCoarse = false)
+    {
+        if (pKF1->mpCamera2 || pKF2->mpCamera2) return ORBmatcher(mfNNratio, mbCheckOrientation).SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse);
+        const Sophus::SE3f T1w = pKF1->GetPose(), T2w = pKF2->GetPose(), Tw2 = pKF2->GetPoseInverse();
+        const Eigen::Vector3f C2 = T2w * pKF1->GetCameraCenter();
+        const Eigen::Vector2f ep = pKF2->mpCamera->project(C2);
+        const Sophus::SE3f T12 = T1w * Tw2;
+        const Eigen::Matrix3f F12 = pKF1->mpCamera->toK_().transpose().inverse() * Sophus::SO3f::hat(T12.translation()) * T12.rotationMatrix() *
+                                    pKF2->mpCamera->toK_().inverse();                  // Pinhole.cpp:109-112
+        float F[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[r * 3 + c] = F12(r, c);
+        struct Side { std::vector<uint8_t> mp, st; std::vector<float> x, y, a; std::vector<int32_t> o; };
+        Side sd[2];
+        KeyFrame* kf[2] = {pKF1, pKF2};
+        OrbmTriSide ts[2];
+        orbslam3_hip::FlatFeatVec<DBoW2::FeatureVector> fv1(pKF1->mFeatVec), fv2(pKF2->mFeatVec);
+        for (int q = 0; q < 2; q++) {
+            const int n = kf[q]->N;
+            Side& s = sd[q];
+            s.mp.resize(n); s.st.resize(n); s.x.resize(n); s.y.resize(n); s.a.resize(n); s.o.resize(n);
+            for (int i = 0; i < n; i++) {
+                s.mp[i] = kf[q]->GetMapPoint(i) != NULL; s.st[i] = kf[q]->mvuRight[i] >= 0;
+                const cv::KeyPoint& kp = kf[q]->mvKeysUn[i];
+                s.x[i] = kp.pt.x; s.y[i] = kp.pt.y; s.a[i] = kp.angle; s.o[i] = kp.octave;
+            }
+            ts[q].n = n; ts[q].desc = kf[q]->mDescriptors.data; ts[q].has_mp = s.mp.data(); ts[q].stereo = s.st.data();
+            ts[q].x = s.x.data(); ts[q].y = s.y.data(); ts[q].octave = s.o.data(); ts[q].angle = s.a.data();
+            ts[q].fv = q ? fv2.view : fv1.view;
+        }
+        std::vector<int32_t> m12(std::max(pKF1->N, 1), -1);
+        const int n = orbslam3_hip::check(orbm_search_for_triangulation(m_, &ts[0], &ts[1], ep(0), ep(1), F, pKF2->mvLevelSigma2.data(),
+                                                                         pKF2->mvScaleFactors.data(), (int)pKF2->mvScaleFactors.size(),
+                                                                         bOnlyStereo, bCoarse, mbCheckOrientation, m12.data()));
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(n);
+        for (int i = 0; i < pKF1->N; i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));     // :1133-1143
+        return n;
+    }
+
+    // SearchBySim3 (src/ORBmatcher.cc:1457-1674) = the Fuse search core run in both directions (level window, first minimum,
+    // no chi2 gate) with TH_HIGH, followed by the agreement check; see INTEGRATION.md 3b for the flattening of each direction.
+
 private:
     OrbmFrame frameView(Frame& F, std::vector<uint8_t>& occ)
     {

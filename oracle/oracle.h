@@ -129,6 +129,19 @@ void  orbm_oracle_fuse_search(const OracleFrameGrid* g, const uint8_t* dKF, cons
                               const int32_t* pred_level, const uint8_t* dMP, float th, int chi2_check,
                               int32_t* best_idx, int32_t* best_dist);
 
+/* SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:648-763). */
+int   orbm_oracle_search_for_initialization(const uint8_t* d1, int n1, const int32_t* octave1, const float* ang1,
+                                            const float* prev_x, const float* prev_y,
+                                            const OracleFrameGrid* g2, const uint8_t* d2, const float* ang2,
+                                            int windowSize, float nnratio, int checkOri, int32_t* match12);
+/* SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (:907-1146), conventional cameras. */
+int   orbm_oracle_search_for_triangulation(const uint8_t* d1, int n1, const uint8_t* has_mp1, const uint8_t* stereo1,
+                                           const float* x1, const float* y1, const float* ang1, const OracleFeatVec* fv1,
+                                           const uint8_t* d2, int n2, const uint8_t* has_mp2, const uint8_t* stereo2,
+                                           const float* x2, const float* y2, const int32_t* octave2, const float* ang2, const OracleFeatVec* fv2,
+                                           float ep_x, float ep_y, const float* F12, const float* sigma2_2, const float* scale2,
+                                           int bOnlyStereo, int bCoarse, int checkOri, int32_t* match12);
+
 void  orbm_oracle_three_maxima(const int* hist_counts, int L, int* ind1, int* ind2, int* ind3); /* :2012-2053 */
 
 /* ---------------- local BA (reference src/Optimizer.cc:1116-1498 + g2o) ---------------- */

@@ -475,4 +475,135 @@ void orbm_oracle_fuse_search(const OracleFrameGrid* g, const uint8_t* dKF, const
     }
 }
 
+// SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) (:648-763), monocular map
+// initialisation.  g2 = grid of F2; prev = vbPrevMatched (x,y per F1 feature).  Returns nmatches, match12[n1].
+// (The caller refreshes vbPrevMatched from match12 afterwards, :757-760.)
+int orbm_oracle_search_for_initialization(const uint8_t* d1, int n1, const int32_t* octave1, const float* ang1,
+                                          const float* prev_x, const float* prev_y,
+                                          const OracleFrameGrid* g2, const uint8_t* d2, const float* ang2,
+                                          int windowSize, float nnratio, int checkOri, int32_t* match12)
+{
+    Grid grid(g2);
+    const int n2 = g2->n;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    std::vector<int> vMatchedDistance(std::max(n2, 1), INT32_MAX), vnMatches21(std::max(n2, 1), -1), idxs;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = octave1[i1];
+        if (level1 > 0) continue;
+        grid.in_area(prev_x[i1], prev_y[i1], (float)windowSize, level1, level1, idxs);
+        if (idxs.empty()) continue;
+        const uint8_t* dd1 = d1 + (size_t)i1 * 32;
+        int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+        for (size_t c = 0; c < idxs.size(); c++) {
+            const int i2 = idxs[c];
+            const int dist = hamming256(dd1, d2 + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { match12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                match12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) rotHist[rot_bin(ang1[i1], ang2[bestIdx2])].push_back(i1);
+            }
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                const int idx1 = rotHist[i][j];
+                if (match12[idx1] >= 0) { match12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    return nmatches;
+}
+
+// SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (:907-1146), conventional
+// cameras (mpCamera2 == NULL, NLeft == -1).  has_mp = GetMapPoint(idx) != NULL, stereo = mvuRight[idx] >= 0,
+// (ep_x, ep_y) = epipole of KF1's centre in KF2 (:918-920), F12 = K1^-T [t12]x R12 K2^-1 row-major (Pinhole.cpp:109-112),
+// sigma2_2 = pKF2->mvLevelSigma2, scale2 = pKF2->mvScaleFactors.  Note that vbMatched2 is never set by the reference loop.
+int orbm_oracle_search_for_triangulation(const uint8_t* d1, int n1, const uint8_t* has_mp1, const uint8_t* stereo1,
+                                         const float* x1, const float* y1, const float* ang1, const OracleFeatVec* fv1,
+                                         const uint8_t* d2, int n2, const uint8_t* has_mp2, const uint8_t* stereo2,
+                                         const float* x2, const float* y2, const int32_t* octave2, const float* ang2, const OracleFeatVec* fv2,
+                                         float ep_x, float ep_y, const float* F12, const float* sigma2_2, const float* scale2,
+                                         int bOnlyStereo, int bCoarse, int checkOri, int32_t* match12)
+{
+    (void)n2;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int a = 0, b = 0;
+    while (a < fv1->n_nodes && b < fv2->n_nodes) {
+        if (fv1->node_id[a] == fv2->node_id[b]) {
+            for (int e1 = fv1->offset[a]; e1 < fv1->offset[a + 1]; e1++) {
+                const int idx1 = (int)fv1->feat[e1];
+                if (has_mp1[idx1]) continue;
+                const bool bStereo1 = stereo1[idx1] != 0;
+                if (bOnlyStereo && !bStereo1) continue;
+                const uint8_t* dd1 = d1 + (size_t)idx1 * 32;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int e2 = fv2->offset[b]; e2 < fv2->offset[b + 1]; e2++) {
+                    const int idx2 = (int)fv2->feat[e2];
+                    if (has_mp2[idx2]) continue;                       // vbMatched2 stays all-false
+                    const bool bStereo2 = stereo2[idx2] != 0;
+                    if (bOnlyStereo && !bStereo2) continue;
+                    const int dist = hamming256(dd1, d2 + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ep_x - x2[idx2], distey = ep_y - y2[idx2];
+                        if (distex * distex + distey * distey < 100 * scale2[octave2[idx2]]) continue;
+                    }
+                    bool ok = bCoarse != 0;
+                    if (!ok) {                                         // Pinhole::epipolarConstrain (Pinhole.cpp:107-129)
+                        const float la = x1[idx1] * F12[0] + y1[idx1] * F12[3] + F12[6];
+                        const float lb = x1[idx1] * F12[1] + y1[idx1] * F12[4] + F12[7];
+                        const float lc = x1[idx1] * F12[2] + y1[idx1] * F12[5] + F12[8];
+                        const float num = la * x2[idx2] + lb * y2[idx2] + lc;
+                        const float den = la * la + lb * lb;
+                        if (den != 0) {
+                            const float dsqr = num * num / den;
+                            ok = dsqr < 3.84 * sigma2_2[octave2[idx2]];
+                        }
+                    }
+                    if (ok) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) rotHist[rot_bin(ang1[idx1], ang2[bestIdx2])].push_back(idx1);
+                }
+            }
+            a++; b++;
+        } else if (fv1->node_id[a] < fv2->node_id[b]) {
+            a = fv_lower_bound(fv1, a, fv2->node_id[b]);
+        } else {
+            b = fv_lower_bound(fv2, b, fv1->node_id[a]);
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 }  // extern "C"

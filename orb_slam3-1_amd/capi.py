@@ -366,6 +366,33 @@ class Matcher:
                                     _p(pts["ur"]), _p(pts["level"]), _p(pts["desc"]), C.c_float(th), int(chi2_check), _p(bi), _p(bd)))
         return bi[:n], bd[:n]
 
+    class _TriSide(C.Structure):
+        _fields_ = [("n", C.c_int32), ("desc", C.c_void_p), ("has_mp", C.c_void_p), ("stereo", C.c_void_p), ("x", C.c_void_p),
+                    ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("fv", FeatVec)]
+
+    def SearchForTriangulation(self, k1, k2, ep, F12, sigma2_2, scale_2, only_stereo=False, coarse=False):
+        """SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse): returns (nmatches, match12)"""
+        sides = []
+        for k in (k1, k2):
+            fv = _fv(k["fv"])
+            sides.append((self._TriSide(len(k["x"]), k["desc"].ctypes.data, k["has_mp"].ctypes.data, k["stereo"].ctypes.data,
+                                        k["x"].ctypes.data, k["y"].ctypes.data, k["octave"].ctypes.data, k["angle"].ctypes.data, fv), fv))
+        m12 = np.full(max(len(k1["x"]), 1), -1, np.int32)
+        n = _check(lib.orbm_search_for_triangulation(self._h, C.byref(sides[0][0]), C.byref(sides[1][0]), C.c_float(ep[0]), C.c_float(ep[1]),
+                                                     _p(F12), _p(sigma2_2), _p(scale_2), len(scale_2), int(only_stereo), int(coarse),
+                                                     int(self.check_ori), _p(m12)))
+        return n, m12[:len(k1["x"])]
+
+    def SearchForInitialization(self, f1, g2, d2, ang2, scale_factors, window_size=100):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): returns (nmatches, vnMatches12)"""
+        f = self._frame(g2, d2, scale_factors, ang2)
+        n1 = len(f1["octave"])
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        n = _check(lib.orbm_search_for_initialization(self._h, _p(f1["desc"]), n1, _p(f1["octave"]), _p(f1["angle"]), _p(f1["prev_x"]),
+                                                      _p(f1["prev_y"]), C.byref(f), int(window_size), C.c_float(self.nnratio),
+                                                      int(self.check_ori), _p(m12)))
+        return n, m12[:n1]
+
 
 class BowPlan:
     def __init__(self, matcher, sets):

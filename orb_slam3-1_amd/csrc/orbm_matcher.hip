@@ -399,6 +399,194 @@ __global__ __launch_bounds__(256) void k_fuse(FuseArgs A)
     }
 }
 
+// ---- SearchForTriangulation (src/ORBmatcher.cc:907-1146), conventional cameras ---------------------------------
+// The reference never sets vbMatched2, so every KF1 feature is matched on its own: one thread per entry of KF1's feature
+// vector walks the KF2 features of the same vocabulary node in order with the reference's `dist > bestDist -> continue`
+// rule (the last of the equally good candidates that pass the epipolar test wins).
+struct TriArgs {
+    const uint8_t* d1; const uint8_t* mp1; const uint8_t* st1; const float* x1; const float* y1; const float* a1;
+    const uint32_t* node1; const int32_t* off1; const uint32_t* feat1;
+    const uint8_t* d2; const uint8_t* mp2; const uint8_t* st2; const float* x2; const float* y2; const int32_t* oct2; const float* a2;
+    const uint32_t* node2; const int32_t* off2; const uint32_t* feat2;
+    const float* sigma2_2; const float* scale2;
+    float F12[9];
+    float ep_x, ep_y;
+    int32_t n1, nn1, nn2, only_stereo, coarse, check_ori;
+    int32_t* match12; int32_t* n_matches;
+};
+
+__global__ __launch_bounds__(256) void k_triangulation(TriArgs A)
+{
+    __shared__ int s_hist[HISTO_LENGTH];
+    __shared__ int s_keep[3];
+    __shared__ int s_count;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < A.n1; i += 256) A.match12[i] = -1;
+    if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    const int total1 = A.nn1 > 0 ? A.off1[A.nn1] : 0;
+    for (int e1 = tid; e1 < total1; e1 += 256) {
+        int lo = 0, hi = A.nn1;                                 // node of entry e1: last k with off1[k] <= e1
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.off1[mid] <= e1) lo = mid; else hi = mid; }
+        const uint32_t key = A.node1[lo];
+        int l2 = 0, h2 = A.nn2;
+        while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (A.node2[mid] < key) l2 = mid + 1; else h2 = mid; }
+        if (l2 >= A.nn2 || A.node2[l2] != key) continue;
+        const int idx1 = (int)A.feat1[e1];
+        if (A.mp1[idx1]) continue;                              // already a MapPoint (:968)
+        const bool bStereo1 = A.st1[idx1] != 0;
+        if (A.only_stereo && !bStereo1) continue;
+        const uint8_t* dd1 = A.d1 + (size_t)idx1 * 32;
+        const float la = A.x1[idx1] * A.F12[0] + A.y1[idx1] * A.F12[3] + A.F12[6];      // Pinhole::epipolarConstrain (Pinhole.cpp:115-117)
+        const float lb = A.x1[idx1] * A.F12[1] + A.y1[idx1] * A.F12[4] + A.F12[7];
+        const float lc = A.x1[idx1] * A.F12[2] + A.y1[idx1] * A.F12[5] + A.F12[8];
+        const float den = la * la + lb * lb;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int e2 = A.off2[l2]; e2 < A.off2[l2 + 1]; e2++) {
+            const int idx2 = (int)A.feat2[e2];
+            if (A.mp2[idx2]) continue;
+            const bool bStereo2 = A.st2[idx2] != 0;
+            if (A.only_stereo && !bStereo2) continue;
+            const int dist = hamming256(dd1, A.d2 + (size_t)idx2 * 32);
+            if (dist > TH_LOW || dist > bestDist) continue;
+            const float kx = A.x2[idx2], ky = A.y2[idx2];
+            const int o2 = A.oct2[idx2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = A.ep_x - kx, distey = A.ep_y - ky;
+                if (distex * distex + distey * distey < 100 * A.scale2[o2]) continue;  // too close to the epipole (:1011)
+            }
+            bool ok = A.coarse != 0;
+            if (!ok && den != 0) {
+                const float num = la * kx + lb * ky + lc;
+                const float dsqr = num * num / den;
+                ok = (double)dsqr < 3.84 * (double)A.sigma2_2[o2];
+            }
+            if (ok) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+            A.match12[idx1] = bestIdx2;
+            if (A.check_ori) atomicAdd(&s_hist[rot_bin(A.a1[idx1], A.a2[bestIdx2])], 1);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (A.check_ori) {
+        if (tid == 0) { int a, b, c; three_maxima(s_hist, HISTO_LENGTH, a, b, c); s_keep[0] = a; s_keep[1] = b; s_keep[2] = c; }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int i = tid; i < A.n1; i += 256) {
+        const int m = A.match12[i];
+        if (m < 0) continue;
+        if (A.check_ori) {
+            const int bin = rot_bin(A.a1[i], A.a2[m]);
+            if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) { A.match12[i] = -1; continue; }
+        }
+        local++;
+    }
+    if (local) atomicAdd(&s_count, local);
+    __syncthreads();
+    if (tid == 0) *A.n_matches = s_count;
+}
+
+// ---- SearchForInitialization (src/ORBmatcher.cc:648-763) ------------------------------------------------------
+// Sequential by construction (vMatchedDistance / vnMatches21 feed back into later windows): one wave, F1 features in
+// order, 64 lanes over the window; the state lives in LDS.
+struct InitArgs {
+    ProjFrameDev F2;
+    const uint8_t* d1; const int32_t* oct1; const float* a1; const float* prev_x; const float* prev_y;
+    int32_t n1, window, check_ori;
+    float nnratio;
+    int32_t* match12; int32_t* n_matches;
+};
+
+__global__ __launch_bounds__(64) void k_initialization(InitArgs A)
+{
+    extern __shared__ int s_state[];        // [n2] matched distance, [n2] vnMatches21
+    __shared__ int s_hist[HISTO_LENGTH];
+    const int lane = threadIdx.x;
+    const ProjFrameDev& F = A.F2;
+    int* s_mdist = s_state;
+    int* s_m21 = s_state + F.n;
+    for (int i = lane; i < F.n; i += 64) { s_mdist[i] = 0x7FFFFFFF; s_m21[i] = -1; }
+    for (int i = lane; i < A.n1; i += 64) A.match12[i] = -1;
+    if (lane < HISTO_LENGTH) s_hist[lane] = 0;
+    __threadfence_block();
+    __syncthreads();
+    int nmatches = 0;
+    const float r = (float)A.window;
+    for (int i1 = 0; i1 < A.n1; i1++) {
+        if (A.oct1[i1] > 0) continue;                                       // level1 > 0 (:666)
+        const float x = A.prev_x[i1], y = A.prev_y[i1];
+        const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.winv));
+        if (nMinCellX >= F.cols) continue;
+        const int nMaxCellX = min(F.cols - 1, (int)ceilf((x - F.min_x + r) * F.winv));
+        if (nMaxCellX < 0) continue;
+        const int nMinCellY = max(0, (int)floorf((y - F.min_y - r) * F.hinv));
+        if (nMinCellY >= F.rows) continue;
+        const int nMaxCellY = min(F.rows - 1, (int)ceilf((y - F.min_y + r) * F.hinv));
+        if (nMaxCellY < 0) continue;
+        const uint8_t* dd1 = A.d1 + (size_t)i1 * 32;
+        const int ny = nMaxCellY - nMinCellY + 1, nx = nMaxCellX - nMinCellX + 1;
+        unsigned long long k1 = kNoKey, k2 = kNoKey;
+        for (int c = lane; c < nx * ny; c += 64) {
+            const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;
+            const int cell = ix * F.rows + iy;
+            const int e0 = F.cell_off[cell], e1 = F.cell_off[cell + 1];
+            for (int e = e0; e < e1; e++) {
+                const int idx = F.cell_feat[e];
+                if (F.octave[idx] > 0) continue;                           // GetFeaturesInArea(…, level1, level1) with level1 = 0
+                const float distx = F.x[idx] - x, disty = F.y[idx] - y;
+                if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+                const int dist = hamming256(dd1, F.desc + (size_t)idx * 32);
+                if (s_mdist[idx] <= dist) continue;                        // :686
+                top2_insert(k1, k2, make_key(dist, c, e - e0, idx));
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
+            top2_insert(k1, k2, o1);
+            top2_insert(k1, k2, o2);
+        }
+        if (k1 == kNoKey) continue;
+        const int bestDist = key_dist(k1), bestIdx2 = key_idx(k1);
+        if (bestDist > TH_LOW) continue;
+        const float second = (k2 == kNoKey) ? (float)0x7FFFFFFF : (float)key_dist(k2);
+        if (!((float)bestDist < second * A.nnratio)) continue;             // :703
+        const int prev = s_m21[bestIdx2];
+        if (prev >= 0) nmatches--;
+        nmatches++;
+        if (lane == 0) {
+            if (prev >= 0) A.match12[prev] = -1;
+            A.match12[i1] = bestIdx2;
+            s_m21[bestIdx2] = i1;
+            s_mdist[bestIdx2] = bestDist;
+            if (A.check_ori) s_hist[rot_bin(A.a1[i1], F.angle[bestIdx2])]++;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    __syncthreads();
+    if (A.check_ori) {
+        // every F1 feature that ever won a window sits in the histogram, stolen or not (:708-718); only live matches are
+        // cleared afterwards (:741-745).  A stolen feature keeps its bin count, so the bins are rebuilt from the log-free
+        // state: counts come from s_hist (increments above), membership from the angles of the surviving matches.
+        int i1a, i2a, i3a;
+        three_maxima(s_hist, HISTO_LENGTH, i1a, i2a, i3a);
+        int removed = 0;
+        for (int i = lane; i < A.n1; i += 64) {
+            const int m = A.match12[i];
+            if (m < 0) continue;
+            const int bin = rot_bin(A.a1[i], F.angle[m]);
+            if (bin != i1a && bin != i2a && bin != i3a) { A.match12[i] = -1; removed++; }
+        }
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        nmatches -= removed;
+    }
+    if (lane == 0) *A.n_matches = nmatches;
+}
+
 }  // namespace orbm
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -852,6 +1040,109 @@ int orbm_search_by_projection_sim3(orbm_matcher* m, const OrbmFrame* kf,
 {
     return run_projection(m, kf, 2, n_pts, valid, proj_u, proj_v, pred_level, nullptr, nullptr, nullptr, nullptr,
                           desc_mp, nullptr, (float)th, 0, 0.f, 0.f, 0, assign, occupied, (float)orbm::TH_LOW * ratio_hamming);
+}
+
+int orbm_search_for_triangulation(orbm_matcher* m, const OrbmTriSide* k1, const OrbmTriSide* k2, float ep_x, float ep_y, const float* F12,
+                                  const float* level_sigma2_2, const float* scale_factors_2, int n_levels_2,
+                                  int only_stereo, int coarse, int check_orientation, int32_t* match12)
+{
+    if (!m || !k1 || !k2 || !F12 || !level_sigma2_2 || !scale_factors_2 || n_levels_2 < 1) return fail(ORBX_ERR_ARG, "NULL argument");
+    const OrbmTriSide* side[2] = {k1, k2};
+    for (int q = 0; q < 2; q++) {
+        const OrbmTriSide* k = side[q];
+        if (k->n < 0 || (k->n > 0 && (!k->desc || !k->has_mp || !k->stereo || !k->x || !k->y || !k->octave))) return fail(ORBX_ERR_ARG, "NULL key-frame arrays");
+        if (check_orientation && k->n > 0 && !k->angle) return fail(ORBX_ERR_ARG, "NULL angles");
+        const int r = check_fv(&k->fv, k->n, q ? "fv2" : "fv1");
+        if (r) return r;
+        if (!features_unique(&k->fv, k->n)) return fail(ORBX_ERR_ARG, "a feature appears in two vocabulary nodes");
+    }
+    for (int i = 0; i < k2->n; i++)
+        if (k2->octave[i] < 0 || k2->octave[i] >= n_levels_2) return fail(ORBX_ERR_ARG, "octave out of range");
+    if (k1->n > 0 && !match12) return fail(ORBX_ERR_ARG, "NULL match12");
+    if (k1->n == 0) return 0;
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    size_t o[2][10];
+    for (int q = 0; q < 2; q++) {
+        const OrbmTriSide* k = side[q];
+        const int n = k->n, nn = k->fv.n_nodes, tot = nn > 0 ? k->fv.offset[nn] : 0;
+        o[q][0] = blob.put(k->desc, (size_t)n * 32); o[q][1] = blob.put(k->has_mp, n); o[q][2] = blob.put(k->stereo, n);
+        o[q][3] = blob.put(k->x, sizeof(float) * n); o[q][4] = blob.put(k->y, sizeof(float) * n);
+        o[q][5] = blob.put(k->octave, sizeof(int32_t) * n); o[q][6] = blob.put(k->angle, k->angle ? sizeof(float) * n : 0);
+        o[q][7] = blob.put(k->fv.node_id, sizeof(uint32_t) * nn); o[q][8] = blob.put(k->fv.offset, sizeof(int32_t) * (nn + 1));
+        o[q][9] = blob.put(k->fv.feat, sizeof(uint32_t) * tot);
+    }
+    const size_t osig = blob.put(level_sigma2_2, sizeof(float) * n_levels_2), osc = blob.put(scale_factors_2, sizeof(float) * n_levels_2);
+    const size_t in_bytes = m->h_blob.size();
+    const size_t omatch = blob.reserve(sizeof(int32_t) * k1->n), onm = blob.reserve(sizeof(int32_t));
+    int r = m->ensure(m->h_blob.size());
+    if (r) return r;
+    uint8_t* b = m->d_blob;
+    orbm::TriArgs A;
+    A.d1 = b + o[0][0]; A.mp1 = b + o[0][1]; A.st1 = b + o[0][2]; A.x1 = (const float*)(b + o[0][3]); A.y1 = (const float*)(b + o[0][4]);
+    A.a1 = (const float*)(b + o[0][6]); A.node1 = (const uint32_t*)(b + o[0][7]); A.off1 = (const int32_t*)(b + o[0][8]); A.feat1 = (const uint32_t*)(b + o[0][9]);
+    A.d2 = b + o[1][0]; A.mp2 = b + o[1][1]; A.st2 = b + o[1][2]; A.x2 = (const float*)(b + o[1][3]); A.y2 = (const float*)(b + o[1][4]);
+    A.oct2 = (const int32_t*)(b + o[1][5]); A.a2 = (const float*)(b + o[1][6]);
+    A.node2 = (const uint32_t*)(b + o[1][7]); A.off2 = (const int32_t*)(b + o[1][8]); A.feat2 = (const uint32_t*)(b + o[1][9]);
+    A.sigma2_2 = (const float*)(b + osig); A.scale2 = (const float*)(b + osc);
+    for (int i = 0; i < 9; i++) A.F12[i] = F12[i];
+    A.ep_x = ep_x; A.ep_y = ep_y;
+    A.n1 = k1->n; A.nn1 = k1->fv.n_nodes; A.nn2 = k2->fv.n_nodes; A.only_stereo = only_stereo; A.coarse = coarse; A.check_ori = check_orientation;
+    A.match12 = (int32_t*)(b + omatch); A.n_matches = (int32_t*)(b + onm);
+    ORBM_HIP(hipMemcpyAsync(b, m->h_blob.data(), in_bytes, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(orbm::k_triangulation, dim3(1), dim3(256), 0, m->stream, A);
+    ORBM_HIP(hipGetLastError());
+    int nm = 0;
+    ORBM_HIP(hipMemcpyAsync(match12, b + omatch, sizeof(int32_t) * k1->n, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipMemcpyAsync(&nm, b + onm, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    return nm;
+}
+
+int orbm_search_for_initialization(orbm_matcher* m, const uint8_t* desc1, int n1, const int32_t* octave1, const float* angle1,
+                                   const float* prev_x, const float* prev_y, const OrbmFrame* f2,
+                                   int window_size, float nnratio, int check_orientation, int32_t* match12)
+{
+    if (!m || !f2) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (n1 < 0 || (n1 > 0 && (!desc1 || !octave1 || !prev_x || !prev_y || !match12))) return fail(ORBX_ERR_ARG, "NULL F1 arrays");
+    if (check_orientation && ((n1 > 0 && !angle1) || (f2->n > 0 && !f2->angle))) return fail(ORBX_ERR_ARG, "NULL angles");
+    std::vector<int32_t> cell_off, cell_feat;
+    float winv, hinv;
+    int r = build_grid(f2, cell_off, cell_feat, winv, hinv);
+    if (r) return r;
+    if (n1 == 0) return 0;
+    const int n = f2->n;
+    if ((size_t)n * 8 + 256 > 150 * 1024) return fail(ORBX_ERR_ARG, "F2 with %d features exceeds the LDS state", n);
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    const size_t ox = blob.put(f2->x, sizeof(float) * n), oy = blob.put(f2->y, sizeof(float) * n);
+    const size_t ooct = blob.put(f2->octave, sizeof(int32_t) * n), oang = blob.put(f2->angle, f2->angle ? sizeof(float) * n : 0);
+    const size_t odesc = blob.put(f2->desc, (size_t)n * 32);
+    const size_t ocoff = blob.put(cell_off.data(), sizeof(int32_t) * cell_off.size()), ocfeat = blob.put(cell_feat.data(), sizeof(int32_t) * cell_feat.size());
+    const size_t od1 = blob.put(desc1, (size_t)n1 * 32), oo1 = blob.put(octave1, sizeof(int32_t) * n1), oa1 = blob.put(angle1, angle1 ? sizeof(float) * n1 : 0);
+    const size_t opx = blob.put(prev_x, sizeof(float) * n1), opy = blob.put(prev_y, sizeof(float) * n1);
+    const size_t in_bytes = m->h_blob.size();
+    const size_t omatch = blob.reserve(sizeof(int32_t) * n1), onm = blob.reserve(sizeof(int32_t));
+    if ((r = m->ensure(m->h_blob.size()))) return r;
+    uint8_t* b = m->d_blob;
+    orbm::InitArgs A;
+    A.F2.x = (const float*)(b + ox); A.F2.y = (const float*)(b + oy); A.F2.octave = (const int32_t*)(b + ooct); A.F2.angle = (const float*)(b + oang);
+    A.F2.desc = b + odesc; A.F2.cell_off = (const int32_t*)(b + ocoff); A.F2.cell_feat = (const int32_t*)(b + ocfeat); A.F2.scale_factors = nullptr;
+    A.F2.min_x = f2->min_x; A.F2.min_y = f2->min_y; A.F2.max_x = f2->max_x; A.F2.max_y = f2->max_y; A.F2.winv = winv; A.F2.hinv = hinv;
+    A.F2.n = n; A.F2.cols = f2->grid_cols; A.F2.rows = f2->grid_rows;
+    A.d1 = b + od1; A.oct1 = (const int32_t*)(b + oo1); A.a1 = (const float*)(b + oa1); A.prev_x = (const float*)(b + opx); A.prev_y = (const float*)(b + opy);
+    A.n1 = n1; A.window = window_size; A.check_ori = check_orientation; A.nnratio = nnratio;
+    A.match12 = (int32_t*)(b + omatch); A.n_matches = (int32_t*)(b + onm);
+    const size_t lds = std::max((size_t)n * 8, (size_t)64);
+    ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_initialization, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORBM_HIP(hipMemcpyAsync(b, m->h_blob.data(), in_bytes, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(orbm::k_initialization, dim3(1), dim3(64), lds, m->stream, A);
+    ORBM_HIP(hipGetLastError());
+    int nm = 0;
+    ORBM_HIP(hipMemcpyAsync(match12, b + omatch, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipMemcpyAsync(&nm, b + onm, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    return nm;
 }
 
 int orbm_fuse_search(orbm_matcher* m, const OrbmFrame* kf, const float* u_right, const float* inv_level_sigma2,

@@ -105,3 +105,47 @@ def make_fuse_case(seed, n=1000, n_pts=3000, nlevels=8, stereo_frac=0.4):
     pts = dict(u=u.astype(np.float32), v=v.astype(np.float32), ur=ur.astype(np.float32), level=level,
                valid=(rs.uniform(size=n_pts) < 0.9).astype(np.uint8), desc=np.ascontiguousarray(desc))
     return g, dKF, scale, u_right, inv_sigma2, pts
+
+
+def make_triangulation_case(seed, n=1000, nlevels=8):
+    """Inputs of ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:907-1146): two key frames whose unmatched
+    features share vocabulary nodes; a sideways-translation fundamental matrix (epipolar lines = image rows) so that the
+    3.84 sigma^2 gate cuts both ways; an epipole inside the image; some features already hold map points."""
+    from . import synth
+    rs = np.random.RandomState(6007 + seed)
+    tree = synth.make_tree(seed)
+    g1, d1, a1, scale = make_frame_features(seed + 200, n, nlevels=nlevels, cluster=False)
+    perm = rs.permutation(n)
+    d2 = _flip(rs, d1[perm], np.where(rs.uniform(size=n) < 0.6, 0.03, 0.3)[:, None])
+    x2 = (g1["x"][perm] - rs.uniform(5, 60, n)).astype(np.float32)
+    y2 = (g1["y"][perm] + rs.normal(0, 1.2, n) * scale[g1["octave"][perm]]).astype(np.float32)
+    oct2 = np.clip(g1["octave"][perm] + rs.randint(-1, 2, n), 0, nlevels - 1).astype(np.int32)
+    a2 = np.mod(a1[perm] + np.where(rs.uniform(size=n) < 0.8, rs.normal(10, 3, n), rs.uniform(0, 360, n)), 360).astype(np.float32)
+    side = []
+    for d, x, y, o, a in ((d1, g1["x"], g1["y"], g1["octave"], a1), (d2, x2, y2, oct2, a2)):
+        nodes, off, feat = synth.feature_vector(synth.assign_nodes(d, tree))
+        side.append(dict(desc=np.ascontiguousarray(d), x=np.ascontiguousarray(x), y=np.ascontiguousarray(y), octave=np.ascontiguousarray(o),
+                         angle=np.ascontiguousarray(a), has_mp=(rs.uniform(size=n) < 0.3).astype(np.uint8),
+                         stereo=(rs.uniform(size=n) < 0.4).astype(np.uint8), fv=(nodes, off, feat)))
+    F12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32) * np.float32(0.7)
+    sigma2 = (scale.astype(np.float64) ** 2).astype(np.float32)
+    return side[0], side[1], (np.float32(300.0), np.float32(240.0)), F12, sigma2, scale
+
+
+def make_initialization_case(seed, n=2000, nlevels=8):
+    """Inputs of ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:648-763): F2 = F1 moved by a few pixels,
+    clustered so that several F1 features compete for (and steal) the same F2 feature."""
+    rs = np.random.RandomState(7331 + seed)
+    g1, d1, a1, scale = make_frame_features(seed + 300, n, nlevels=nlevels, cluster=True)
+    oct1 = np.where(rs.uniform(size=n) < 0.6, 0, g1["octave"]).astype(np.int32)
+    perm = rs.permutation(n)
+    g2 = dict(g1)
+    g2["x"] = (g1["x"][perm] + rs.normal(6, 8, n)).clip(0, g1["max_x"] - 1).astype(np.float32)
+    g2["y"] = (g1["y"][perm] + rs.normal(0, 8, n)).clip(0, g1["max_y"] - 1).astype(np.float32)
+    g2["octave"] = np.where(rs.uniform(size=n) < 0.8, oct1[perm], 1).astype(np.int32)
+    d2 = _flip(rs, d1[perm], np.where(rs.uniform(size=n) < 0.6, 0.03, 0.2)[:, None])
+    dup = rs.uniform(size=n) < 0.1
+    d2[dup] = d1[perm][dup]
+    a2 = np.mod(a1[perm] + np.where(rs.uniform(size=n) < 0.8, rs.normal(5, 3, n), rs.uniform(0, 360, n)), 360).astype(np.float32)
+    f1 = dict(desc=np.ascontiguousarray(d1), octave=oct1, angle=a1, prev_x=g1["x"].copy(), prev_y=g1["y"].copy())
+    return f1, g2, np.ascontiguousarray(d2), a2, scale

@@ -160,6 +160,24 @@ class Oracle:
             C.byref(s), _p(dKF), _p(scale_factors), len(pts["u"]), _p(pts["valid"]), _p(pts["u"]), _p(pts["v"]),
             _p(pts["level"]), _p(pts["desc"]), int(th), C.c_float(ratio_hamming), _p(assign), _p(occupied))
 
+    def search_for_triangulation(self, k1, k2, ep, F12, sigma2_2, scale_2, only_stereo, coarse, check_ori):
+        a, b = self._fv(k1["fv"]), self._fv(k2["fv"])
+        m12 = np.full(max(len(k1["x"]), 1), -1, np.int32)
+        n = self.lib.orbm_oracle_search_for_triangulation(
+            _p(k1["desc"]), len(k1["x"]), _p(k1["has_mp"]), _p(k1["stereo"]), _p(k1["x"]), _p(k1["y"]), _p(k1["angle"]), C.byref(a),
+            _p(k2["desc"]), len(k2["x"]), _p(k2["has_mp"]), _p(k2["stereo"]), _p(k2["x"]), _p(k2["y"]), _p(k2["octave"]), _p(k2["angle"]),
+            C.byref(b), C.c_float(ep[0]), C.c_float(ep[1]), _p(F12), _p(sigma2_2), _p(scale_2), int(only_stereo), int(coarse), int(check_ori), _p(m12))
+        return n, m12[:len(k1["x"])]
+
+    def search_for_initialization(self, f1, g2, d2, ang2, window_size, nnratio, check_ori):
+        s = self._grid(g2)
+        n1 = len(f1["octave"])
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        n = self.lib.orbm_oracle_search_for_initialization(
+            _p(f1["desc"]), n1, _p(f1["octave"]), _p(f1["angle"]), _p(f1["prev_x"]), _p(f1["prev_y"]), C.byref(s), _p(d2), _p(ang2),
+            int(window_size), C.c_float(nnratio), int(check_ori), _p(m12))
+        return n, m12[:n1]
+
     def fuse_search(self, g, dKF, scale_factors, u_right, inv_sigma2, pts, th, chi2_check=True):
         s = self._grid(g)
         n = len(pts["u"])

@@ -171,3 +171,34 @@ def test_fuse_search(pkg, oracle, sm, seed, th, chi2, npts):
     if npts >= 3000:
         assert (bd0 <= 50).sum() > 0.2 * npts          # plenty of fusable points (TH_LOW) ...
         assert (bi0 < 0).sum() > 0                     # ... and some with an empty window / all candidates gated out
+
+
+@pytest.mark.parametrize("seed,only_stereo,coarse,ori", [(0, False, False, True), (1, True, False, True), (2, False, True, False), (3, False, False, False)])
+def test_search_for_triangulation(pkg, oracle, sm, seed, only_stereo, coarse, ori):
+    """SearchForTriangulation (:907-1146): per-feature search inside shared vocabulary nodes, epipole / epipolar gates,
+    `dist > bestDist -> continue` (the last equally good candidate wins), rotation histogram"""
+    k1, k2, ep, F12, sigma2, scale = sm.make_triangulation_case(seed)
+    n0, m0 = oracle.search_for_triangulation(k1, k2, ep, F12, sigma2, scale, only_stereo, coarse, ori)
+    m = pkg.Matcher(0.6, ori)
+    try:
+        n1, m1 = m.SearchForTriangulation(k1, k2, ep, F12, sigma2, scale, only_stereo, coarse)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > (5 if only_stereo else 60)
+    np.testing.assert_array_equal(m1, m0)
+
+
+@pytest.mark.parametrize("seed,win,ratio,ori", [(0, 100, 0.9, True), (1, 30, 0.9, True), (2, 100, 0.7, False)])
+def test_search_for_initialization(pkg, oracle, sm, seed, win, ratio, ori):
+    """SearchForInitialization (:648-763): level-0 features only, matched-distance feedback, stolen matches, ratio test"""
+    f1, g2, d2, a2, scale = sm.make_initialization_case(seed)
+    n0, m0 = oracle.search_for_initialization(f1, g2, d2, a2, win, ratio, ori)
+    m = pkg.Matcher(ratio, ori)
+    try:
+        n1, m1 = m.SearchForInitialization(f1, g2, d2, a2, scale, win)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 100
+    np.testing.assert_array_equal(m1, m0)
+    assert n0 == int((m0 >= 0).sum())
+    assert len(set(m0[m0 >= 0])) == n0                   # one-to-one after the stealing
