@@ -386,9 +386,10 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
                            (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
     mark();
-    hipLaunchKernelGGL(k_orient_desc, dim3((sel_frame_entries + 3) / 4, B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
+    const int quads = (sel_frame_entries + 3) / 4;
+    hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)(((long long)quads * B + 7) / 8 * 8)), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
                        d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p, d_kp_dst.p, sel_frame_entries,
-                       o_kps, o_desc, cap, d_lvl_kps.p);
+                       o_kps, o_desc, cap, d_lvl_kps.p, quads, B);
     mark();
     prof_marks = mark_i;
     prof_stream = st;

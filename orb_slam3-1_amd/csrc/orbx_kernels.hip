@@ -733,19 +733,26 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
                                                      const int* __restrict__ sel_count,
                                                      const int* __restrict__ kp_dst, int kp_frame_stride,
                                                      OrbxKeyPoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap,
-                                                     OrbxKeyPoint* __restrict__ lvl_kps /* optional: per-level keypoints, level coords */)
+                                                     OrbxKeyPoint* __restrict__ lvl_kps /* optional: per-level keypoints, level coords */,
+                                                     int quads_per_frame, int batch)
 {
-    // grid = (quads of selection slots, frame).  Both patches a keypoint needs -- the 31x31 disc of the unblurred level (IC_Angle) and the 37x37 window
+    // Both patches a keypoint needs -- the 31x31 disc of the unblurred level (IC_Angle) and the 37x37 window
     // of the blurred level that the rotated pattern can reach (|coordinate| <= 18 < EDGE_THRESHOLD) -- are fetched up front
     // with aligned dword loads into a wave-private LDS window, so a wave sees two dependent memory round trips (selection
     // record, patches) instead of four, and 11 dword requests per lane instead of 24 byte requests.
     constexpr int kBR = 18, kBW = 10, kPR = 15, kPW = 9;        // blur: 37 rows x 10 dwords; pyr: 31 rows x 9 dwords
     __shared__ uint32_t s_patch[4][(2 * kBR + 1) * kBW + (2 * kPR + 1) * kPW];
-    const int frame = blockIdx.y;
+    // 1-D grid of quads_per_frame * batch workgroups.  Workgroup w runs on XCD w % 8: giving XCD k the contiguous range
+    // [k * total / 8, (k + 1) * total / 8) of (frame, quad) pairs keeps all the patches of a frame in ONE L2 (2.4 MB of
+    // pyramid + blur per frame against 4 MB of L2) instead of fetching every frame into all eight.
+    const int total_wg = gridDim.x, per_xcd = total_wg >> 3;            // the host pads the grid to a multiple of 8
+    const int v_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int frame = v_id / quads_per_frame, quad = v_id - frame * quads_per_frame;
+    if (frame >= batch) return;                                         // grid padding (uniform for the workgroup)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the selection slots of all levels are one flat range [0, sel_frame_stride): a wave takes slot s and finds its level
     // from the level offsets (scalar loads), so no workgroup is launched for slots a level does not have
-    const int s_flat = blockIdx.x * 4 + wave;
+    const int s_flat = quad * 4 + wave;
     int level = 0;
     for (int l = 1; l < n_levels; l++) level = (s_flat >= levels[l].sel_off) ? l : level;
     const LevelDesc L = levels[level];
