@@ -87,6 +87,22 @@ int orbx_features_per_level(const orbx_extractor* h, int* n_per_level);
 int orbx_pyramid_level_size(const orbx_extractor* h, int level, int* width, int* height);
 int orbx_pyramid_level(orbx_extractor* h, int frame, int level, int border, uint8_t* dst, int dst_stride);
 
+/* void Frame::ComputeStereoMatches() (src/Frame.cc:931-1101): for every left key point the best right
+ * key point in its row band (Hamming), an 11x11 SAD sliding window on the pyramid level of the left key point, parabola
+ * sub-pixel fit, disparity gates and the median cut.  `left` / `right` are the two extractor handles of the rectified
+ * stereo pair (mpORBextractorLeft / Right); their pyramids of the LAST extract call stand for mvImagePyramid.  kps are
+ * mvKeys / mvKeysRight, mb = baseline in metres, mbf = baseline * fx.  Outputs mvuRight / mvDepth (-1 where unmatched).
+ * Host buffers, frame `frame` of the last batch: */
+int orbx_stereo_matches(orbx_extractor* left, orbx_extractor* right, int frame,
+                        const OrbxKeyPoint* kps_l, const uint8_t* desc_l, int n_l,
+                        const OrbxKeyPoint* kps_r, const uint8_t* desc_r, int n_r, float mb, float mbf, float* u_right, float* depth);
+/* Device-resident batch: the outputs of orbx_extract_batch_device of both handles ([batch][cap] arrays, d_n per frame);
+ * d_u_right / d_depth are [batch][cap] floats.  One wave per left key point; only enqueues on `stream`. */
+int orbx_stereo_matches_device(orbx_extractor* left, orbx_extractor* right, int batch,
+                               const OrbxKeyPoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
+                               const OrbxKeyPoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r, int cap,
+                               float mb, float mbf, float* d_u_right, float* d_depth, void* stream);
+
 /* Per-stage device time of the LAST extract call, measured with HIP events recorded on the launch stream
  * (used by bench.py for the roofline figure).  Stages: 0 level-0 copy, 1 pyramid resize, 2 FAST cells, 3 octree,
  * 4 output index, 5 blur, 6 orientation + descriptors.  Times in milliseconds. */

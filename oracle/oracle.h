@@ -32,6 +32,12 @@ typedef struct OracleKeyPoint {
     int32_t class_id;
 } OracleKeyPoint;
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:931-1101) on the pyramids of the last extract call of hL / hR.
+ * Returns the number of matches before the median cut, or -2 if a patch left the image (cv::Mat would assert). */
+int   orb_oracle_stereo_matches(void* hL, void* hR, const OracleKeyPoint* kpsL, const uint8_t* descL, int N,
+                                const OracleKeyPoint* kpsR, const uint8_t* descR, int Nr, float mb, float mbf,
+                                float* uRight, float* depth);
+
 /* ---------------- extractor (reference src/ORBextractor.cc) ---------------- */
 void* orb_oracle_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
 void  orb_oracle_destroy(void* h);

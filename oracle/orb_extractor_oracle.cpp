@@ -800,4 +800,103 @@ void orb_oracle_sort_nodes(int* count, int* ulx, int* tag, int n)
     }
 }
 
+// Frame::ComputeStereoMatches (reference src/Frame.cc:931-1101), SURVEY.md 8(f) rank 4: row-band candidates, best Hamming
+// match, 11x11 SAD sliding window on the pyramid level of the left key point, parabola sub-pixel fit, median-based outlier
+// cut.  hL / hR are the oracle extractors that produced kpsL / kpsR (their pyramids of the LAST extract call are
+// mpORBextractorLeft/Right->mvImagePyramid).  kps are mvKeys / mvKeysRight (level-0 coordinates).  Outputs mvuRight, mvDepth.
+int orb_oracle_stereo_matches(void* hL, void* hR, const OracleKeyPoint* kpsL, const uint8_t* descL, int N,
+                              const OracleKeyPoint* kpsR, const uint8_t* descR, int Nr, float mb, float mbf,
+                              float* uRight, float* depth)
+{
+    Extractor* eL = (Extractor*)hL;
+    Extractor* eR = (Extractor*)hR;
+    const int TH_HIGH = 100, TH_LOW = 50;
+    for (int i = 0; i < N; i++) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = eL->lh[0];
+    std::vector<std::vector<size_t> > vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; iR++) {
+        const float kpY = kpsR[iR].y;
+        const float r = 2.0f * eL->scale[kpsR[iR].octave];
+        const int maxr = (int)std::ceil(kpY + r);
+        const int minr = (int)std::floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);        // (the reference indexes unchecked)
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    std::vector<std::pair<int, int> > vDistIdx;
+    for (int iL = 0; iL < N; iL++) {
+        const OracleKeyPoint& kpL = kpsL[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y, uL = kpL.x;
+        const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = descL + (size_t)iL * 32;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const OracleKeyPoint& kpR = kpsR[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orbm_oracle_hamming(dL, descR + iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = kpsR[bestIdxR].x;
+            const float scaleFactor = eL->inv_scale[kpL.octave];
+            const float scaleduL = std::round(kpL.x * scaleFactor);
+            const float scaledvL = std::round(kpL.y * scaleFactor);
+            const float scaleduR0 = std::round(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const int lw = eL->lw[kpL.octave], lhh = eL->lh[kpL.octave];
+            const std::vector<uint8_t>& IL = eL->pyr[kpL.octave];
+            const std::vector<uint8_t>& IRi = eR->pyr[kpL.octave];
+            int bestDistS = INT32_MAX, bestincR = 0;
+            float vDists[2 * 5 + 1];
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= eR->lw[kpL.octave]) continue;
+            const int y0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w);
+            if (y0 < 0 || y0 + 2 * w + 1 > lhh || xl0 < 0 || xl0 + 2 * w + 1 > lw) return -2;      // cv::Mat::rowRange would assert
+            for (int incR = -L; incR <= +L; incR++) {
+                const int xr0 = (int)(scaleduR0 + incR - w);
+                if (xr0 < 0 || xr0 + 2 * w + 1 > eR->lw[kpL.octave]) return -2;
+                int sad = 0;                                            // cv::norm(IL, IR, NORM_L1) on 8UC1 = integer sum
+                for (int yy = 0; yy < 2 * w + 1; yy++)
+                    for (int xx = 0; xx < 2 * w + 1; xx++)
+                        sad += std::abs((int)IL[(size_t)(y0 + yy) * lw + xl0 + xx] - (int)IRi[(size_t)(y0 + yy) * eR->lw[kpL.octave] + xr0 + xx]);
+                const float dist = (float)sad;
+                if (dist < bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = eL->scale[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                depth[iL] = mbf / disparity;
+                uRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0;                                      // (the reference would read vDistIdx[0])
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        uRight[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+    }
+    return (int)vDistIdx.size();
+}
+
 }  // extern "C"

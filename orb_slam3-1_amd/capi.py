@@ -187,6 +187,21 @@ class Extractor:
                                              lapping_area[0], lapping_area[1], d_kps_ptr, d_desc_ptr, cap,
                                              d_n_ptr, d_mono_ptr, d_status_ptr, stream))
 
+    def stereo_matches(self, right, kps_l, desc_l, kps_r, desc_r, mb, mbf, frame=0):
+        """Frame::ComputeStereoMatches with self = left extractor, `right` = right extractor (pyramids of their last calls)."""
+        kps_l = np.ascontiguousarray(kps_l); kps_r = np.ascontiguousarray(kps_r)
+        desc_l = np.ascontiguousarray(desc_l); desc_r = np.ascontiguousarray(desc_r)
+        n = len(kps_l)
+        ur = np.full(max(n, 1), -1, np.float32); dp = np.full(max(n, 1), -1, np.float32)
+        _check(lib.orbx_stereo_matches(self._h, right._h, int(frame), _p(kps_l), _p(desc_l), n, _p(kps_r), _p(desc_r), len(kps_r),
+                                       C.c_float(mb), C.c_float(mbf), _p(ur), _p(dp)))
+        return ur[:n], dp[:n]
+
+    def stereo_matches_device(self, right, batch, d_kps_l, d_desc_l, d_n_l, d_kps_r, d_desc_r, d_n_r, cap, mb, mbf, d_u_right, d_depth, stream=None):
+        _check(lib.orbx_stereo_matches_device(self._h, right._h, int(batch), C.c_void_p(d_kps_l), C.c_void_p(d_desc_l), C.c_void_p(d_n_l),
+                                              C.c_void_p(d_kps_r), C.c_void_p(d_desc_r), C.c_void_p(d_n_r), int(cap), C.c_float(mb), C.c_float(mbf),
+                                              C.c_void_p(d_u_right), C.c_void_p(d_depth), C.c_void_p(stream or 0)))
+
     def profile_enable(self, on=True):
         lib.orbx_profile_enable.argtypes = [C.c_void_p, C.c_int]
         _check(lib.orbx_profile_enable(self._h, int(on)))

@@ -124,6 +124,8 @@ struct orbx_extractor {
     DevBuf<OrbxKeyPoint> d_kps;
     DevBuf<uint8_t> d_desc;
     DevBuf<int> d_n, d_mono, d_status;
+    DevBuf<int> d_sad;                   // ComputeStereoMatches: SAD of the accepted matches
+    DevBuf<uint8_t> d_stereo_io;         // host-buffer variant of the stereo matcher
     int out_cap = 0;
     hipStream_t stream = nullptr;
     // per-stage HIP-event profiling (off by default)
@@ -474,6 +476,7 @@ void orbx_destroy(orbx_extractor* e)
     e->d_pyr.release(); e->d_blur.release(); e->d_cand.release(); e->d_scratch.release(); e->d_sel.release();
     e->d_cell_count.release(); e->d_sel_count.release(); e->d_kp_dst.release(); e->d_lvl_kps.release();
     e->d_kps.release(); e->d_desc.release(); e->d_n.release(); e->d_mono.release(); e->d_status.release();
+    e->d_sad.release(); e->d_stereo_io.release();
     delete e;
 }
 
@@ -653,6 +656,78 @@ int orbx_debug_introsort(int32_t* count, int32_t* ulx, int32_t* node, int n)
     for (int i = 0; i < n; i++) { v[i].count = count[i]; v[i].ulx = ulx[i]; v[i].node = node[i]; }
     introsort_nodes(v.data(), n);
     for (int i = 0; i < n; i++) { count[i] = v[i].count; ulx[i] = v[i].ulx; node[i] = v[i].node; }
+    return ORBX_OK;
+}
+
+// Frame::ComputeStereoMatches (src/Frame.cc:931-1101) on the pyramids both extractors hold from their LAST extract call.
+static int stereo_enqueue(orbx_extractor* l, orbx_extractor* r, int frame0, int batch,
+                          const OrbxKeyPoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
+                          const OrbxKeyPoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r, int cap,
+                          float mb, float mbf, float* d_u_right, float* d_depth, hipStream_t st)
+{
+    if (l->geo_w == 0 || l->geo_w != r->geo_w || l->geo_h != r->geo_h || l->nlevels != r->nlevels || l->scale_factor_f != r->scale_factor_f)
+        return fail(ORBX_ERR_ARG, "the two extractors do not hold pyramids of the same geometry");
+    if (l->device != r->device) return fail(ORBX_ERR_ARG, "the two extractors live on different devices");
+    if (frame0 < 0 || batch < 1 || frame0 + batch > l->last_batch || frame0 + batch > r->last_batch) return fail(ORBX_ERR_ARG, "frames outside the last extract call");
+    if (l->nlevels > 16) return fail(ORBX_ERR_ARG, "more than 16 pyramid levels");
+    if (cap < 1 || cap > 8192) return fail(ORBX_ERR_ARG, "cap %d outside 1..8192", cap);
+    if (!(mb > 0.f) || !(mbf > 0.f)) return fail(ORBX_ERR_ARG, "mb and mbf must be positive");
+    int rr = l->d_sad.ensure((size_t)batch * cap);
+    if (rr) return rr;
+    StereoTables T;
+    for (int i = 0; i < 16; i++) { T.scale[i] = l->scale[std::min(i, l->nlevels - 1)]; T.inv_scale[i] = l->inv_scale[std::min(i, l->nlevels - 1)]; }
+    const uint8_t* pl = l->d_pyr.p + (size_t)frame0 * l->pyr_frame_bytes;
+    const uint8_t* pr = r->d_pyr.p + (size_t)frame0 * r->pyr_frame_bytes;
+    hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, batch), dim3(256), 0, st, pl, pr, l->pyr_frame_bytes, l->d_levels.p, T,
+                       d_kps_l, d_desc_l, d_n_l, d_kps_r, d_desc_r, d_n_r, cap, mb, mbf, d_u_right, d_depth, l->d_sad.p);
+    int n_pow2 = 2;
+    while (n_pow2 < cap) n_pow2 <<= 1;
+    hipLaunchKernelGGL(k_stereo_median, dim3(batch), dim3(256), (size_t)n_pow2 * sizeof(int), st, d_n_l, cap, n_pow2, d_u_right, d_depth, l->d_sad.p);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_stereo_matches_device(orbx_extractor* left, orbx_extractor* right, int batch,
+                               const OrbxKeyPoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
+                               const OrbxKeyPoint* d_kps_r, const uint8_t* d_desc_r, const int32_t* d_n_r, int cap,
+                               float mb, float mbf, float* d_u_right, float* d_depth, void* stream)
+{
+    if (!left || !right || !d_kps_l || !d_desc_l || !d_n_l || !d_kps_r || !d_desc_r || !d_n_r || !d_u_right || !d_depth) return fail(ORBX_ERR_ARG, "NULL argument");
+    ORBX_HIP(hipSetDevice(left->device));
+    return stereo_enqueue(left, right, 0, batch, d_kps_l, d_desc_l, d_n_l, d_kps_r, d_desc_r, d_n_r, cap, mb, mbf, d_u_right, d_depth, (hipStream_t)stream);
+}
+
+int orbx_stereo_matches(orbx_extractor* left, orbx_extractor* right, int frame,
+                        const OrbxKeyPoint* kps_l, const uint8_t* desc_l, int n_l,
+                        const OrbxKeyPoint* kps_r, const uint8_t* desc_r, int n_r, float mb, float mbf, float* u_right, float* depth)
+{
+    if (!left || !right || n_l < 0 || n_r < 0 || (n_l > 0 && (!kps_l || !desc_l || !u_right || !depth)) || (n_r > 0 && (!kps_r || !desc_r)))
+        return fail(ORBX_ERR_ARG, "NULL argument");
+    if (n_l == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(left->device));
+    const int cap = std::max(std::max(n_l, n_r), 1);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_kl = 0, o_dl = al(o_kl + sizeof(OrbxKeyPoint) * (size_t)cap), o_kr = al(o_dl + 32 * (size_t)cap), o_dr = al(o_kr + sizeof(OrbxKeyPoint) * (size_t)cap),
+                 o_n = al(o_dr + 32 * (size_t)cap), o_u = al(o_n + 8), o_d = al(o_u + 4 * (size_t)cap), total = al(o_d + 4 * (size_t)cap);
+    int r = left->d_stereo_io.ensure(total);
+    if (r) return r;
+    uint8_t* b = left->d_stereo_io.p;
+    hipStream_t st = left->stream;
+    const int32_t nn[2] = {n_l, n_r};
+    ORBX_HIP(hipMemcpyAsync(b + o_kl, kps_l, sizeof(OrbxKeyPoint) * (size_t)n_l, hipMemcpyHostToDevice, st));
+    ORBX_HIP(hipMemcpyAsync(b + o_dl, desc_l, 32 * (size_t)n_l, hipMemcpyHostToDevice, st));
+    if (n_r > 0) {
+        ORBX_HIP(hipMemcpyAsync(b + o_kr, kps_r, sizeof(OrbxKeyPoint) * (size_t)n_r, hipMemcpyHostToDevice, st));
+        ORBX_HIP(hipMemcpyAsync(b + o_dr, desc_r, 32 * (size_t)n_r, hipMemcpyHostToDevice, st));
+    }
+    ORBX_HIP(hipMemcpyAsync(b + o_n, nn, 8, hipMemcpyHostToDevice, st));
+    ORBX_HIP(hipStreamSynchronize(right->stream));      // the right pyramid was written on the other handle's stream
+    r = stereo_enqueue(left, right, frame, 1, (const OrbxKeyPoint*)(b + o_kl), b + o_dl, (const int32_t*)(b + o_n),
+                       (const OrbxKeyPoint*)(b + o_kr), b + o_dr, (const int32_t*)(b + o_n) + 1, cap, mb, mbf, (float*)(b + o_u), (float*)(b + o_d), st);
+    if (r) return r;
+    ORBX_HIP(hipMemcpyAsync(u_right, b + o_u, 4 * (size_t)n_l, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipMemcpyAsync(depth, b + o_d, 4 * (size_t)n_l, hipMemcpyDeviceToHost, st));
+    ORBX_HIP(hipStreamSynchronize(st));
     return ORBX_OK;
 }
 

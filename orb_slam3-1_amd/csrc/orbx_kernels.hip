@@ -834,4 +834,162 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (reference src/Frame.cc:931-1101), SURVEY 8(f) rank 4.  One wave per left key point:
+// the row table of the reference (vRowIndices) becomes a lane-strided scan of the right key points with the same band
+// test; first minimum through a (distance, index) key; then the 11 x 11 SAD sliding window over 11 shifts on the left
+// key point's pyramid level, parabola fit and the disparity gates, in the reference's float expressions.
+// ------------------------------------------------------------------------------------------------
+struct StereoTables { float scale[16], inv_scale[16]; };
+
+__global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR, size_t frame_stride,
+                                                     const LevelDesc* __restrict__ levels, StereoTables T,
+                                                     const OrbxKeyPoint* __restrict__ kpsL, const uint8_t* __restrict__ descL, const int32_t* __restrict__ nL,
+                                                     const OrbxKeyPoint* __restrict__ kpsR, const uint8_t* __restrict__ descR, const int32_t* __restrict__ nR,
+                                                     int cap, float mb, float mbf,
+                                                     float* __restrict__ u_right, float* __restrict__ depth, int32_t* __restrict__ sad_out)
+{
+    __shared__ uint8_t s_l[4][11 * 12], s_r[4][11 * 24];
+    __shared__ int s_part[4][11 * 11];
+    const int frame = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int iL = blockIdx.x * 4 + wave;
+    const int n_l = min(nL[frame], cap), n_r = min(nR[frame], cap);
+    const bool live = iL < n_l;
+    const size_t fo = (size_t)frame * cap;
+    // ---- best right key point by descriptor distance (:973-1008) ----
+    float uL = 0, vL = 0;
+    int levelL = 0;
+    unsigned key = 0xFFFFFFFFu;
+    if (live) {
+        const OrbxKeyPoint kl = kpsL[fo + iL];
+        uL = kl.x; vL = kl.y; levelL = kl.octave;
+        const int v_row = (int)vL;                                           // vRowIndices[vL]
+        const float minZ = mb, minD = 0, maxD = mbf / minZ;
+        const float minU = uL - maxD, maxU = uL - minD;
+        const unsigned long long* dl = (const unsigned long long*)(descL + (fo + iL) * 32);
+        const unsigned long long d0 = dl[0], d1 = dl[1], d2 = dl[2], d3 = dl[3];
+        for (int iR = lane; iR < n_r; iR += 64) {
+            const OrbxKeyPoint kr = kpsR[fo + iR];
+            const float r = 2.0f * T.scale[kr.octave & 15];
+            const int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
+            if (v_row < minr || v_row > maxr) continue;                      // the row table of :941-960
+            if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
+            if (!(kr.x >= minU && kr.x <= maxU)) continue;
+            const unsigned long long* dr = (const unsigned long long*)(descR + (fo + iR) * 32);
+            const int dist = __popcll(d0 ^ dr[0]) + __popcll(d1 ^ dr[1]) + __popcll(d2 ^ dr[2]) + __popcll(d3 ^ dr[3]);
+            if (dist < 100) key = min(key, ((unsigned)dist << 20) | (unsigned)iR);     // bestDist starts at TH_HIGH; first minimum
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    const int thOrbDist = (100 + 50) / 2;
+    bool ok = live && key != 0xFFFFFFFFu && (int)(key >> 20) < thOrbDist;
+    // ---- sub-pixel match by correlation (:1011-1083) ----
+    float scaleduR0 = 0;
+    int y0 = 0, xl0 = 0, xr_start = 0;
+    size_t loff = 0;
+    int lstride = 0;
+    if (ok) {
+        const float uR0 = kpsR[fo + (key & 0xFFFFFu)].x;
+        const float scaleFactor = T.inv_scale[levelL & 15];
+        const float scaleduL = roundf(uL * scaleFactor), scaledvL = roundf(vL * scaleFactor);
+        scaleduR0 = roundf(uR0 * scaleFactor);
+        const LevelDesc L = levels[levelL];
+        loff = (size_t)L.off; lstride = L.stride;
+        const int w = 5, Ls = 5;
+        const float iniu = scaleduR0 + Ls - w, endu = scaleduR0 + Ls + w + 1;
+        if (iniu < 0 || endu >= (float)L.w) ok = false;
+        y0 = (int)(scaledvL - w); xl0 = (int)(scaleduL - w); xr_start = (int)(scaleduR0 - Ls - w);
+        // cv::Mat::rowRange / colRange would assert outside the level image; key points of the extractor never get here
+        if (y0 < 0 || y0 + 11 > L.h || xl0 < 0 || xl0 + 11 > L.w || xr_start < 0 || xr_start + 21 > L.w) ok = false;
+    }
+    if (ok) {
+        const uint8_t* il = pyrL + (size_t)frame * frame_stride + loff;
+        const uint8_t* ir = pyrR + (size_t)frame * frame_stride + loff;
+        for (int i = lane; i < 121; i += 64) { const int r = i / 11, c = i - r * 11; s_l[wave][r * 12 + c] = il[(size_t)(y0 + r) * lstride + xl0 + c]; }
+        for (int i = lane; i < 231; i += 64) { const int r = i / 21, c = i - r * 21; s_r[wave][r * 24 + c] = ir[(size_t)(y0 + r) * lstride + xr_start + c]; }
+    }
+    __syncthreads();
+    if (ok) {
+        for (int i = lane; i < 121; i += 64) {
+            const int sft = i / 11, r = i - sft * 11;
+            int acc = 0;
+#pragma unroll
+            for (int c = 0; c < 11; c++) acc += abs((int)s_l[wave][r * 12 + c] - (int)s_r[wave][r * 24 + sft + c]);
+            s_part[wave][sft * 11 + r] = acc;
+        }
+    }
+    __syncthreads();
+    if (ok && lane == 0) {
+        const int Ls = 5;
+        float vDists[11];
+        int bestDist = 0x7FFFFFFF, bestincR = 0;
+        for (int sft = 0; sft < 11; sft++) {
+            int sad = 0;
+            for (int r = 0; r < 11; r++) sad += s_part[wave][sft * 11 + r];
+            const float dist = (float)sad;                                   // cv::norm(IL, IR, NORM_L1)
+            if (dist < (float)bestDist) { bestDist = (int)dist; bestincR = sft - Ls; }
+            vDists[sft] = dist;
+        }
+        float ur_out = -1.0f, depth_out = -1.0f;
+        int sad_best = -1;
+        if (!(bestincR == -Ls || bestincR == Ls)) {
+            const float dist1 = vDists[Ls + bestincR - 1], dist2 = vDists[Ls + bestincR], dist3 = vDists[Ls + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (!(deltaR < -1 || deltaR > 1)) {
+                float bestuR = T.scale[levelL & 15] * ((float)scaleduR0 + (float)bestincR + deltaR);
+                float disparity = (uL - bestuR);
+                const float minD = 0, maxD = mbf / mb;
+                if (disparity >= minD && disparity < maxD) {
+                    if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }      // double literals, as in :1073-1074
+                    depth_out = mbf / disparity;
+                    ur_out = bestuR;
+                    sad_best = bestDist;
+                }
+            }
+        }
+        u_right[fo + iL] = ur_out; depth[fo + iL] = depth_out; sad_out[fo + iL] = sad_best;
+    } else if (live && lane == 0) {
+        u_right[fo + iL] = -1.0f; depth[fo + iL] = -1.0f; sad_out[fo + iL] = -1;
+    }
+}
+
+// median cut of :1086-1100: matches whose SAD is >= 1.5 * 1.4 * median are dropped.  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nL, int cap, int n_pow2,
+                                                      float* __restrict__ u_right, float* __restrict__ depth, const int32_t* __restrict__ sad)
+{
+    extern __shared__ int s_sad[];       // n_pow2
+    __shared__ int s_cnt;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int n = min(nL[frame], cap);
+    const size_t fo = (size_t)frame * cap;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < n_pow2; i += 256) {
+        const int v = (i < n) ? sad[fo + i] : -1;
+        s_sad[i] = v >= 0 ? v : 0x7FFFFFFF;
+        local += v >= 0;
+    }
+    if (local) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n_pow2 >> 1); t += 256) {
+                const int lo = 2 * t - (t & (j - 1)), hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const int a = s_sad[lo], b = s_sad[hi];
+                if ((a > b) == up) { s_sad[lo] = b; s_sad[hi] = a; }
+            }
+            __syncthreads();
+        }
+    const int m = s_cnt;
+    if (m == 0) return;
+    const float median = (float)s_sad[m / 2];
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = tid; i < n; i += 256) {
+        const int v = sad[fo + i];
+        if (v >= 0 && !((float)v < thDist)) { u_right[fo + i] = -1; depth[fo + i] = -1; }
+    }
+}
+
 }  // namespace orbx

@@ -311,3 +311,16 @@ def make_vocabulary_fast(seed, k=10, L=6):
     word_id = np.full(n, -1, np.int32)
     word_id[n_inner:] = np.arange(n - n_inner)
     return dict(n_nodes=n, L=L, k=k, child_off=child_off.astype(np.int32), child_id=child_id, desc=desc, weight=weight, word_id=word_id)
+
+
+def make_stereo_pair(seed, w=640, h=480, band=60, dmin=3, dmax=40):
+    """Rectified stereo pair for Frame::ComputeStereoMatches: the right image is the left one with a different integer
+    disparity per horizontal band (fronto-parallel 'objects' at different depths)."""
+    left = make_frame(seed, w, h)
+    right = np.zeros_like(left)
+    rs = np.random.RandomState(4409 + seed)
+    for y0 in range(0, h, band):
+        d = int(rs.randint(dmin, dmax + 1))
+        right[y0:y0 + band, :w - d] = left[y0:y0 + band, d:]
+        right[y0:y0 + band, w - d:] = left[y0:y0 + band, w - d:]
+    return left, right

@@ -399,3 +399,14 @@ def oracle_transform(orc, voc, desc, levelsup=4):
     nb, nf = C.c_int32(), C.c_int32()
     used = orc.lib.dbow_oracle_transform(C.byref(s), _p(desc), n, int(levelsup), _p(bi), _p(bv), C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf))
     return (bi[:nb.value], bv[:nb.value]), (fn[:nf.value], fo[:nf.value + 1], ff[:used])
+
+
+def oracle_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
+    """Frame::ComputeStereoMatches on the pyramids of exL / exR's last extract call: (n_before_cut, uRight, depth)"""
+    kpsL = np.ascontiguousarray(kpsL); kpsR = np.ascontiguousarray(kpsR)
+    descL = np.ascontiguousarray(descL); descR = np.ascontiguousarray(descR)
+    n = len(kpsL)
+    ur = np.full(max(n, 1), -1, np.float32); dp = np.full(max(n, 1), -1, np.float32)
+    r = exL.L.orb_oracle_stereo_matches(exL.h, exR.h, _p(kpsL), _p(descL), n, _p(kpsR), _p(descR), len(kpsR),
+                                        C.c_float(mb), C.c_float(mbf), _p(ur), _p(dp))
+    return r, ur[:n], dp[:n]
