@@ -158,6 +158,19 @@ public:
         }
         pyramid_valid_ = true;
     }
+    // void Frame::ComputeStereoMatches() (src/Frame.cc:931-1101) with this = mpORBextractorLeft: both pyramids stay in HBM
+    // (no SyncPyramid), the frame gets mvuRight / mvDepth.
+    void ComputeStereoMatches(ORBextractorHIP& right, Frame& F)
+    {
+        F.mvuRight.assign(F.N, -1.0f);
+        F.mvDepth.assign(F.N, -1.0f);
+        if (F.N == 0) return;
+        static_assert(sizeof(cv::KeyPoint) == sizeof(OrbxKeyPoint), "cv::KeyPoint layout");
+        orbslam3_hip::check(orbx_stereo_matches(ex_.handle(), right.ex_.handle(), 0,
+                                                (const OrbxKeyPoint*)F.mvKeys.data(), F.mDescriptors.data, F.N,
+                                                (const OrbxKeyPoint*)F.mvKeysRight.data(), F.mDescriptorsRight.data, (int)F.mvKeysRight.size(),
+                                                F.mb, F.mbf, F.mvuRight.data(), F.mvDepth.data()));
+    }
     int GetLevels() { return ex_.GetLevels(); }
     float GetScaleFactor() { return ex_.GetScaleFactor(); }
     std::vector<float> GetScaleFactors() { return ex_.GetScaleFactors(); }
