@@ -64,6 +64,10 @@ class TorchDist:
 
     def sum_(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        # RCCL enqueues the all-reduce on torch's current stream and returns; the shard kernels that consume the buffer
+        # run on the shard's own stream, so the host waits here (the LM loop needs the scalars of this trial anyway)
+        if getattr(t, "is_cuda", False):
+            self.torch.cuda.current_stream(t.device).synchronize()
         return t
 
     def sum_scalars(self, vals):
