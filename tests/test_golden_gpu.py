@@ -153,3 +153,41 @@ def test_sharded_hip_path_world1(pkg, synth):
         sh.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_next_rows_golden(pkg, synth):
+    """SURVEY 8(f) rows against frozen oracle outputs: vocabulary transform, Fuse search core, SearchForTriangulation,
+    ComputeStereoMatches (fixtures from tools/make_golden.py)."""
+    sm = importlib.import_module("orb_slam3-1_amd.synth_match")
+    g = np.load(os.path.join(GOLDEN, "vocab_k6_L3_300.npz"))
+    voc = synth.make_vocabulary(40, k=6, L=3)
+    rs = np.random.RandomState(40)
+    vd = np.ascontiguousarray(voc["desc"][rs.randint(1, voc["n_nodes"], 300)] ^ (rs.uniform(size=(300, 32)) < 0.03).astype(np.uint8))
+    v = pkg.Vocabulary(voc)
+    try:
+        (bi, bv), (fn, fo, ff) = v.transform(vd, 2)
+    finally:
+        v.close()
+    for a, k in ((bi, "bow_id"), (bv, "bow_val"), (fn, "fv_node"), (fo, "fv_off"), (ff, "fv_feat")):
+        np.testing.assert_array_equal(a, g[k])
+    m = pkg.Matcher(0.6, True)
+    try:
+        gr, dKF, scale, u_right, inv_s2, pts = sm.make_fuse_case(41, n=600, n_pts=500)
+        fbi, fbd = m.FuseSearch(gr, dKF, scale, u_right, inv_s2, pts, 3.0, True)
+        g = np.load(os.path.join(GOLDEN, "fuse_500.npz"))
+        np.testing.assert_array_equal(fbi, g["best_idx"]); np.testing.assert_array_equal(fbd, g["best_dist"])
+        k1, k2, ep, F12, sigma2, sc2 = sm.make_triangulation_case(42, n=600)
+        tn, tm = m.SearchForTriangulation(k1, k2, ep, F12, sigma2, sc2, False, False)
+        g = np.load(os.path.join(GOLDEN, "triangulation_600.npz"))
+        assert tn == int(g["n"]); np.testing.assert_array_equal(tm, g["match12"])
+    finally:
+        m.close()
+    left, right = synth.make_stereo_pair(43)
+    exL, exR = pkg.Extractor(), pkg.Extractor()
+    try:
+        _, kL, dL = exL(left, (0, 0)); _, kR, dR = exR(right, (0, 0))
+        ur, dp = exL.stereo_matches(exR, kL, dL, kR, dR, 0.11, 47.9)
+    finally:
+        exL.close(); exR.close()
+    g = np.load(os.path.join(GOLDEN, "stereo_pair_43.npz"))
+    np.testing.assert_array_equal(ur, g["u_right"]); np.testing.assert_array_equal(dp, g["depth"])
