@@ -109,8 +109,51 @@ __device__ void bow_node(const BowPairDev& P, int k, int f, float nnratio, int c
     }
 }
 
+// One vocabulary node of a pair handled by a 16-lane group: the KF features of the node are taken in order (a Frame
+// feature consumed by one of them must be invisible to the next), the Frame features of the node are spread over the
+// lanes.  (distance, position) keys make the 16-lane minimum the reference's first best / second best.  The lanes keep
+// the "already consumed" state of the candidates they own in a register bitmask (positions lane, lane+16, ...).
+constexpr int kBowGroup = 16, kBowThreads = 1024;
 template <bool KFKF>
-__global__ __launch_bounds__(256) void k_bow(const BowPairDev* __restrict__ pairs, float nnratio, int check_ori)
+__device__ void bow_node_group(const BowPairDev& P, int k, int f, float nnratio, int check_ori, int* s_hist, int sub)
+{
+    const int b2 = P.off2[f], n2 = P.off2[f + 1] - b2;
+    unsigned taken = 0;                                         // bit j: candidate sub + 16*j is consumed
+    for (int i1 = P.off1[k]; i1 < P.off1[k + 1]; i1++) {
+        const int idx1 = (int)P.feat1[i1];
+        if (!P.v1[idx1]) continue;                           // !pMP || pMP->isBad()   (uniform over the group)
+        const unsigned long long* da = (const unsigned long long*)(P.d1 + (size_t)idx1 * 32);
+        const unsigned long long a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3];
+        unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        for (int c = sub, j = 0; c < n2; c += kBowGroup, j++) {
+            if ((taken >> j) & 1u) continue;
+            const int idx2 = (int)P.feat2[b2 + c];
+            if (KFKF && !P.v2[idx2]) continue;
+            const unsigned long long* db = (const unsigned long long*)(P.d2 + (size_t)idx2 * 32);
+            const unsigned key = ((unsigned)(__popcll(a0 ^ db[0]) + __popcll(a1 ^ db[1]) + __popcll(a2 ^ db[2]) + __popcll(a3 ^ db[3])) << 16) | (unsigned)c;
+            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+        }
+        for (int o = kBowGroup / 2; o > 0; o >>= 1) {
+            const unsigned o1 = (unsigned)__shfl_xor((int)k1, o), o2 = (unsigned)__shfl_xor((int)k2, o);
+            if (o1 < k1) { k2 = min(k1, o2); k1 = o1; } else k2 = min(k2, o1);
+        }
+        if (k1 == 0xFFFFFFFFu) continue;
+        const int best1 = (int)(k1 >> 16), best2 = (k2 == 0xFFFFFFFFu) ? 256 : (int)(k2 >> 16), cbest = (int)(k1 & 0xFFFFu);
+        const bool low = KFKF ? (best1 < TH_LOW) : (best1 <= TH_LOW);       // :848 is strict, :327 is not
+        if (low && (float)best1 < nnratio * (float)best2) {
+            if ((cbest & (kBowGroup - 1)) == sub) taken |= 1u << (cbest / kBowGroup);
+            if (sub == 0) {
+                const int bestIdx = (int)P.feat2[b2 + cbest];
+                if (KFKF) { P.match[idx1] = bestIdx; P.matched2[bestIdx] = 1; }
+                else P.match[bestIdx] = idx1;
+                if (check_ori) atomicAdd(&s_hist[rot_bin(P.a1[idx1], P.a2[bestIdx])], 1);
+            }
+        }
+    }
+}
+
+template <bool KFKF>
+__global__ __launch_bounds__(kBowThreads) void k_bow(const BowPairDev* __restrict__ pairs, float nnratio, int check_ori)
 {
     __shared__ int s_hist[HISTO_LENGTH];
     __shared__ int s_keep[3];
@@ -118,10 +161,11 @@ __global__ __launch_bounds__(256) void k_bow(const BowPairDev* __restrict__ pair
     const BowPairDev P = pairs[blockIdx.x];
     const int tid = threadIdx.x;
     const int n_out = KFKF ? P.n1 : P.n2;
-    for (int i = tid; i < n_out; i += 256) P.match[i] = -1;
-    if (KFKF) for (int i = tid; i < P.n2; i += 256) P.matched2[i] = 0;
+    for (int i = tid; i < n_out; i += kBowThreads) P.match[i] = -1;
+    if (KFKF) for (int i = tid; i < P.n2; i += kBowThreads) P.matched2[i] = 0;
     if (tid < HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_count = 0;
+    __threadfence_block();
     __syncthreads();
     if (P.serial) {
         if (tid == 0) {
@@ -134,20 +178,26 @@ __global__ __launch_bounds__(256) void k_bow(const BowPairDev* __restrict__ pair
             }
         }
     } else {
-        for (int k = tid; k < P.nn1; k += 256) {
+        const int sub = tid & (kBowGroup - 1);
+        for (int k = tid / kBowGroup; k < P.nn1; k += kBowThreads / kBowGroup) {
             const uint32_t key = P.node1[k];
             int lo = 0, hi = P.nn2;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.node2[mid] < key) lo = mid + 1; else hi = mid; }
-            if (lo < P.nn2 && P.node2[lo] == key) bow_node<KFKF>(P, k, lo, nnratio, check_ori, s_hist);
+            if (lo < P.nn2 && P.node2[lo] == key) {
+                // a node with more than 512 Frame features does not fit the per-lane bitmask: one lane walks it
+                if (P.off2[lo + 1] - P.off2[lo] > 32 * kBowGroup) { if (sub == 0) bow_node<KFKF>(P, k, lo, nnratio, check_ori, s_hist); }
+                else bow_node_group<KFKF>(P, k, lo, nnratio, check_ori, s_hist, sub);
+            }
         }
     }
+    __threadfence_block();
     __syncthreads();
     if (check_ori) {
         if (tid == 0) { int a, b, c; three_maxima(s_hist, HISTO_LENGTH, a, b, c); s_keep[0] = a; s_keep[1] = b; s_keep[2] = c; }
         __syncthreads();
     }
     int local = 0;
-    for (int i = tid; i < n_out; i += 256) {
+    for (int i = tid; i < n_out; i += kBowThreads) {
         const int m = P.match[i];
         if (m < 0) continue;
         if (check_ori) {
@@ -715,7 +765,7 @@ static int bow_batch(orbm_matcher* m, int n_pairs,
         descs[p] = D;
     }
     ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), m->h_blob.size(), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(orbm::k_bow<KFKF>, dim3(n_pairs), dim3(256), 0, m->stream, (const orbm::BowPairDev*)(base + desc_off), nnratio, check_ori);
+    hipLaunchKernelGGL(orbm::k_bow<KFKF>, dim3(n_pairs), dim3(orbm::kBowThreads), 0, m->stream, (const orbm::BowPairDev*)(base + desc_off), nnratio, check_ori);
     ORBM_HIP(hipGetLastError());
     for (int p = 0; p < n_pairs; p++) {
         const PairOffsets& o = po[p];
@@ -960,7 +1010,7 @@ int orbm_bow_plan_run(orbm_bow_plan* pl, float nnratio, int check_orientation, v
 {
     if (!pl) return fail(ORBX_ERR_ARG, "NULL plan");
     ORBM_HIP(hipSetDevice(pl->m->device));
-    hipLaunchKernelGGL(orbm::k_bow<false>, dim3(pl->n_pairs), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(orbm::k_bow<false>, dim3(pl->n_pairs), dim3(orbm::kBowThreads), 0, (hipStream_t)stream,
                        (const orbm::BowPairDev*)(pl->d_blob + pl->desc_off), nnratio, check_orientation);
     ORBM_HIP(hipGetLastError());
     return ORBX_OK;
