@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ORBX_BENCH_BATCH", "256")))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lba", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="extra leg: the same batch cut over this many independent HIP streams")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="extra leg (off by default so that every profiled launch has the headline's size): the same batch cut over "
+                         "this many independent HIP streams, e.g. --streams 4")
     args = ap.parse_args()
 
     import torch

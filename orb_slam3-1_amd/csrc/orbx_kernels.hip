@@ -132,6 +132,10 @@ __device__ __forceinline__ int fast_m(const uint8_t* __restrict__ t, int pitch)
     return max(m, 0);
 }
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+
 // One 256-thread workgroup per FAST cell.  LDS: image tile (cell + 3 px ring halo, re-aligned so that tile column 0 sits
 // on a dword), M tile with a 1-px zero halo (NMS must treat everything outside the cell's own interior as 0), survivor
 // list, two keypoint bitmasks (iniTh / minTh) and their word-prefix sums.
@@ -214,27 +218,46 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         w4[0] = base[4 * pd]; w4[1] = base[4 * pd + 1]; w4[2] = base[4 * pd + 2];
         w5[0] = base[5 * pd]; w5[1] = base[5 * pd + 1]; w5[2] = base[5 * pd + 2];
         w6[0] = base[6 * pd]; w6[1] = base[6 * pd + 1]; w6[2] = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = 4 * gx + k;
-            if (x >= iw) break;
-            const int v = (int)ORBX_B(w3, 3 + k);
-            const int lo = v - min_th, hi = v + min_th;     // dark: ring < lo, bright: ring > hi
-            int a = (int)ORBX_B(w6, 3 + k), b = (int)ORBX_B(w0, 3 + k);                 // ring 0 / 8
-            int dark = (a < lo) | (b < lo), bright = (a > hi) | (b > hi);
-#define ORBX_PAIR(A, B) a = (int)(A); b = (int)(B); dark &= (a < lo) | (b < lo); bright &= (a > hi) | (b > hi);
-            ORBX_PAIR(ORBX_B(w3, 6 + k), ORBX_B(w3, k))            // 4 / 12
-            ORBX_PAIR(ORBX_B(w5, 5 + k), ORBX_B(w1, 1 + k))        // 2 / 10
-            ORBX_PAIR(ORBX_B(w1, 5 + k), ORBX_B(w5, 1 + k))        // 6 / 14
-            if (dark | bright) {
-                ORBX_PAIR(ORBX_B(w6, 4 + k), ORBX_B(w0, 2 + k))    // 1 / 9
-                ORBX_PAIR(ORBX_B(w4, 6 + k), ORBX_B(w2, k))        // 3 / 11
-                ORBX_PAIR(ORBX_B(w2, 6 + k), ORBX_B(w4, k))        // 5 / 13
-                ORBX_PAIR(ORBX_B(w0, 4 + k), ORBX_B(w6, 2 + k))    // 7 / 15
-                if (dark | bright) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x);
-            }
+        // The four pixels travel in two registers of 2 x u16: pixels (0, 2) and pixels (1, 3).  v_perm_b32 pulls the two
+        // bytes of a ring position out of the row window and zero-extends them in ONE instruction; per ring pair the test
+        // "one of the two is darker than v - t" for ALL pairs is  max over pairs of min(a, b) < v - t  (packed min / max),
+        // likewise  min over pairs of max(a, b) > v + t  for the bright polarity: 12 packed ops per pair for 4 pixels.
+#define ORBX_SEL_E(r) ((uint32_t)(r) | 0x0C000C00u | ((uint32_t)((r) + 2) << 16))
+#define ORBX_SEL_O(r) ((uint32_t)((r) + 1) | 0x0C000C00u | ((uint32_t)((r) + 3) << 16))
+#define ORBX_PE(W, s) as_us2(__builtin_amdgcn_perm((W)[((s) >> 2) + 1], (W)[(s) >> 2], ORBX_SEL_E((s) & 3)))
+#define ORBX_PO(W, s) as_us2(__builtin_amdgcn_perm((W)[((s) >> 2) + 1], (W)[(s) >> 2], ORBX_SEL_O((s) & 3)))
+        const us2 T2 = as_us2((uint32_t)min_th | ((uint32_t)min_th << 16));
+        const us2 ce = ORBX_PE(w3, 3), co = ORBX_PO(w3, 3);
+        const us2 lo_e = __builtin_elementwise_sub_sat(ce, T2), lo_o = __builtin_elementwise_sub_sat(co, T2);   // max(v - t, 0)
+        const us2 hi_e = ce + T2, hi_o = co + T2;
+        us2 dk_e = as_us2(0u), dk_o = as_us2(0u), br_e = as_us2(0xFFFFFFFFu), br_o = as_us2(0xFFFFFFFFu);
+#define ORBX_PAIR(WA, SA, WB, SB) { \
+            const us2 ae = ORBX_PE(WA, SA), ao = ORBX_PO(WA, SA), be = ORBX_PE(WB, SB), bo = ORBX_PO(WB, SB); \
+            dk_e = __builtin_elementwise_max(dk_e, __builtin_elementwise_min(ae, be)); \
+            dk_o = __builtin_elementwise_max(dk_o, __builtin_elementwise_min(ao, bo)); \
+            br_e = __builtin_elementwise_min(br_e, __builtin_elementwise_max(ae, be)); \
+            br_o = __builtin_elementwise_min(br_o, __builtin_elementwise_max(ao, bo)); }
+        ORBX_PAIR(w6, 3, w0, 3)        // ring 0 / 8
+        ORBX_PAIR(w3, 6, w3, 0)        // 4 / 12
+        ORBX_PAIR(w5, 5, w1, 1)        // 2 / 10
+        ORBX_PAIR(w1, 5, w5, 1)        // 6 / 14
+        ORBX_PAIR(w6, 4, w0, 2)        // 1 / 9
+        ORBX_PAIR(w4, 6, w2, 0)        // 3 / 11
+        ORBX_PAIR(w2, 6, w4, 0)        // 5 / 13
+        ORBX_PAIR(w0, 4, w6, 2)        // 7 / 15
 #undef ORBX_PAIR
-        }
+        // non-zero 16-bit lane = candidate: sat(lo - dk) != 0  <=>  dk < v - t;   sat(br - hi) != 0  <=>  br > v + t
+        const uint32_t c_e = as_u32(__builtin_elementwise_sub_sat(lo_e, dk_e)) | as_u32(__builtin_elementwise_sub_sat(br_e, hi_e));
+        const uint32_t c_o = as_u32(__builtin_elementwise_sub_sat(lo_o, dk_o)) | as_u32(__builtin_elementwise_sub_sat(br_o, hi_o));
+        const int x4 = 4 * gx;
+        if ((c_e & 0xFFFFu) && x4 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4);
+        if ((c_o & 0xFFFFu) && x4 + 1 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4 + 1);
+        if ((c_e >> 16) && x4 + 2 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4 + 2);
+        if ((c_o >> 16) && x4 + 3 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4 + 3);
+#undef ORBX_PE
+#undef ORBX_PO
+#undef ORBX_SEL_E
+#undef ORBX_SEL_O
     }
     __syncthreads();
     ORBX_FTICK(1)

@@ -15,6 +15,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fet
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu --no-lba > /dev/null 2> $OUT/pmc_write.err || { echo "pmc write failed"; exit 1; }
 python tools/collect_pmc.py $OUT/pmc_fetch $OUT/pmc_write 256 > $OUT/pmc_traffic.log && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 cp $(ls $OUT/prof/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+timeout -k 10 200 python bench.py --streams 4 --no-cpu --no-lba > $OUT/bench_streams4.json 2> $OUT/bench_streams4.err || echo "streams-4 bench failed"
 python - <<PY
 import json
 d = json.load(open("$OUT/bench.json"))
