@@ -293,6 +293,26 @@ def main():
                            "single_frame_call_ms": 1e3 * dt1, "single_frame_kernel_ms": kms1 / 20}
             ps.close()
 
+        # ---- projection-search leg: SearchByProjection(CurrentFrame, LastFrame) (TrackWithMotionModel) for a batch of frames,
+        # one wave per frame in one launch; host buffers in and out (the call includes grid build, upload and download) ----
+        if not args.no_lba:
+            smm = importlib.import_module("orb_slam3-1_amd.synth_match")
+            pcases = [smm.make_last_frame_case(i) for i in range(8)]
+            pcases = [(g, dF, aF, sc, last, a.copy(), o_.copy()) for (g, dF, aF, sc, last, a, o_) in pcases * (B // 8)]
+            mproj = pkg.Matcher(0.9, True, device=local_rank)
+            pprep = mproj.prepare_last_batch(pcases)
+            mproj.run_last_batch(pprep, 15.0)
+            for c in pcases:
+                c[5][:] = -1; c[6][:] = 0
+            t0 = time.perf_counter()
+            nm = mproj.run_last_batch(pprep, 15.0)
+            dtq = time.perf_counter() - t0
+            out["proj"] = {"metric": "SearchByProjection(last frame) frames/s", "value": len(pcases) / dtq, "unit": "frames/s", "dtype": "u8",
+                           "workload": "%d frames x 1000 features, 900 projected points each, th 15, orientation check; one C call "
+                                       "(host grid build + upload + one launch, a wave per frame + download)" % len(pcases),
+                           "ms_per_batch": 1e3 * dtq, "matches_per_frame": float(np.mean(nm))}
+            mproj.close()
+
         # ---- vocabulary transform leg: Frame::ComputeBoW for the batch, on the extractor's output ----
         if not args.no_lba:
             voc = synth.make_vocabulary_fast(0, k=10, L=6)           # ORBvoc.txt's shape: 1 111 111 nodes, 35 MB of centroids
@@ -346,6 +366,13 @@ def main():
                 out["lba"]["cpu_baseline"] = {"value": it / dtc, "unit": "iters/s", "cores": 1, "kind": "port",
                                               "sample": "3 solves of the same window, %d iterations" % it}
                 out["lba"]["speedup_vs_cpu_1core"] = out["lba"]["value"] / (it / dtc)
+            if "proj" in out:
+                t0 = time.perf_counter()
+                for (g, dF, aF, sc, last, a, o_) in pcases[:16]:
+                    o.search_by_projection_last(g, dF, aF, sc, last, 15.0, True, np.full_like(a, -1), np.zeros_like(o_))
+                dtc = (time.perf_counter() - t0) / 16
+                out["proj"]["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "16 frames"}
+                out["proj"]["speedup_vs_cpu_1core"] = out["proj"]["value"] * dtc
             if "vocab" in out:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 from oracle_api import oracle_transform

@@ -204,6 +204,22 @@ int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
                                    float th, int check_orientation,
                                    int32_t* assign, uint8_t* occupied);
 
+/* Batched forms of the two tracking searches: n_frames independent (frame, projected points) problems -- e.g. one frame
+ * of every client stream of a tracking server -- in ONE launch, a wave per frame.  Field meaning as in the single-frame
+ * calls above (level = pred_level / last_octave, angle = last_angle); n_matches is written per query. */
+typedef struct OrbmProjQuery {
+    const OrbmFrame* frame;
+    int32_t n_pts;
+    const uint8_t* valid; const float* proj_u; const float* proj_v; const int32_t* level;
+    const float* view_cos; const float* track_depth; const uint8_t* mp_bad;      /* Frame x map points only */
+    const float* angle;                                                            /* last-frame search only */
+    const uint8_t* desc_mp; const uint8_t* mp_has_obs;
+    int32_t* assign; uint8_t* occupied;     /* in/out, frame->n entries */
+    int32_t n_matches;                      /* out */
+} OrbmProjQuery;
+int orbm_search_by_projection_last_batch(orbm_matcher* m, OrbmProjQuery* queries, int n_frames, float th, int check_orientation);
+int orbm_search_by_projection_batch(orbm_matcher* m, OrbmProjQuery* queries, int n_frames, float th, int far_points, float th_far, float nnratio);
+
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, float th,
  *                                    int ORBdist) (src/ORBmatcher.cc:1889-2010; Tracking::Relocalization).
  * One entry per pKF->GetMapPointMatches()[i]: valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP) && dist3D inside

@@ -381,6 +381,31 @@ class Matcher:
                                     _p(pts["ur"]), _p(pts["level"]), _p(pts["desc"]), C.c_float(th), int(chi2_check), _p(bi), _p(bd)))
         return bi[:n], bd[:n]
 
+    class _ProjQuery(C.Structure):
+        _fields_ = [("frame", C.c_void_p), ("n_pts", C.c_int32), ("valid", C.c_void_p), ("proj_u", C.c_void_p), ("proj_v", C.c_void_p),
+                    ("level", C.c_void_p), ("view_cos", C.c_void_p), ("track_depth", C.c_void_p), ("mp_bad", C.c_void_p), ("angle", C.c_void_p),
+                    ("desc_mp", C.c_void_p), ("mp_has_obs", C.c_void_p), ("assign", C.c_void_p), ("occupied", C.c_void_p), ("n_matches", C.c_int32)]
+
+    def prepare_last_batch(self, cases):
+        """cases: list of (g, dF, angF, scale_factors, last, assign, occupied) as for SearchByProjection_last"""
+        n = len(cases)
+        qs = (self._ProjQuery * n)()
+        frames = []
+        for i, (g, dF, angF, scale, last, assign, occ) in enumerate(cases):
+            f = self._frame(g, dF, scale, angF)
+            frames.append(f)
+            q = qs[i]
+            q.frame = C.addressof(f); q.n_pts = len(last["u"])
+            q.valid, q.proj_u, q.proj_v, q.level = (last[k].ctypes.data for k in ("valid", "u", "v", "octave"))
+            q.angle = last["angle"].ctypes.data; q.desc_mp = last["desc"].ctypes.data; q.mp_has_obs = last["has_obs"].ctypes.data
+            q.assign = assign.ctypes.data; q.occupied = occ.ctypes.data
+        return dict(qs=qs, frames=frames, cases=cases, n=n)
+
+    def run_last_batch(self, prep, th):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono=true) for every case in one launch; returns n_matches per case"""
+        _check(lib.orbm_search_by_projection_last_batch(self._h, prep["qs"], prep["n"], C.c_float(th), int(self.check_ori)))
+        return [q.n_matches for q in prep["qs"]]
+
     class _TriSide(C.Structure):
         _fields_ = [("n", C.c_int32), ("desc", C.c_void_p), ("has_mp", C.c_void_p), ("stereo", C.c_void_p), ("x", C.c_void_p),
                     ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("fv", FeatVec)]

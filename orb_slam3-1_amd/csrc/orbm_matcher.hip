@@ -219,6 +219,7 @@ struct ProjFrameDev {
     const float* scale_factors;
     float min_x, min_y, max_x, max_y, winv, hinv;
     int32_t n, cols, rows;
+    int32_t n_levels = 0;       // > 0: k_proj keeps the scale factors in LDS
 };
 
 constexpr unsigned long long kNoKey = ~0ull;
@@ -230,16 +231,50 @@ __device__ __forceinline__ unsigned long long make_key(int dist, int cell_ord, i
 __device__ __forceinline__ int key_dist(unsigned long long k) { return (int)(k >> 55); }
 __device__ __forceinline__ int key_idx(unsigned long long k) { return (int)(k & 0x1FFFFFull); }
 
+__device__ __forceinline__ unsigned long long read_lane64(unsigned long long v, int l)     // l is wave-uniform
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Wave-wide minimum without LDS traffic: the classic gfx9 DPP ladder (row_shr 1/2/4/8, row_bcast 15, row_bcast 31) leaves
+// the minimum in lane 63.  Lanes without a source keep `old` = identity, so no row / bank masks are needed.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x111, 0xF, 0xF, false));    // row_shr:1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x112, 0xF, 0xF, false));    // row_shr:2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x114, 0xF, 0xF, false));    // row_shr:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x118, 0xF, 0xF, false));    // row_shr:8
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xF, 0xF, false));    // row_bcast:15
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xF, 0xF, false));    // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
+{
+    const unsigned hi = (unsigned)(k >> 32);
+    const unsigned mh = wave_min_u32(hi);
+    const unsigned ml = wave_min_u32(hi == mh ? (unsigned)k : 0xFFFFFFFFu);
+    return ((unsigned long long)mh << 32) | ml;
+}
+
 __device__ __forceinline__ void top2_insert(unsigned long long& k1, unsigned long long& k2, unsigned long long k)
 {
     if (k < k1) { k2 = k1; k1 = k; }
     else if (k < k2) k2 = k;
 }
 
+#ifdef ORBM_PROJ_TIMING      // cycle sums of job 0 (tools/proj_timing.py); never defined in the product build
+__device__ unsigned long long d_proj_prof[8];
+#define ORBM_PTICK(k) if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_now = clock64(); d_proj_prof[k] += (unsigned long long)(t_now - t_prev); t_prev = t_now; }
+#else
+#define ORBM_PTICK(k)
+#endif
+
 // Frame::GetFeaturesInArea (src/Frame.cc:744-810) + the candidate loop of SearchByProjection: returns the two
 // smallest candidates in (distance, visiting order) lexicographic order == the reference's best / second best.
-__device__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float x, float y, float r, int minLevel, int maxLevel,
-                              const uint8_t* dmp, int lane, unsigned long long& best, unsigned long long& second)
+__device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float x, float y, float r, int minLevel, int maxLevel,
+                              const unsigned long long* dq, int lane, int* s_col, unsigned long long& best, unsigned long long& second)
 {
     best = second = kNoKey;
     const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.winv));
@@ -254,8 +289,52 @@ __device__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float
     const int ny = nMaxCellY - nMinCellY + 1, nx = nMaxCellX - nMinCellX + 1;
     const int ncell = nx * ny;
     unsigned long long k1 = kNoKey, k2 = kNoKey;
+#ifdef ORBM_PROJ_TIMING
+    long long t_prev = clock64();
+#endif
+    if (nx <= 16 && F.n < 16384) {
+        // The cells of one grid column are adjacent in the CSR (cell = ix * rows + iy), so a window is nx contiguous runs
+        // of features -- and walking a run front to back IS the reference's visiting order.  The runs are flattened over
+        // the lanes (exclusive prefix of the run lengths by a DPP ladder), which keeps the wave busy even when one cell
+        // holds most of the candidates.
+        int run_b = 0, run_n = 0;
+        if (lane < nx) {
+            const int cell0 = (nMinCellX + lane) * F.rows + nMinCellY;
+            run_b = F.cell_off[cell0];
+            run_n = F.cell_off[cell0 + ny] - run_b;
+        }
+        int inc = run_n;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);        // row_shr:1 .. 8: inclusive prefix over lanes 0..15
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);
+        const int total = __builtin_amdgcn_readlane(inc, nx - 1);
+        if (lane < nx) { s_col[lane] = inc - run_n; s_col[16 + lane] = run_b; }
+        __syncthreads();
+        for (int t = lane; t < total; t += 64) {
+            int cx = 0;
+            for (int k = 1; k < nx; k++) cx += (t >= s_col[k]) ? 1 : 0;
+            const int pos = t - s_col[cx];
+            const int idx = F.cell_feat[s_col[16 + cx] + pos];
+            if (bCheckLevels) {
+                const int oc = F.octave[idx];
+                if (oc < minLevel) continue;
+                if (maxLevel >= 0 && oc > maxLevel) continue;
+            }
+            const float distx = F.x[idx] - x, disty = F.y[idx] - y;
+            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+            if (s_occ[idx]) continue;                                        // mvpMapPoints[idx] && Observations()>0
+            const unsigned long long* db = (const unsigned long long*)(F.desc + (size_t)idx * 32);
+            const int dist = __popcll(dq[0] ^ db[0]) + __popcll(dq[1] ^ db[1]) + __popcll(dq[2] ^ db[2]) + __popcll(dq[3] ^ db[3]);
+            if (dist >= 256) continue;
+            top2_insert(k1, k2, make_key(dist, cx, pos, idx));               // (column, position in its run) = visiting order
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else {
+    const float inv_ny = 1.0f / (float)ny;
     for (int c = lane; c < ncell; c += 64) {
-        const int ix = nMinCellX + c / ny, iy = nMinCellY + c % ny;       // ix outer, iy inner (:774-778)
+        const int cq = (int)(((float)c + 0.5f) * inv_ny);                   // c / ny (exact: c < 2^12, ny <= 2^7)
+        const int ix = nMinCellX + cq, iy = nMinCellY + (c - cq * ny);     // ix outer, iy inner (:774-778)
         const int cell = ix * F.rows + iy;
         const int e0 = F.cell_off[cell], e1 = F.cell_off[cell + 1];
         for (int e = e0; e < e1; e++) {
@@ -268,18 +347,21 @@ __device__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float
             const float distx = F.x[idx] - x, disty = F.y[idx] - y;
             if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
             if (s_occ[idx]) continue;                                        // mvpMapPoints[idx] && Observations()>0
-            const int dist = hamming256(dmp, F.desc + (size_t)idx * 32);
+            const unsigned long long* db = (const unsigned long long*)(F.desc + (size_t)idx * 32);
+            const int dist = __popcll(dq[0] ^ db[0]) + __popcll(dq[1] ^ db[1]) + __popcll(dq[2] ^ db[2]) + __popcll(dq[3] ^ db[3]);
             if (dist >= 256) continue;                                       // never beats the initial bestDist = 256
             top2_insert(k1, k2, make_key(dist, c, e - e0, idx));
         }
     }
-    // wave reduction of (k1, k2) pairs
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
-        top2_insert(k1, k2, o1);
-        top2_insert(k1, k2, o2);
     }
-    best = k1; second = k2;
+    ORBM_PTICK(1)
+    // wave reduction of the (k1, k2) pairs with DPP minimum ladders (no LDS round trips): best, then second best
+    // (keys are unique, so exactly one lane owns the minimum; it promotes its runner-up before the second pass)
+    const unsigned long long b1 = wave_min_u64(k1);
+    if (k1 == b1) { k1 = k2; k2 = kNoKey; }
+    const unsigned long long b2 = (b1 == kNoKey) ? kNoKey : wave_min_u64(k1);
+    best = b1; second = b2;
+    ORBM_PTICK(2)
 }
 
 struct ProjArgs {
@@ -298,44 +380,94 @@ struct ProjArgs {
     int32_t* assign; uint8_t* occupied;
     int32_t* log_feat; int32_t* log_bin;     // M5 rotation log, capacity n_pts
     int32_t* n_matches;
+    int32_t lds_frame;                       // stage the frame (grid, key points, descriptors) in LDS
 };
 
-__global__ __launch_bounds__(64) void k_proj(ProjArgs A)
+// STAGE: the frame fits in LDS (host decides for the whole launch); a compile-time switch so that every frame access in
+// that instantiation is a ds_read (address space known) rather than a flat load through a may-be-LDS pointer.
+template <bool STAGE>
+__global__ __launch_bounds__(64) void k_proj(const ProjArgs* __restrict__ jobs)
 {
-    extern __shared__ uint8_t s_occ[];      // occupancy flags of the frame's features
+    const ProjArgs A = jobs[blockIdx.x];        // one wave per job (frame): jobs are independent, a batch is one launch
+    extern __shared__ __align__(16) uint8_t s_dyn[];
     __shared__ int s_hist[HISTO_LENGTH];
     const int lane = threadIdx.x;
-    const ProjFrameDev& F = A.F;
+    ProjFrameDev F = A.F;
+    // The points are searched one after the other (greedy dependence), so a point costs a chain of dependent reads of
+    // the frame's grid, key points and descriptors.  When the frame fits (49 B per feature + the cell table), it is staged
+    // in LDS once and the chain runs at LDS latency instead of HBM / L2 latency.
+    uint8_t* s_occ = s_dyn;
+    if (STAGE) {
+        const int n = F.n, ncell = F.cols * F.rows;
+        size_t off = ((size_t)n + 15) & ~(size_t)15;
+        uint8_t* s_desc = s_dyn + off; off += (size_t)n * 32;
+        float* s_x = (float*)(s_dyn + off); off += (size_t)n * 4;
+        float* s_y = (float*)(s_dyn + off); off += (size_t)n * 4;
+        int32_t* s_oct = (int32_t*)(s_dyn + off); off += (size_t)n * 4;
+        int32_t* s_cfeat = (int32_t*)(s_dyn + off); off += (size_t)n * 4;
+        int32_t* s_coff = (int32_t*)(s_dyn + off);
+        for (int i = lane; i < n * 8; i += 64) ((uint32_t*)s_desc)[i] = ((const uint32_t*)F.desc)[i];
+        for (int i = lane; i < n; i += 64) { s_x[i] = F.x[i]; s_y[i] = F.y[i]; s_oct[i] = F.octave[i]; }
+        const int nfeat_cells = F.cell_off[ncell];
+        for (int i = lane; i < nfeat_cells; i += 64) s_cfeat[i] = F.cell_feat[i];
+        for (int i = lane; i <= ncell; i += 64) s_coff[i] = F.cell_off[i];
+        F.desc = s_desc; F.x = s_x; F.y = s_y; F.octave = s_oct; F.cell_feat = s_cfeat; F.cell_off = s_coff;
+    }
+    __shared__ float s_scale[32];
+    __shared__ int s_col[32];                   // search_window: run starts / CSR bases of the window's grid columns
+    if (F.n_levels > 0 && F.n_levels <= 32) {
+        if (lane < F.n_levels) s_scale[lane] = F.scale_factors[lane];
+        F.scale_factors = s_scale;
+    }
     for (int i = lane; i < F.n; i += 64) s_occ[i] = A.occupied[i];
     if (lane < HISTO_LENGTH) s_hist[lane] = 0;
     __syncthreads();
     int nmatches = 0, nlog = 0;
     const bool bFactor = A.th != 1.0f;
+    // point data is fetched one point ahead: the loads of point i+1 are in flight while point i walks its window
+    struct Pt { int valid, level, bad; float u, v, depth, vcos; unsigned long long d[4]; };
+    auto load_pt = [&](int i) {
+        Pt p;
+        p.valid = A.valid[i]; p.level = A.level[i]; p.u = A.u[i]; p.v = A.v[i];
+        p.bad = 0; p.depth = 0.f; p.vcos = 0.f;
+        if (!A.last_frame_mode) { p.bad = A.bad[i]; p.depth = A.depth[i]; p.vcos = A.view_cos[i]; }
+        const unsigned long long* dp = (const unsigned long long*)(A.desc + (size_t)i * 32);
+        p.d[0] = dp[0]; p.d[1] = dp[1]; p.d[2] = dp[2]; p.d[3] = dp[3];
+        return p;
+    };
+    Pt nxt;
+    if (A.n_pts > 0) nxt = load_pt(0);
+#ifdef ORBM_PROJ_TIMING
+    long long t_prev = clock64();
+    const long long t_begin = t_prev;
+#endif
     for (int i = 0; i < A.n_pts; i++) {
-        if (!A.valid[i]) continue;
-        float x = A.u[i], y = A.v[i], r;
+        const Pt cur = nxt;
+        if (i + 1 < A.n_pts) nxt = load_pt(i + 1);
+        if (!cur.valid) continue;
+        float x = cur.u, y = cur.v, r;
         int minLevel, maxLevel;
         if (!A.last_frame_mode) {
-            if (A.far_points && A.depth[i] > A.th_far) continue;
-            if (A.bad[i]) continue;
-            const int lvl = A.level[i];
-            r = ((double)A.view_cos[i] > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos (:215-221)
+            if (A.far_points && cur.depth > A.th_far) continue;
+            if (cur.bad) continue;
+            const int lvl = cur.level;
+            r = ((double)cur.vcos > 0.998) ? 2.5f : 4.0f;             // RadiusByViewingCos (:215-221)
             if (bFactor) r *= A.th;
             r = r * F.scale_factors[lvl];
             minLevel = lvl - 1; maxLevel = lvl;
         } else if (A.last_frame_mode == 1) {
             if (x < F.min_x || x > F.max_x) continue;                  // :1711-1714, :1917-1920
             if (y < F.min_y || y > F.max_y) continue;
-            const int oct = A.level[i];
+            const int oct = cur.level;
             r = A.th * F.scale_factors[oct];
             minLevel = oct - 1; maxLevel = oct + 1;
         } else {
-            const int lvl = A.level[i];
+            const int lvl = cur.level;
             r = A.th * F.scale_factors[lvl];                          // :489
             minLevel = lvl - 1; maxLevel = lvl;                        // :509 (KeyFrame::GetFeaturesInArea itself does not filter)
         }
         unsigned long long kb, ks;
-        search_window(F, s_occ, x, y, r, minLevel, maxLevel, A.desc + (size_t)i * 32, lane, kb, ks);
+        search_window(F, s_occ, x, y, r, minLevel, maxLevel, cur.d, lane, s_col, kb, ks);
         if (kb == kNoKey) continue;
         const int bestDist = key_dist(kb), bestIdx = key_idx(kb);
         if ((float)bestDist > A.dist_th) continue;                    // TH_HIGH (:122, :1844), ORBdist (:1967), TH_LOW*ratioHamming (:522)
@@ -359,6 +491,9 @@ __global__ __launch_bounds__(64) void k_proj(ProjArgs A)
         __syncthreads();        // the occupancy update must be seen by the next point's window search
     }
     __syncthreads();
+#ifdef ORBM_PROJ_TIMING
+    if (blockIdx.x == 0 && lane == 0) { d_proj_prof[0] += (unsigned long long)(clock64() - t_begin); d_proj_prof[7] += (unsigned long long)A.n_pts; }
+#endif
     if (A.last_frame_mode == 1 && A.check_ori && lane == 0) {
         int i1, i2, i3;
         three_maxima(s_hist, HISTO_LENGTH, i1, i2, i3);
@@ -806,72 +941,135 @@ static int build_grid(const OrbmFrame* f, std::vector<int32_t>& cell_off, std::v
     return ORBX_OK;
 }
 
+// one projection-search problem (a frame and the points projected into it); host pointers
+struct ProjJob {
+    const OrbmFrame* f;
+    int n_pts;
+    const uint8_t* valid; const float* u; const float* v; const int32_t* level;
+    const float* view_cos; const float* depth; const uint8_t* bad;     // mode 0
+    const float* angle;                                                  // mode 1
+    const uint8_t* desc; const uint8_t* has_obs;
+    int32_t* assign; uint8_t* occupied;
+    int n_matches;      // out
+};
+
+// Packs all jobs into one blob, ONE k_proj launch with a wave per job, copies assign / occupied / counts back.
+static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int last_mode,
+                               float th, int far_points, float th_far, float nnratio, int check_ori, float dist_th)
+{
+    if (!m) return fail(ORBX_ERR_ARG, "NULL matcher");
+    if (!jobs || n_jobs < 1) return fail(ORBX_ERR_ARG, "no jobs");
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    const size_t oargs = blob.reserve(sizeof(orbm::ProjArgs) * (size_t)n_jobs);
+    struct Off { size_t x, y, oct, ang, desc, coff, cfeat, sf, valid, u, v, level, vc, dep, bad, angl, dmp, obs, assign, occ, logf, logb, nm; float winv, hinv; };
+    std::vector<Off> offs(n_jobs);
+    std::vector<int32_t> cell_off, cell_feat;
+    size_t max_n = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        const ProjJob& q = jobs[j];
+        const OrbmFrame* f = q.f;
+        const int n_pts = q.n_pts;
+        if (n_pts < 0 || (n_pts > 0 && (!q.valid || !q.u || !q.v || !q.level || !q.desc))) return fail(ORBX_ERR_ARG, "job %d: NULL point arrays", j);
+        if (last_mode == 0 && n_pts > 0 && (!q.has_obs || !q.view_cos || !q.depth || !q.bad)) return fail(ORBX_ERR_ARG, "job %d: NULL map point arrays", j);
+        if (!q.assign || !q.occupied) return fail(ORBX_ERR_ARG, "job %d: NULL assign/occupied", j);
+        Off& o = offs[j];
+        int r = build_grid(f, cell_off, cell_feat, o.winv, o.hinv);
+        if (r) return r;
+        if (last_mode == 1 && check_ori && n_pts > 0 && (!q.angle || !f->angle)) return fail(ORBX_ERR_ARG, "job %d: NULL angle arrays", j);
+        for (int i = 0; i < n_pts; i++)
+            if (q.valid[i] && (q.level[i] < 0 || q.level[i] >= f->n_levels)) return fail(ORBX_ERR_ARG, "job %d point %d: level %d out of range", j, i, q.level[i]);
+        if ((size_t)f->n + 256 > 150 * 1024) return fail(ORBX_ERR_ARG, "frame with %d features exceeds the LDS occupancy table", f->n);
+        const int n = f->n;
+        max_n = std::max(max_n, (size_t)n);
+        o.x = blob.put(f->x, sizeof(float) * n); o.y = blob.put(f->y, sizeof(float) * n);
+        o.oct = blob.put(f->octave, sizeof(int32_t) * n);
+        o.ang = blob.put(f->angle, f->angle ? sizeof(float) * n : 0);
+        o.desc = blob.put(f->desc, (size_t)n * 32);
+        o.coff = blob.put(cell_off.data(), sizeof(int32_t) * cell_off.size());
+        o.cfeat = blob.put(cell_feat.data(), sizeof(int32_t) * cell_feat.size());
+        o.sf = blob.put(f->scale_factors, sizeof(float) * f->n_levels);
+        o.valid = blob.put(q.valid, n_pts); o.u = blob.put(q.u, sizeof(float) * n_pts); o.v = blob.put(q.v, sizeof(float) * n_pts);
+        o.level = blob.put(q.level, sizeof(int32_t) * n_pts);
+        o.vc = blob.put(q.view_cos, q.view_cos ? sizeof(float) * n_pts : 0); o.dep = blob.put(q.depth, q.depth ? sizeof(float) * n_pts : 0);
+        o.bad = blob.put(q.bad, q.bad ? n_pts : 0); o.angl = blob.put(q.angle, q.angle ? sizeof(float) * n_pts : 0);
+        o.dmp = blob.put(q.desc, (size_t)n_pts * 32); o.obs = blob.put(q.has_obs, q.has_obs ? n_pts : 0);
+        o.logf = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1)); o.logb = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1));
+    }
+    // in/out and output arrays of all jobs sit together at the end: one copy brings every result back
+    const size_t out_begin = (m->h_blob.size() + 15) & ~(size_t)15;
+    for (int j = 0; j < n_jobs; j++) {
+        const ProjJob& q = jobs[j];
+        const int n = q.f->n;
+        Off& o = offs[j];
+        o.assign = blob.put(q.assign, sizeof(int32_t) * n); o.occ = blob.put(q.occupied, n);
+        o.nm = blob.reserve(sizeof(int32_t));
+    }
+    int r = m->ensure(m->h_blob.size());
+    if (r) return r;
+    uint8_t* base = m->d_blob;
+    orbm::ProjArgs* args = (orbm::ProjArgs*)(m->h_blob.data() + oargs);
+    for (int j = 0; j < n_jobs; j++) {
+        const ProjJob& q = jobs[j];
+        const OrbmFrame* f = q.f;
+        const Off& o = offs[j];
+        orbm::ProjArgs A;
+        A.F.x = (const float*)(base + o.x); A.F.y = (const float*)(base + o.y); A.F.octave = (const int32_t*)(base + o.oct);
+        A.F.angle = (const float*)(base + o.ang); A.F.desc = base + o.desc;
+        A.F.cell_off = (const int32_t*)(base + o.coff); A.F.cell_feat = (const int32_t*)(base + o.cfeat);
+        A.F.scale_factors = (const float*)(base + o.sf);
+        A.F.min_x = f->min_x; A.F.min_y = f->min_y; A.F.max_x = f->max_x; A.F.max_y = f->max_y; A.F.winv = o.winv; A.F.hinv = o.hinv;
+        A.F.n = f->n; A.F.cols = f->grid_cols; A.F.rows = f->grid_rows; A.F.n_levels = f->n_levels;
+        A.n_pts = q.n_pts; A.valid = base + o.valid; A.u = (const float*)(base + o.u); A.v = (const float*)(base + o.v);
+        A.level = (const int32_t*)(base + o.level); A.view_cos = (const float*)(base + o.vc); A.depth = (const float*)(base + o.dep);
+        A.bad = base + o.bad; A.angle = (const float*)(base + o.angl); A.desc = base + o.dmp; A.has_obs = q.has_obs ? base + o.obs : nullptr;
+        A.dist_th = dist_th;
+        A.th = th; A.th_far = th_far; A.nnratio = nnratio; A.far_points = far_points; A.check_ori = check_ori; A.last_frame_mode = last_mode;
+        A.assign = (int32_t*)(base + o.assign); A.occupied = base + o.occ;
+        A.log_feat = (int32_t*)(base + o.logf); A.log_bin = (int32_t*)(base + o.logb); A.n_matches = (int32_t*)(base + o.nm);
+        args[j] = A;
+    }
+    size_t max_cells = 0;
+    for (int j = 0; j < n_jobs; j++) max_cells = std::max(max_cells, (size_t)jobs[j].f->grid_cols * jobs[j].f->grid_rows);
+    const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64);
+    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 48 + (max_cells + 1) * 4 + 64;
+    const bool stage = lds_full <= 150 * 1024;
+    const size_t lds = stage ? lds_full : lds_occ;
+    for (int j = 0; j < n_jobs; j++) args[j].lds_frame = stage ? 1 : 0;
+    ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), m->h_blob.size(), hipMemcpyHostToDevice, m->stream));
+    if (stage) {
+        ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(orbm::k_proj<true>, dim3(n_jobs), dim3(64), lds, m->stream, (const orbm::ProjArgs*)(base + oargs));
+    } else {
+        ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(orbm::k_proj<false>, dim3(n_jobs), dim3(64), lds, m->stream, (const orbm::ProjArgs*)(base + oargs));
+    }
+    ORBM_HIP(hipGetLastError());
+    ORBM_HIP(hipMemcpyAsync(m->h_blob.data() + out_begin, base + out_begin, m->h_blob.size() - out_begin, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    for (int j = 0; j < n_jobs; j++) {
+        const Off& o = offs[j];
+        const int n = jobs[j].f->n;
+        if (n > 0) {
+            std::memcpy(jobs[j].assign, m->h_blob.data() + o.assign, sizeof(int32_t) * n);
+            std::memcpy(jobs[j].occupied, m->h_blob.data() + o.occ, n);
+        }
+        std::memcpy(&jobs[j].n_matches, m->h_blob.data() + o.nm, sizeof(int32_t));
+    }
+    return ORBX_OK;
+}
+
 static int run_projection(orbm_matcher* m, const OrbmFrame* f, int last_mode, int n_pts, const uint8_t* valid,
                           const float* u, const float* v, const int32_t* level, const float* view_cos, const float* depth,
                           const uint8_t* bad, const float* angle, const uint8_t* desc, const uint8_t* has_obs,
                           float th, int far_points, float th_far, float nnratio, int check_ori,
                           int32_t* assign, uint8_t* occupied, float dist_th = (float)orbm::TH_HIGH)
 {
-    if (!m) return fail(ORBX_ERR_ARG, "NULL matcher");
-    if (n_pts < 0 || (n_pts > 0 && (!valid || !u || !v || !level || !desc))) return fail(ORBX_ERR_ARG, "NULL point arrays");
-    if (last_mode == 0 && n_pts > 0 && !has_obs) return fail(ORBX_ERR_ARG, "NULL has_obs");
-    if (!last_mode && n_pts > 0 && (!view_cos || !depth || !bad)) return fail(ORBX_ERR_ARG, "NULL map point arrays");
-    if (last_mode == 1 && check_ori && n_pts > 0 && (!angle || !f->angle)) return fail(ORBX_ERR_ARG, "NULL angle arrays");
-    if (!assign || !occupied) return fail(ORBX_ERR_ARG, "NULL assign/occupied");
-    std::vector<int32_t> cell_off, cell_feat;
-    float winv, hinv;
-    int r = build_grid(f, cell_off, cell_feat, winv, hinv);
-    if (r) return r;
-    for (int i = 0; i < n_pts; i++)
-        if (valid[i] && (level[i] < 0 || level[i] >= f->n_levels)) return fail(ORBX_ERR_ARG, "point %d: level %d out of range", i, level[i]);
-    if ((size_t)f->n + 256 > 150 * 1024) return fail(ORBX_ERR_ARG, "frame with %d features exceeds the LDS occupancy table", f->n);
-    ORBM_HIP(hipSetDevice(m->device));
-    Blob blob(m->h_blob);
-    const int n = f->n;
-    const size_t ox = blob.put(f->x, sizeof(float) * n), oy = blob.put(f->y, sizeof(float) * n);
-    const size_t ooct = blob.put(f->octave, sizeof(int32_t) * n);
-    const size_t oang = blob.put(f->angle, f->angle ? sizeof(float) * n : 0);
-    const size_t odesc = blob.put(f->desc, (size_t)n * 32);
-    const size_t ocoff = blob.put(cell_off.data(), sizeof(int32_t) * cell_off.size());
-    const size_t ocfeat = blob.put(cell_feat.data(), sizeof(int32_t) * cell_feat.size());
-    const size_t osf = blob.put(f->scale_factors, sizeof(float) * f->n_levels);
-    const size_t ovalid = blob.put(valid, n_pts), ou = blob.put(u, sizeof(float) * n_pts), ov = blob.put(v, sizeof(float) * n_pts);
-    const size_t olevel = blob.put(level, sizeof(int32_t) * n_pts);
-    const size_t ovc = blob.put(view_cos, view_cos ? sizeof(float) * n_pts : 0), odep = blob.put(depth, depth ? sizeof(float) * n_pts : 0);
-    const size_t obad = blob.put(bad, bad ? n_pts : 0), oangl = blob.put(angle, angle ? sizeof(float) * n_pts : 0);
-    const size_t odmp = blob.put(desc, (size_t)n_pts * 32), oobs = blob.put(has_obs, has_obs ? n_pts : 0);
-    const size_t oassign = blob.put(assign, sizeof(int32_t) * n), oocc = blob.put(occupied, n);
-    const size_t ologf = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1)), ologb = blob.reserve(sizeof(int32_t) * std::max(n_pts, 1));
-    const size_t onm = blob.reserve(sizeof(int32_t));
-    if ((r = m->ensure(m->h_blob.size()))) return r;
-    uint8_t* base = m->d_blob;
-    orbm::ProjArgs A;
-    A.F.x = (const float*)(base + ox); A.F.y = (const float*)(base + oy); A.F.octave = (const int32_t*)(base + ooct);
-    A.F.angle = (const float*)(base + oang); A.F.desc = base + odesc;
-    A.F.cell_off = (const int32_t*)(base + ocoff); A.F.cell_feat = (const int32_t*)(base + ocfeat);
-    A.F.scale_factors = (const float*)(base + osf);
-    A.F.min_x = f->min_x; A.F.min_y = f->min_y; A.F.max_x = f->max_x; A.F.max_y = f->max_y; A.F.winv = winv; A.F.hinv = hinv;
-    A.F.n = n; A.F.cols = f->grid_cols; A.F.rows = f->grid_rows;
-    A.n_pts = n_pts; A.valid = base + ovalid; A.u = (const float*)(base + ou); A.v = (const float*)(base + ov);
-    A.level = (const int32_t*)(base + olevel); A.view_cos = (const float*)(base + ovc); A.depth = (const float*)(base + odep);
-    A.bad = base + obad; A.angle = (const float*)(base + oangl); A.desc = base + odmp; A.has_obs = has_obs ? base + oobs : nullptr;
-    A.dist_th = dist_th;
-    A.th = th; A.th_far = th_far; A.nnratio = nnratio; A.far_points = far_points; A.check_ori = check_ori; A.last_frame_mode = last_mode;
-    A.assign = (int32_t*)(base + oassign); A.occupied = base + oocc;
-    A.log_feat = (int32_t*)(base + ologf); A.log_bin = (int32_t*)(base + ologb); A.n_matches = (int32_t*)(base + onm);
-    const size_t lds = ((size_t)n + 63) & ~(size_t)63;
-    ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)64)));
-    ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), m->h_blob.size(), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(orbm::k_proj, dim3(1), dim3(64), std::max(lds, (size_t)64), m->stream, A);
-    ORBM_HIP(hipGetLastError());
-    int nm = 0;
-    if (n > 0) {
-        ORBM_HIP(hipMemcpyAsync(assign, base + oassign, sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
-        ORBM_HIP(hipMemcpyAsync(occupied, base + oocc, n, hipMemcpyDeviceToHost, m->stream));
-    }
-    ORBM_HIP(hipMemcpyAsync(&nm, base + onm, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-    ORBM_HIP(hipStreamSynchronize(m->stream));
-    return nm;
+    ProjJob q;
+    q.f = f; q.n_pts = n_pts; q.valid = valid; q.u = u; q.v = v; q.level = level; q.view_cos = view_cos; q.depth = depth; q.bad = bad;
+    q.angle = angle; q.desc = desc; q.has_obs = has_obs; q.assign = assign; q.occupied = occupied; q.n_matches = 0;
+    const int r = run_projection_jobs(m, &q, 1, last_mode, th, far_points, th_far, nnratio, check_ori, dist_th);
+    return r ? r : q.n_matches;
 }
 
 extern "C" {
@@ -1073,6 +1271,46 @@ int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
     return run_projection(m, cur, 1, n_last, last_valid, proj_u, proj_v, last_octave, nullptr, nullptr, nullptr, last_angle,
                           desc_mp, mp_has_obs, th, 0, 0.f, 0.f, check_orientation, assign, occupied);
 }
+
+// Batched forms: n_frames independent (frame, points) problems in ONE launch, a wave per frame.
+static int run_projection_batch(orbm_matcher* m, OrbmProjQuery* q, int n_frames, int mode, float th, int far_points, float th_far,
+                                float nnratio, int check_ori, float dist_th)
+{
+    if (!q || n_frames < 1) return fail(ORBX_ERR_ARG, "no queries");
+    std::vector<ProjJob> jobs(n_frames);
+    for (int j = 0; j < n_frames; j++) {
+        ProjJob& p = jobs[j];
+        p.f = q[j].frame; p.n_pts = q[j].n_pts; p.valid = q[j].valid; p.u = q[j].proj_u; p.v = q[j].proj_v; p.level = q[j].level;
+        p.view_cos = q[j].view_cos; p.depth = q[j].track_depth; p.bad = q[j].mp_bad; p.angle = q[j].angle; p.desc = q[j].desc_mp;
+        p.has_obs = q[j].mp_has_obs; p.assign = q[j].assign; p.occupied = q[j].occupied; p.n_matches = 0;
+        if (!p.f) return fail(ORBX_ERR_ARG, "query %d: NULL frame", j);
+        if (mode == 1 && p.n_pts > 0 && !p.has_obs) return fail(ORBX_ERR_ARG, "query %d: NULL mp_has_obs", j);
+    }
+    const int r = run_projection_jobs(m, jobs.data(), n_frames, mode, th, far_points, th_far, nnratio, check_ori, dist_th);
+    if (r) return r;
+    for (int j = 0; j < n_frames; j++) q[j].n_matches = jobs[j].n_matches;
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection_last_batch(orbm_matcher* m, OrbmProjQuery* queries, int n_frames, float th, int check_orientation)
+{
+    return run_projection_batch(m, queries, n_frames, 1, th, 0, 0.f, 0.f, check_orientation, (float)orbm::TH_HIGH);
+}
+
+int orbm_search_by_projection_batch(orbm_matcher* m, OrbmProjQuery* queries, int n_frames, float th, int far_points, float th_far, float nnratio)
+{
+    return run_projection_batch(m, queries, n_frames, 0, th, far_points, th_far, nnratio, 0, (float)orbm::TH_HIGH);
+}
+
+#ifdef ORBM_PROJ_TIMING
+int orbm_debug_proj_prof(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(orbm::d_proj_prof), sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(orbm::d_proj_prof), z, sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    return ORBX_OK;
+}
+#endif
 
 int orbm_search_by_projection_kf(orbm_matcher* m, const OrbmFrame* cur,
                                  int n_pts, const uint8_t* valid, const float* proj_u, const float* proj_v,

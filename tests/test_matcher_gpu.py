@@ -202,3 +202,24 @@ def test_search_for_initialization(pkg, oracle, sm, seed, win, ratio, ori):
     np.testing.assert_array_equal(m1, m0)
     assert n0 == int((m0 >= 0).sum())
     assert len(set(m0[m0 >= 0])) == n0                   # one-to-one after the stealing
+
+
+def test_search_by_projection_last_batch(pkg, oracle, sm):
+    """a wave per frame: the batched launch equals the per-frame oracle runs (ragged sizes, an empty query)"""
+    cases, refs = [], []
+    for i, (n, nl) in enumerate(((1000, 900), (400, 700), (1000, 0), (1500, 1200), (64, 50))):
+        g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(30 + i, n=n, n_last=max(nl, 1))
+        if nl == 0:
+            last = {k: v[:0].copy() for k, v in last.items()}
+        a0, o0 = assign.copy(), occ.copy()
+        n0 = oracle.search_by_projection_last(g, dF, angF, scale, last, 15.0, True, a0, o0)
+        refs.append((n0, a0, o0))
+        cases.append((g, dF, angF, scale, last, assign.copy(), occ.copy()))
+    m = pkg.Matcher(0.9, True)
+    try:
+        ns = m.run_last_batch(m.prepare_last_batch(cases), 15.0)
+    finally:
+        m.close()
+    for (n0, a0, o0), n1, c in zip(refs, ns, cases):
+        assert n1 == n0
+        np.testing.assert_array_equal(c[5], a0); np.testing.assert_array_equal(c[6], o0)
