@@ -364,6 +364,12 @@ __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8
     ORBM_PTICK(2)
 }
 
+// ---- Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:472-503, 812-822) on the device ---------------------
+// One workgroup per frame: key = (cell, feature index), bitonic sort in LDS -> the CSR the window searches walk
+// (features of a cell in insertion order = ascending index), cell offsets by binary search over the sorted keys.
+struct ProjArgs;
+__global__ __launch_bounds__(256) void k_grid(const ProjArgs* __restrict__ jobs, int n_pow2);
+
 struct ProjArgs {
     ProjFrameDev F;
     int32_t n_pts;
@@ -382,6 +388,40 @@ struct ProjArgs {
     int32_t* n_matches;
     int32_t lds_frame;                       // stage the frame (grid, key points, descriptors) in LDS
 };
+
+__global__ __launch_bounds__(256) void k_grid(const ProjArgs* __restrict__ jobs, int n_pow2)
+{
+    extern __shared__ __align__(16) unsigned long long s_gkey[];
+    const ProjFrameDev F = jobs[blockIdx.x].F;
+    const int tid = threadIdx.x, n = F.n, ncell = F.cols * F.rows;
+    int32_t* cell_off = const_cast<int32_t*>(F.cell_off);
+    int32_t* cell_feat = const_cast<int32_t*>(F.cell_feat);
+    for (int i = tid; i < n_pow2; i += 256) {
+        unsigned long long key = ~0ull;
+        if (i < n) {
+            const int px = (int)roundf((F.x[i] - F.min_x) * F.winv), py = (int)roundf((F.y[i] - F.min_y) * F.hinv);      // PosInGrid
+            if (px >= 0 && px < F.cols && py >= 0 && py < F.rows) key = ((unsigned long long)(px * F.rows + py) << 32) | (unsigned)i;
+        }
+        s_gkey[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n_pow2 >> 1); t += 256) {
+                const int lo = 2 * t - (t & (j - 1)), hi = lo + j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long a = s_gkey[lo], b = s_gkey[hi];
+                if ((a > b) == up) { s_gkey[lo] = b; s_gkey[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += 256) if (s_gkey[i] != ~0ull) cell_feat[i] = (int32_t)(s_gkey[i] & 0xFFFFFFFFull);
+    for (int c = tid; c <= ncell; c += 256) {            // cell_off[c] = number of keys with cell < c
+        int lo = 0, hi = n_pow2;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((s_gkey[mid] >> 32) < (unsigned long long)c) lo = mid + 1; else hi = mid; }
+        cell_off[c] = lo;
+    }
+}
 
 // STAGE: the frame fits in LDS (host decides for the whole launch); a compile-time switch so that every frame access in
 // that instantiation is a ds_read (address space known) rather than a flat load through a may-be-LDS pointer.
@@ -729,10 +769,11 @@ __global__ __launch_bounds__(64) void k_initialization(InitArgs A)
                 top2_insert(k1, k2, make_key(dist, c, e - e0, idx));
             }
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
-            top2_insert(k1, k2, o1);
-            top2_insert(k1, k2, o2);
+        {   // best / second best of the wave by DPP minimum ladders (see search_window)
+            const unsigned long long b1 = wave_min_u64(k1);
+            if (k1 == b1) { k1 = k2; k2 = kNoKey; }
+            const unsigned long long b2 = (b1 == kNoKey) ? kNoKey : wave_min_u64(k1);
+            k1 = b1; k2 = b2;
         }
         if (k1 == kNoKey) continue;
         const int bestDist = key_dist(k1), bestIdx2 = key_idx(k1);
@@ -966,6 +1007,8 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
     std::vector<Off> offs(n_jobs);
     std::vector<int32_t> cell_off, cell_feat;
     size_t max_n = 0;
+    bool device_grid = true;        // Frame::AssignFeaturesToGrid on the device (k_grid) when every frame fits its LDS sort
+    for (int j = 0; j < n_jobs; j++) device_grid = device_grid && jobs[j].f && jobs[j].f->n <= 8192;
     for (int j = 0; j < n_jobs; j++) {
         const ProjJob& q = jobs[j];
         const OrbmFrame* f = q.f;
@@ -974,8 +1017,16 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
         if (last_mode == 0 && n_pts > 0 && (!q.has_obs || !q.view_cos || !q.depth || !q.bad)) return fail(ORBX_ERR_ARG, "job %d: NULL map point arrays", j);
         if (!q.assign || !q.occupied) return fail(ORBX_ERR_ARG, "job %d: NULL assign/occupied", j);
         Off& o = offs[j];
-        int r = build_grid(f, cell_off, cell_feat, o.winv, o.hinv);
-        if (r) return r;
+        int r;
+        if (device_grid) {      // validation and the two reciprocals only: the CSR itself is built by k_grid
+            if (!f || f->n < 0 || f->grid_cols < 1 || f->grid_rows < 1 || f->grid_cols * (int64_t)f->grid_rows > (1 << 20)) return fail(ORBX_ERR_ARG, "bad frame grid");
+            if (f->n > 0 && (!f->x || !f->y || !f->octave || !f->desc)) return fail(ORBX_ERR_ARG, "NULL frame arrays");
+            if (!f->scale_factors || f->n_levels < 1) return fail(ORBX_ERR_ARG, "NULL scale factors");
+            o.winv = (float)f->grid_cols / (f->max_x - f->min_x);
+            o.hinv = (float)f->grid_rows / (f->max_y - f->min_y);
+            cell_off.assign((size_t)f->grid_cols * f->grid_rows + 1, 0);
+            cell_feat.assign(std::max(f->n, 1), 0);
+        } else if ((r = build_grid(f, cell_off, cell_feat, o.winv, o.hinv))) return r;
         if (last_mode == 1 && check_ori && n_pts > 0 && (!q.angle || !f->angle)) return fail(ORBX_ERR_ARG, "job %d: NULL angle arrays", j);
         for (int i = 0; i < n_pts; i++)
             if (q.valid[i] && (q.level[i] < 0 || q.level[i] >= f->n_levels)) return fail(ORBX_ERR_ARG, "job %d point %d: level %d out of range", j, i, q.level[i]);
@@ -1037,6 +1088,12 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
     const size_t lds = stage ? lds_full : lds_occ;
     for (int j = 0; j < n_jobs; j++) args[j].lds_frame = stage ? 1 : 0;
     ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), m->h_blob.size(), hipMemcpyHostToDevice, m->stream));
+    if (device_grid) {
+        int n_pow2 = 2;
+        while ((size_t)n_pow2 < max_n) n_pow2 <<= 1;
+        ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_grid, hipFuncAttributeMaxDynamicSharedMemorySize, n_pow2 * 8));
+        hipLaunchKernelGGL(orbm::k_grid, dim3(n_jobs), dim3(256), (size_t)n_pow2 * 8, m->stream, (const orbm::ProjArgs*)(base + oargs), n_pow2);
+    }
     if (stage) {
         ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(orbm::k_proj<true>, dim3(n_jobs), dim3(64), lds, m->stream, (const orbm::ProjArgs*)(base + oargs));
