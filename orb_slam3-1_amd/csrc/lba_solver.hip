@@ -398,7 +398,10 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S,
     // Register-resident: thread (ty, tx) of a 16 x 16 grid owns the elements (ty + 16a, tx + 16b), a, b < 4, of the
     // 64 x 64-padded block L and of X = L^-1.  Per column j one barrier: the owners publish column j of L, row j of X
     // and the pivot through double-buffered LDS vectors; everybody then updates its registers.
-    __shared__ double s_col[2][64], s_row[2][64], s_piv[2];
+    // TWO columns per barrier: the owners publish the raw columns j, j+1 of L and rows j, j+1 of X; every thread then
+    // forms the 2x2 pivot factor itself and applies the rank-2 update  L -= u0 v0^T + u1 v1^T,  X -= u0 x0^T + u1 x1^T.
+    // (The block size nb is even: 6 rows per pose.)
+    __shared__ double s_col0[2][64], s_col1[2][64], s_row0[2][64], s_row1[2][64];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     double Lr[4][4], Xr[4][4];
 #pragma unroll
@@ -410,66 +413,101 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S,
             Xr[a][b] = (r == c) ? 1.0 : 0.0;
         }
     bool failed = false;
+    const int nb2 = (nb + 1) & ~1;          // an odd tail column pairs with the identity padding
 #pragma unroll
     for (int ja = 0; ja < 4; ja++) {
-        for (int jy = 0; jy < 16; jy++) {
-            const int j = 16 * ja + jy;
-            if (j >= nb || failed) break;
-            const int p = j & 1;
+        for (int jy = 0; jy < 16; jy += 2) {
+            const int j0 = 16 * ja + jy, j1 = j0 + 1;
+            if (j0 >= nb2 || failed) break;
+            const int p = (jy >> 1) & 1;
             if (tx == jy) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) s_col[p][ty + 16 * a] = Lr[a][ja];
-                if (ty == jy) s_piv[p] = Lr[ja][ja];
+                for (int a = 0; a < 4; a++) s_col0[p][ty + 16 * a] = Lr[a][ja];
+            }
+            if (tx == jy + 1) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) s_col1[p][ty + 16 * a] = Lr[a][ja];
             }
             if (ty == jy) {
 #pragma unroll
-                for (int b = 0; b < 4; b++) s_row[p][tx + 16 * b] = Xr[ja][b];
+                for (int b = 0; b < 4; b++) s_row0[p][tx + 16 * b] = Xr[ja][b];
+            }
+            if (ty == jy + 1) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) s_row1[p][tx + 16 * b] = Xr[ja][b];
             }
             __syncthreads();
-            const double djj = s_piv[p];
-            if (!(djj > 0.0) || !isfinite(djj)) { failed = true; break; }      // uniform: same value in every thread
-            // 1/sqrt(d) from the hardware estimate + two Newton steps, sqrt(d) = d * (1/sqrt(d)) + one Heron correction:
-            // ~1 ulp, and far shorter than the correctly rounded f64 sqrt + divide on the critical path of every column
-            double inv = __builtin_amdgcn_rsq(djj);
-            inv = inv * fma(-0.5 * djj * inv, inv, 1.5);
-            inv = inv * fma(-0.5 * djj * inv, inv, 1.5);
-            double ljj = djj * inv;
-            ljj = fma(fma(-ljj, ljj, djj), 0.5 * inv, ljj);
-            // ja (= j / 16) is a compile-time constant inside the unrolled outer loop, so whole register tiles drop out:
-            // rows a < ja are finished, L-updates only touch columns b >= ja (and b <= a), X-updates only columns b <= ja.
-            double lr[4], lc[4], xc[4];
+            const double d0 = s_col0[p][j0], e10 = s_col0[p][j1], d1raw = s_col1[p][j1];
+            if (!(d0 > 0.0) || !isfinite(d0)) { failed = true; break; }        // uniform: same values in every thread
+            // 1/sqrt(d) from the hardware estimate + two Newton steps, sqrt(d) = d * (1/sqrt(d)) + one Heron correction
+            double inv0 = __builtin_amdgcn_rsq(d0);
+            inv0 = inv0 * fma(-0.5 * d0 * inv0, inv0, 1.5);
+            inv0 = inv0 * fma(-0.5 * d0 * inv0, inv0, 1.5);
+            double l00 = d0 * inv0;
+            l00 = fma(fma(-l00, l00, d0), 0.5 * inv0, l00);
+            const double l10 = e10 * inv0;
+            const double d1 = fma(-l10, l10, d1raw);
+            if (!(d1 > 0.0) || !isfinite(d1)) { failed = true; break; }
+            double inv1 = __builtin_amdgcn_rsq(d1);
+            inv1 = inv1 * fma(-0.5 * d1 * inv1, inv1, 1.5);
+            inv1 = inv1 * fma(-0.5 * d1 * inv1, inv1, 1.5);
+            double l11 = d1 * inv1;
+            l11 = fma(fma(-l11, l11, d1), 0.5 * inv1, l11);
+            // ja is a compile-time constant inside the unrolled outer loop, so whole register tiles drop out
+            double u0[4], u1[4], v0[4], v1[4], x0[4], x1[4];
 #pragma unroll
-            for (int a = 0; a < 4; a++) lr[a] = (a >= ja) ? s_col[p][ty + 16 * a] * inv : 0.0;
+            for (int a = 0; a < 4; a++) {
+                u0[a] = 0.0; u1[a] = 0.0;
+                if (a >= ja) {
+                    u0[a] = s_col0[p][ty + 16 * a] * inv0;
+                    u1[a] = fma(-u0[a], l10, s_col1[p][ty + 16 * a]) * inv1;
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                lc[b] = (b >= ja) ? s_col[p][tx + 16 * b] * inv : 0.0;
-                xc[b] = (b <= ja) ? s_row[p][tx + 16 * b] * inv : 0.0;
+                v0[b] = 0.0; v1[b] = 0.0; x0[b] = 0.0; x1[b] = 0.0;
+                if (b >= ja) {
+                    v0[b] = s_col0[p][tx + 16 * b] * inv0;
+                    v1[b] = fma(-v0[b], l10, s_col1[p][tx + 16 * b]) * inv1;
+                }
+                if (b <= ja) {
+                    x0[b] = s_row0[p][tx + 16 * b] * inv0;
+                    x1[b] = fma(-l10, x0[b], s_row1[p][tx + 16 * b]) * inv1;
+                }
             }
 #pragma unroll
             for (int a = 0; a < 4; a++) {
                 if (a < ja) continue;
                 const int r = ty + 16 * a;
-                const bool ra = r > j;
+                const bool ra = r > j1;             // rows below both pivots take the rank-2 update
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const int c = tx + 16 * b;
                     if (b > ja) {
-                        if (b <= a && ra && c <= r) Lr[a][b] -= lr[a] * lc[b];          // c > j holds for every b > ja
+                        if (b <= a && ra && c <= r) Lr[a][b] -= fma(u1[a], v1[b], u0[a] * v0[b]);      // c > j1 holds for every b > ja
                     } else if (b < ja) {
-                        if (ra) Xr[a][b] -= lr[a] * xc[b];                              // c <= j holds for every b < ja
+                        if (ra) Xr[a][b] -= fma(u1[a], x1[b], u0[a] * x0[b]);                          // c <= j0 holds for every b < ja
                     } else if (ra) {
-                        if (c > j) { if (c <= r) Lr[a][b] -= lr[a] * lc[b]; }
-                        else Xr[a][b] -= lr[a] * xc[b];
+                        if (c > j1) { if (c <= r) Lr[a][b] -= fma(u1[a], v1[b], u0[a] * v0[b]); }
+                        else Xr[a][b] -= fma(u1[a], x1[b], u0[a] * x0[b]);                             // x0[j1] = 0: column j1 only sees u1 x1
                     }
                 }
             }
             if (tx == jy) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) { const int r = ty + 16 * a; if (r > j) Lr[a][ja] = lr[a]; else if (r == j) Lr[a][ja] = ljj; }
+                for (int a = 0; a < 4; a++) { const int r = ty + 16 * a; if (r > j0) Lr[a][ja] = u0[a]; else if (r == j0) Lr[a][ja] = l00; }
+            }
+            if (tx == jy + 1) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) { const int r = ty + 16 * a; if (r > j1) Lr[a][ja] = u1[a]; else if (r == j1) Lr[a][ja] = l11; }
             }
             if (ty == jy) {
 #pragma unroll
-                for (int b = 0; b < 4; b++) { if (tx + 16 * b <= j) Xr[ja][b] = xc[b]; }
+                for (int b = 0; b < 4; b++) { if (tx + 16 * b <= j0) Xr[ja][b] = x0[b]; }
+            }
+            if (ty == jy + 1) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) { if (tx + 16 * b <= j1) Xr[ja][b] = x1[b]; }
             }
         }
     }
