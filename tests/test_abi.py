@@ -53,6 +53,27 @@ def test_no_device_fails_loudly(pkg):
         pkg.Matcher()
     with pytest.raises(pkg.OrbxError):
         pkg.LbaSolver()
+    with pytest.raises(pkg.OrbxError) as e:
+        pkg.PoseSolver()
+    assert e.value.code == -4
+    synth = __import__("importlib").import_module("orb_slam3-1_amd.synth")
+    with pytest.raises(pkg.OrbxError) as e:
+        pkg.Vocabulary(synth.make_vocabulary(0, k=4, L=2))
+    assert e.value.code == -4
+
+
+def test_malformed_vocabulary_rejected(pkg):
+    """orbv_create validates the flattened tree before any device work (argument errors come first, also without a GPU)"""
+    synth = __import__("importlib").import_module("orb_slam3-1_amd.synth")
+    voc = synth.make_vocabulary(0, k=4, L=2)
+    bad = dict(voc); bad["child_id"] = voc["child_id"].copy(); bad["child_id"][0] = voc["n_nodes"] + 5
+    with pytest.raises(pkg.OrbxError) as e:
+        pkg.Vocabulary(bad)
+    assert e.value.code == -3
+    bad = dict(voc); bad["child_off"] = voc["child_off"].copy(); bad["child_off"][1] = 0          # the root has no children
+    with pytest.raises(pkg.OrbxError) as e:
+        pkg.Vocabulary(bad)
+    assert e.value.code == -3
 
 
 def test_bad_arguments_rejected(pkg):
