@@ -330,6 +330,34 @@ def main():
                 vstep()
             torch.cuda.synchronize()
             dtv = (time.perf_counter() - t0) / 10
+            # ---- the whole front end as one device-resident chain: extract -> vocabulary transform -> SearchByBoW between
+            # consecutive frames (frame 2i = the "key frame", frame 2i+1 = the same scene moved by 3 px), no host round trip ----
+            pair_imgs = np.stack([np.roll(host_imgs[(i // 2) % n_distinct], 3 * (i % 2), axis=1) for i in range(B)])
+            d_pairs = torch.from_numpy(np.ascontiguousarray(pair_imgs)).to(dev)
+            c_match = torch.zeros((B // 2) * cap, dtype=torch.int32, device=dev); c_nm = torch.zeros(B // 2, dtype=torch.int32, device=dev)
+
+            def cside(b):
+                return dict(desc=d_desc.data_ptr() + b * cap * 32, kps=d_kps.data_ptr() + b * cap * 28, n=d_n.data_ptr() + 4 * b, cap=cap,
+                            fv_node=v_fn.data_ptr() + 4 * b * cap, fv_off=v_fo.data_ptr() + 4 * b * (cap + 1), fv_feat=v_ff.data_ptr() + 4 * b * cap,
+                            n_fv_nodes=v_nf.data_ptr() + 4 * b)
+            cplan = pkg.DeviceBowPlan(matcher, [(cside(2 * i), cside(2 * i + 1), c_match.data_ptr() + 4 * i * cap, c_nm.data_ptr() + 4 * i)
+                                                for i in range(B // 2)])
+
+            def cstep():
+                ex.extract_batch_device(d_pairs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                        d_n.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
+                vstep()
+                cplan.run(stream)
+            cstep(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                cstep()
+            torch.cuda.synchronize()
+            dtc_ = (time.perf_counter() - t0) / 10
+            out["chain"] = {"metric": "device-resident front end frames/s (extract + DBoW2 transform + SearchByBoW vs previous frame)",
+                            "value": B / dtc_, "unit": "frames/s", "ms_per_batch": 1e3 * dtc_,
+                            "bow_matches_per_pair": float(c_nm.float().mean().item()), "workload": "%d frames = %d consecutive pairs" % (B, B // 2)}
+            cplan.close()
             out["vocab"] = {"metric": "DBoW2 transform frames/s", "value": B / dtv, "unit": "frames/s", "dtype": "u8/f64",
                             "workload": "%d frames x %.0f descriptors through a k=10, L=6 tree (1.1 M nodes), levelsup 4, BowVector + FeatureVector" % (B, n_kp),
                             "ms_per_batch": 1e3 * dtv, "words_per_frame": float(v_nb.float().mean().item())}

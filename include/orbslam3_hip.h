@@ -160,6 +160,22 @@ int orbm_bow_plan_run(orbm_bow_plan* plan, float nnratio, int check_orientation,
 int orbm_bow_plan_fetch(orbm_bow_plan* plan, OrbmBowPair* pairs, void* stream);
 void orbm_bow_plan_destroy(orbm_bow_plan* plan);
 
+/* Fully device-resident pairs: descriptors / key points as orbx_extract_batch_device wrote them, feature vectors as
+ * orbv_transform_batch_device wrote them, counts read from device memory at run time -- extract -> transform -> SearchByBoW
+ * without a host round trip.  `valid` may be NULL (every KF feature holds a good MapPoint).  fetch() is not used with such a
+ * plan: match_f2kf[cap] / n_matches are the caller's device arrays. */
+typedef struct OrbmBowSideDevice {
+    const uint8_t* desc; const OrbxKeyPoint* kps; const int32_t* n; int32_t cap;      /* extractor outputs of one frame */
+    const uint8_t* valid;                                                                /* KF side only, may be NULL */
+    const uint32_t* fv_node; const int32_t* fv_off; const uint32_t* fv_feat; const int32_t* n_fv_nodes;   /* transform outputs */
+} OrbmBowSideDevice;
+typedef struct OrbmBowPairDevice {
+    OrbmBowSideDevice kf, f;
+    int32_t* match_f2kf;    /* device, f.cap entries */
+    int32_t* n_matches;     /* device */
+} OrbmBowPairDevice;
+int orbm_bow_plan_create_device(orbm_matcher* m, const OrbmBowPairDevice* pairs, int n_pairs, orbm_bow_plan** out);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:765-905).
  * match12[n1] = feature index in KF2 or -1.  Strict `< TH_LOW` as the reference (:848). */
 int orbm_search_by_bow_kfkf(orbm_matcher* m,

@@ -434,6 +434,48 @@ class Matcher:
         return n, m12[:n1]
 
 
+class _BowSideDevice(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("kps", C.c_void_p), ("n", C.c_void_p), ("cap", C.c_int32), ("valid", C.c_void_p),
+                ("fv_node", C.c_void_p), ("fv_off", C.c_void_p), ("fv_feat", C.c_void_p), ("n_fv_nodes", C.c_void_p)]
+
+
+class _BowPairDevice(C.Structure):
+    _fields_ = [("kf", _BowSideDevice), ("f", _BowSideDevice), ("match_f2kf", C.c_void_p), ("n_matches", C.c_void_p)]
+
+
+class DeviceBowPlan:
+    """SearchByBoW on device-resident pairs: sides = dicts of device addresses (desc, kps, n, cap, fv_node, fv_off, fv_feat,
+    n_fv_nodes[, valid]) as produced by Extractor.extract_batch_device + Vocabulary.transform_batch_device."""
+
+    def __init__(self, matcher, pairs):
+        n = len(pairs)
+        arr = (_BowPairDevice * n)()
+        for i, (kf, f, match_ptr, nm_ptr) in enumerate(pairs):
+            for side, d in ((arr[i].kf, kf), (arr[i].f, f)):
+                side.desc, side.kps, side.n, side.cap = d["desc"], d["kps"], d["n"], int(d["cap"])
+                side.valid = d.get("valid") or None
+                side.fv_node, side.fv_off, side.fv_feat, side.n_fv_nodes = d["fv_node"], d["fv_off"], d["fv_feat"], d["n_fv_nodes"]
+            arr[i].match_f2kf = match_ptr; arr[i].n_matches = nm_ptr
+        h = C.c_void_p()
+        _check(lib.orbm_bow_plan_create_device(matcher._h, arr, n, C.byref(h)))
+        self._h, self._m = h, matcher
+
+    def run(self, stream=None):
+        _check(lib.orbm_bow_plan_run(self._h, C.c_float(self._m.nnratio), int(self._m.check_ori), C.c_void_p(stream or 0)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.orbm_bow_plan_destroy.argtypes = [C.c_void_p]
+            lib.orbm_bow_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BowPlan:
     def __init__(self, matcher, sets):
         lib.orbm_bow_plan_create.argtypes = [C.c_void_p, C.POINTER(BowPair), C.c_int, C.POINTER(C.c_void_p)]

@@ -78,6 +78,11 @@ struct BowPairDev {
     const uint8_t* d1; const uint8_t* v1; const float* a1; const uint32_t* node1; const int32_t* off1; const uint32_t* feat1;
     const uint8_t* d2; const uint8_t* v2; const float* a2; const uint32_t* node2; const int32_t* off2; const uint32_t* feat2;
     int32_t n1, n2, nn1, nn2;
+    // device-resident pairs (orbm_bow_plan_create_device): the four counts live in device memory (outputs of the extractor
+    // and of the vocabulary transform), angles are read out of OrbxKeyPoint records (stride 7 floats), v1 may be NULL (all valid)
+    const int32_t* n1p = nullptr; const int32_t* n2p = nullptr; const int32_t* nn1p = nullptr; const int32_t* nn2p = nullptr;
+    int32_t a1_stride = 1, a2_stride = 1;
+    int32_t cap1 = 0, cap2 = 0;
     int32_t* match;         // [n2] (KF-F: Frame feature -> KF feature) or [n1] (KF-KF: KF1 feature -> KF2 feature)
     uint8_t* matched2;      // [n2] KF-KF only
     int32_t* n_matches;
@@ -89,7 +94,7 @@ __device__ void bow_node(const BowPairDev& P, int k, int f, float nnratio, int c
 {
     for (int i1 = P.off1[k]; i1 < P.off1[k + 1]; i1++) {
         const int idx1 = (int)P.feat1[i1];
-        if (!P.v1[idx1]) continue;                           // !pMP || pMP->isBad()
+        if (P.v1 && !P.v1[idx1]) continue;                   // !pMP || pMP->isBad()
         const uint8_t* da = P.d1 + (size_t)idx1 * 32;
         int best1 = 256, bestIdx = -1, best2 = 256;
         for (int i2 = P.off2[f]; i2 < P.off2[f + 1]; i2++) {
@@ -104,7 +109,7 @@ __device__ void bow_node(const BowPairDev& P, int k, int f, float nnratio, int c
         if (low && (float)best1 < nnratio * (float)best2) {
             if (KFKF) { P.match[idx1] = bestIdx; P.matched2[bestIdx] = 1; }
             else P.match[bestIdx] = idx1;
-            if (check_ori) atomicAdd(&s_hist[rot_bin(P.a1[idx1], P.a2[bestIdx])], 1);
+            if (check_ori) atomicAdd(&s_hist[rot_bin(P.a1[(size_t)idx1 * P.a1_stride], P.a2[(size_t)bestIdx * P.a2_stride])], 1);
         }
     }
 }
@@ -121,7 +126,7 @@ __device__ void bow_node_group(const BowPairDev& P, int k, int f, float nnratio,
     unsigned taken = 0;                                         // bit j: candidate sub + 16*j is consumed
     for (int i1 = P.off1[k]; i1 < P.off1[k + 1]; i1++) {
         const int idx1 = (int)P.feat1[i1];
-        if (!P.v1[idx1]) continue;                           // !pMP || pMP->isBad()   (uniform over the group)
+        if (P.v1 && !P.v1[idx1]) continue;                   // !pMP || pMP->isBad()   (uniform over the group)
         const unsigned long long* da = (const unsigned long long*)(P.d1 + (size_t)idx1 * 32);
         const unsigned long long a0 = da[0], a1 = da[1], a2 = da[2], a3 = da[3];
         unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
@@ -146,7 +151,7 @@ __device__ void bow_node_group(const BowPairDev& P, int k, int f, float nnratio,
                 const int bestIdx = (int)P.feat2[b2 + cbest];
                 if (KFKF) { P.match[idx1] = bestIdx; P.matched2[bestIdx] = 1; }
                 else P.match[bestIdx] = idx1;
-                if (check_ori) atomicAdd(&s_hist[rot_bin(P.a1[idx1], P.a2[bestIdx])], 1);
+                if (check_ori) atomicAdd(&s_hist[rot_bin(P.a1[(size_t)idx1 * P.a1_stride], P.a2[(size_t)bestIdx * P.a2_stride])], 1);
             }
         }
     }
@@ -158,7 +163,10 @@ __global__ __launch_bounds__(kBowThreads) void k_bow(const BowPairDev* __restric
     __shared__ int s_hist[HISTO_LENGTH];
     __shared__ int s_keep[3];
     __shared__ int s_count;
-    const BowPairDev P = pairs[blockIdx.x];
+    BowPairDev P = pairs[blockIdx.x];
+    if (P.n1p) {        // device-resident pair: counts come from device memory, clamped to the arrays' capacity
+        P.n1 = min(*P.n1p, P.cap1); P.n2 = min(*P.n2p, P.cap2); P.nn1 = min(*P.nn1p, P.cap1); P.nn2 = min(*P.nn2p, P.cap2);
+    }
     const int tid = threadIdx.x;
     const int n_out = KFKF ? P.n1 : P.n2;
     for (int i = tid; i < n_out; i += kBowThreads) P.match[i] = -1;
@@ -201,7 +209,8 @@ __global__ __launch_bounds__(kBowThreads) void k_bow(const BowPairDev* __restric
         const int m = P.match[i];
         if (m < 0) continue;
         if (check_ori) {
-            const int bin = KFKF ? rot_bin(P.a1[i], P.a2[m]) : rot_bin(P.a1[m], P.a2[i]);
+            const int bin = KFKF ? rot_bin(P.a1[(size_t)i * P.a1_stride], P.a2[(size_t)m * P.a2_stride])
+                                 : rot_bin(P.a1[(size_t)m * P.a1_stride], P.a2[(size_t)i * P.a2_stride]);
             if (bin != s_keep[0] && bin != s_keep[1] && bin != s_keep[2]) { P.match[i] = -1; continue; }
         }
         local++;
@@ -1261,6 +1270,42 @@ int orbm_bow_plan_create(orbm_matcher* m, const OrbmBowPair* pairs, int n_pairs,
     return ORBX_OK;
 }
 
+int orbm_bow_plan_create_device(orbm_matcher* m, const OrbmBowPairDevice* pairs, int n_pairs, orbm_bow_plan** out)
+{
+    if (!m || !pairs || n_pairs < 1 || !out) return fail(ORBX_ERR_ARG, "bad plan arguments");
+    *out = nullptr;
+    ORBM_HIP(hipSetDevice(m->device));
+    std::vector<orbm::BowPairDev> descs(n_pairs);
+    for (int p = 0; p < n_pairs; p++) {
+        const OrbmBowPairDevice& q = pairs[p];
+        const OrbmBowSideDevice* sd[2] = {&q.kf, &q.f};
+        for (int k = 0; k < 2; k++)
+            if (!sd[k]->desc || !sd[k]->kps || !sd[k]->n || !sd[k]->fv_node || !sd[k]->fv_off || !sd[k]->fv_feat || !sd[k]->n_fv_nodes || sd[k]->cap < 1)
+                return fail(ORBX_ERR_ARG, "pair %d: NULL device arrays", p);
+        if (!q.match_f2kf || !q.n_matches) return fail(ORBX_ERR_ARG, "pair %d: NULL outputs", p);
+        orbm::BowPairDev D;
+        D.d1 = q.kf.desc; D.v1 = q.kf.valid; D.a1 = (const float*)q.kf.kps + 3;       // OrbxKeyPoint.angle
+        D.node1 = q.kf.fv_node; D.off1 = q.kf.fv_off; D.feat1 = q.kf.fv_feat;
+        D.d2 = q.f.desc; D.v2 = nullptr; D.a2 = (const float*)q.f.kps + 3;
+        D.node2 = q.f.fv_node; D.off2 = q.f.fv_off; D.feat2 = q.f.fv_feat;
+        D.n1 = D.n2 = D.nn1 = D.nn2 = 0;
+        D.n1p = q.kf.n; D.n2p = q.f.n; D.nn1p = q.kf.n_fv_nodes; D.nn2p = q.f.n_fv_nodes;
+        D.a1_stride = D.a2_stride = (int32_t)(sizeof(OrbxKeyPoint) / sizeof(float));
+        D.cap1 = q.kf.cap; D.cap2 = q.f.cap;
+        D.match = q.match_f2kf; D.matched2 = nullptr; D.n_matches = q.n_matches;
+        D.serial = 0;       // the vocabulary transform puts every feature into exactly one node
+        descs[p] = D;
+    }
+    orbm_bow_plan* pl = new orbm_bow_plan();
+    pl->m = m; pl->n_pairs = n_pairs; pl->desc_off = 0;
+    if (hipMalloc((void**)&pl->d_blob, sizeof(orbm::BowPairDev) * n_pairs) != hipSuccess) { delete pl; return fail(ORBX_ERR_HIP, "hipMalloc failed"); }
+    if (hipMemcpy(pl->d_blob, descs.data(), sizeof(orbm::BowPairDev) * n_pairs, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(pl->d_blob); delete pl; return fail(ORBX_ERR_HIP, "upload failed");
+    }
+    *out = pl;
+    return ORBX_OK;
+}
+
 int orbm_bow_plan_run(orbm_bow_plan* pl, float nnratio, int check_orientation, void* stream)
 {
     if (!pl) return fail(ORBX_ERR_ARG, "NULL plan");
@@ -1274,6 +1319,7 @@ int orbm_bow_plan_run(orbm_bow_plan* pl, float nnratio, int check_orientation, v
 int orbm_bow_plan_fetch(orbm_bow_plan* pl, OrbmBowPair* pairs, void* stream)
 {
     if (!pl || !pairs) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (pl->po.empty()) return fail(ORBX_ERR_ARG, "a device-resident plan writes into the caller's device arrays: nothing to fetch");
     ORBM_HIP(hipSetDevice(pl->m->device));
     hipStream_t st = (hipStream_t)stream;
     for (int p = 0; p < pl->n_pairs; p++) {
