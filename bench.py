@@ -405,9 +405,10 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 from oracle_api import oracle_transform
                 hd = d_desc.cpu().numpy().reshape(B, cap, 32)
+                nk_now = d_n.cpu().numpy()              # (the chain leg re-used the extractor's output buffers)
                 t0 = time.perf_counter()
                 for b_ in range(8):
-                    oracle_transform(o, voc, hd[b_, :int(nk[b_])], 4)
+                    oracle_transform(o, voc, hd[b_, :int(nk_now[b_])], 4)
                 dtc = (time.perf_counter() - t0) / 8
                 out["vocab"]["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "8 frames"}
                 out["vocab"]["speedup_vs_cpu_1core"] = out["vocab"]["value"] * dtc
