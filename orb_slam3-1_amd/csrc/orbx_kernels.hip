@@ -703,18 +703,21 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         }
     }
     __syncthreads();
+    const uint32_t tapA = (uint32_t)t0 | ((uint32_t)t1 << 8) | ((uint32_t)t2 << 16) | ((uint32_t)t3 << 24);
+    const uint32_t tapB = (uint32_t)t2 | ((uint32_t)t1 << 8) | ((uint32_t)t0 << 16);
     // horizontal pass: one work item = 4 adjacent outputs, fed by three aligned dword LDS reads (12 source bytes)
     for (int i = tid; i < (kBlurTH + 6) * (kBlurTW / 4); i += 256) {
         const int r = i / (kBlurTW / 4), q = i - r * (kBlurTW / 4);
         const uint32_t* w = (const uint32_t*)(s_src + r * SP) + q;
         const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        uint32_t b[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { b[k] = (w0 >> (8 * k)) & 0xFFu; b[4 + k] = (w1 >> (8 * k)) & 0xFFu; b[8 + k] = (w2 >> (8 * k)) & 0xFFu; }
+        // output column 4q+k uses source bytes k+1 .. k+7 of the 12: two byte dot products (v_dot4_u32_u8) per output,
+        // taps (t0 t1 t2 t3) on bytes k+1..k+4 and (t2 t1 t0 0) on bytes k+5..k+8; the windows come from v_alignbyte.
+        // The taps sum to 256, so a sum never exceeds 255 * 256 = 65280: no clamp needed.
         uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)        // output column 4q+k uses source bytes k+1 .. k+7 of the 12
-            o[k] = min((uint32_t)t0 * (b[k + 1] + b[k + 7]) + (uint32_t)t1 * (b[k + 2] + b[k + 6]) + (uint32_t)t2 * (b[k + 3] + b[k + 5]) + (uint32_t)t3 * b[k + 4], 65535u);
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), tapB, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), tapB, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), tapB, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(w1, tapA, __builtin_amdgcn_udot4(w2, tapB, 0u, false), false);
         uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
         *(uint2*)(s_h + r * kBlurTW + 4 * q) = pk;
     }
