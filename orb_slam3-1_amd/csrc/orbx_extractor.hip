@@ -106,7 +106,9 @@ struct orbx_extractor {
     int cand_frame_entries = 0, sel_frame_entries = 0;
     int tile_pitch = 0, tile_rows = 0, m_pitch = 0, m_rows = 0, surv_off = 0, bits_off = 0;
     size_t fast_lds = 0, oct_lds = 0;
-    int oct_pool = 0, oct_lds_keys = 0;
+    int oct_pool = 0, oct_lds_keys = 0, oct_small_keys = 0;
+    size_t oct_small_lds = 0;
+    bool oct_keys_forced = false;
 
     DevBuf<LevelDesc> d_levels;
     DevBuf<CellDesc> d_cells;
@@ -290,11 +292,16 @@ int orbx_extractor::setup_geometry(int w, int h)
     if (oct_pool > 16000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree", max_nfeat);
     const char* env = getenv("ORBX_OCT_LDS_KEYS");
     oct_lds_keys = env ? atoi(env) : 0;      // measured on MI355X: L2-resident HBM scratch + more resident waves beats LDS keys
+    oct_keys_forced = env != nullptr;        // ... for large batches; small batches are latency-bound and take LDS keys (enqueue())
     const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 14 + 2 * kOctLogFactor) + (size_t)((oct_pool + 15) & ~15);
     if (node_bytes + 8 * (size_t)oct_lds_keys > 150 * 1024) oct_lds_keys = (int)((150 * 1024 - node_bytes) / 8);
     if (oct_lds_keys < 0) oct_lds_keys = 0;
     oct_lds = node_bytes + 8 * (size_t)oct_lds_keys + 16;
-    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_lds));
+    // second configuration for small batches: both key buffers of a level (up to 4096 candidates) live in LDS
+    oct_small_keys = 4096;
+    if (node_bytes + 8 * (size_t)oct_small_keys > 150 * 1024) oct_small_keys = std::max(0, (int)((150 * 1024 - node_bytes) / 8));
+    oct_small_lds = node_bytes + 8 * (size_t)oct_small_keys + 16;
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(oct_lds, oct_small_lds)));
     ORBX_HIP(hipFuncSetAttribute((const void*)k_fast_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
     int r;
     if ((r = d_levels.upload(levels)) || (r = d_cells.upload(cells)) || (r = d_tiles.upload(tiles))) return r;
@@ -376,8 +383,14 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                            (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
         ORBX_HIP(hipEventRecord(ev_join, side_stream));
     }
-    hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), oct_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
-                       d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, oct_lds_keys,
+    // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
+    // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
+    // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
+    const bool small_batch = !oct_keys_forced && (long long)B * nlevels <= 512;
+    const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
+    const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
+    hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), o_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
+                       d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
                        d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status);
     mark();
     hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,

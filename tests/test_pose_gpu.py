@@ -58,3 +58,24 @@ def test_pose_golden(pkg, synth):
             _check(w, s.optimize(w), np.load(os.path.join(GOLDEN, name + ".npz")))
     finally:
         s.close()
+
+
+def test_pose_is_invariant_to_edge_order(pkg, synth):
+    """a property that needs no oracle: permuting the edges permutes the outlier flags and leaves the pose alone (the block
+    reductions are ordered, but the sum is the same set of terms)"""
+    w = synth.make_pose_problem(40, n=700, outlier_frac=0.15, stereo_frac=0.3)
+    rs = np.random.RandomState(1)
+    p = rs.permutation(700)
+    w2 = dict(w)
+    for k in ("Xw", "obs", "inv_sigma2", "stereo"):
+        w2[k] = np.ascontiguousarray(w[k][p])
+    s = pkg.PoseSolver()
+    try:
+        r1, r2 = s.optimize_batch([w, w2])
+    finally:
+        s.close()
+    np.testing.assert_array_equal(r1["outlier"][p], r2["outlier"])
+    assert r1["inliers"] == r2["inliers"]
+    np.testing.assert_allclose(r2["q"], r1["q"], rtol=0, atol=1e-9); np.testing.assert_allclose(r2["t"], r1["t"], rtol=0, atol=1e-9)
+    Rerr = np.abs(r1["t"] - w["true_t"]).max()
+    assert Rerr < 0.05

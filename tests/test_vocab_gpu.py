@@ -72,3 +72,27 @@ def test_transform_batch_device_feeds_search_by_bow(pkg, oracle, synth):
         np.testing.assert_array_equal(bi[b, :nb[b]], bi0); np.testing.assert_array_equal(bv[b, :nb[b]], bv0)
         np.testing.assert_array_equal(fn[b, :nf[b]], fn0); np.testing.assert_array_equal(fo[b, :nf[b] + 1], fo0)
         np.testing.assert_array_equal(ff[b, :fo0[-1]], ff0)
+
+
+def test_transform_full_size_tree(pkg, oracle, synth):
+    """the shape of ORBvoc.txt (k = 10, L = 6: 1 111 111 nodes, 35 MB of centroids), levelsup = 4 as Frame::ComputeBoW uses it"""
+    voc = synth.make_vocabulary_fast(1, k=10, L=6)
+    rs = np.random.RandomState(9)
+    desc = rs.randint(0, 256, size=(1500, 32)).astype(np.uint8)
+    (bi0, bv0), (fn0, fo0, ff0) = oracle_transform(oracle, voc, desc, 4)
+    v = pkg.Vocabulary(voc)
+    try:
+        (bi1, bv1), (fn1, fo1, ff1) = v.transform(desc, 4)
+        w1, wt1, nd1 = v.transform_features(desc[:64], 4)
+    finally:
+        v.close()
+    np.testing.assert_array_equal(bi1, bi0); np.testing.assert_array_equal(bv1, bv0)
+    np.testing.assert_array_equal(fn1, fn0); np.testing.assert_array_equal(fo1, fo0); np.testing.assert_array_equal(ff1, ff0)
+    # size-independent properties: every word is a leaf, the node 4 levels up is its ancestor at depth 2, sum(bow) = 1
+    n_inner = (10 ** 6 - 1) // 9
+    assert (w1 + n_inner < voc["n_nodes"]).all() and abs(bv1.sum() - 1.0) < 1e-12
+    leaf = w1.astype(np.int64) + n_inner
+    anc = leaf
+    for _ in range(4):
+        anc = (anc - 1) // 10
+    np.testing.assert_array_equal(anc, nd1.astype(np.int64))
