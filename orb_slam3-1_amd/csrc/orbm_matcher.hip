@@ -1551,6 +1551,9 @@ int orbm_fuse_search(orbm_matcher* m, const OrbmFrame* kf, const float* u_right,
     if (r) return r;
     for (int i = 0; i < n_pts; i++)
         if (valid[i] && (pred_level[i] < 0 || pred_level[i] >= kf->n_levels)) return fail(ORBX_ERR_ARG, "point %d: level %d out of range", i, pred_level[i]);
+    if (chi2_check)
+        for (int i = 0; i < kf->n; i++)
+            if (kf->octave[i] < 0 || kf->octave[i] >= kf->n_levels) return fail(ORBX_ERR_ARG, "key point %d: octave %d out of range", i, kf->octave[i]);
     if (n_pts == 0) return ORBX_OK;
     ORBM_HIP(hipSetDevice(m->device));
     Blob blob(m->h_blob);

@@ -692,7 +692,7 @@ static int stereo_enqueue(orbx_extractor* l, orbx_extractor* r, int frame0, int 
     const uint8_t* pl = l->d_pyr.p + (size_t)frame0 * l->pyr_frame_bytes;
     const uint8_t* pr = r->d_pyr.p + (size_t)frame0 * r->pyr_frame_bytes;
     hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, batch), dim3(256), 0, st, pl, pr, l->pyr_frame_bytes, l->d_levels.p, T,
-                       d_kps_l, d_desc_l, d_n_l, d_kps_r, d_desc_r, d_n_r, cap, mb, mbf, d_u_right, d_depth, l->d_sad.p);
+                       d_kps_l, d_desc_l, d_n_l, d_kps_r, d_desc_r, d_n_r, cap, mb, mbf, l->nlevels, d_u_right, d_depth, l->d_sad.p);
     int n_pow2 = 2;
     while (n_pow2 < cap) n_pow2 <<= 1;
     hipLaunchKernelGGL(k_stereo_median, dim3(batch), dim3(256), (size_t)n_pow2 * sizeof(int), st, d_n_l, cap, n_pow2, d_u_right, d_depth, l->d_sad.p);

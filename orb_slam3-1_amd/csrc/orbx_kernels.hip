@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
                                                      const LevelDesc* __restrict__ levels, StereoTables T,
                                                      const OrbxKeyPoint* __restrict__ kpsL, const uint8_t* __restrict__ descL, const int32_t* __restrict__ nL,
                                                      const OrbxKeyPoint* __restrict__ kpsR, const uint8_t* __restrict__ descR, const int32_t* __restrict__ nR,
-                                                     int cap, float mb, float mbf,
+                                                     int cap, float mb, float mbf, int n_levels,
                                                      float* __restrict__ u_right, float* __restrict__ depth, int32_t* __restrict__ sad_out)
 {
     __shared__ uint8_t s_l[4][11 * 12], s_r[4][11 * 24];
@@ -909,6 +909,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
     for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
     const int thOrbDist = (100 + 50) / 2;
     bool ok = live && key != 0xFFFFFFFFu && (int)(key >> 20) < thOrbDist;
+    if (levelL < 0 || levelL >= n_levels) ok = false;          // key points that do not come from this extractor: no table lookups out of range
     // ---- sub-pixel match by correlation (:1011-1083) ----
     float scaleduR0 = 0;
     int y0 = 0, xl0 = 0, xr_start = 0;
