@@ -298,10 +298,14 @@ int orbx_extractor::setup_geometry(int w, int h)
     if (oct_lds_keys < 0) oct_lds_keys = 0;
     oct_lds = node_bytes + 8 * (size_t)oct_lds_keys + 16;
     // second configuration for small batches: both key buffers of a level (up to 4096 candidates) live in LDS
-    oct_small_keys = 4096;
-    if (node_bytes + 8 * (size_t)oct_small_keys > 150 * 1024) oct_small_keys = std::max(0, (int)((150 * 1024 - node_bytes) / 8));
+    int max_cand_cap = 0;
+    for (const LevelDesc& lv : levels) max_cand_cap = std::max(max_cand_cap, lv.cand_cap);
+    oct_small_keys = max_cand_cap;
+    if (node_bytes + 8 * (size_t)oct_small_keys > 150 * 1024) oct_small_keys = 0;      // does not fit: small batches use the scratch path too
     oct_small_lds = node_bytes + 8 * (size_t)oct_small_keys + 16;
-    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(oct_lds, oct_small_lds)));
+    if (oct_lds_keys > 0 && oct_lds_keys < max_cand_cap) oct_lds_keys = 0;              // the LDS instantiation needs room for a whole level
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)node_bytes + 64));
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(oct_lds, oct_small_lds)));
     ORBX_HIP(hipFuncSetAttribute((const void*)k_fast_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
     int r;
     if ((r = d_levels.upload(levels)) || (r = d_cells.upload(cells)) || (r = d_tiles.upload(tiles))) return r;
@@ -386,10 +390,11 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
     // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
     // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
-    const bool small_batch = !oct_keys_forced && (long long)B * nlevels <= 512;
+    const bool small_batch = !oct_keys_forced && oct_small_keys > 0 && (long long)B * nlevels <= 512;
     const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
     const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
-    hipLaunchKernelGGL(k_octree, dim3(nlevels, B), dim3(64), o_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
+    auto oct_kernel = o_keys > 0 ? k_octree<true> : k_octree<false>;
+    hipLaunchKernelGGL(oct_kernel, dim3(nlevels, B), dim3(64), o_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
                        d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
                        d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status);
     mark();
@@ -747,6 +752,14 @@ int orbx_stereo_matches(orbx_extractor* left, orbx_extractor* right, int frame,
 // host-side evaluation of the shared float helpers (pins them against the oracle in the CPU tests)
 float orbx_debug_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 void orbx_debug_sincos(float a, float* c, float* s) { sincos_f32(a, c, s); }
+
+#ifdef ORBX_OCT_TIMING
+int orbx_debug_oct_prof(unsigned long long* out8)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(d_oct_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return ORBX_ERR_HIP;
+    return ORBX_OK;
+}
+#endif
 
 #ifdef ORBX_FAST_TIMING
 // reads and clears the cycle sums of k_fast_cells (timing builds only; not part of include/orbslam3_hip.h)

@@ -335,15 +335,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // the level's candidates fit, HBM scratch otherwise).  Node bookkeeping is wave-uniform scalar work;
 // the stable 4-way key partition of DivideNode is wave-parallel (ballot + prefix popcount).
 // ------------------------------------------------------------------------------------------------
+#ifdef ORBX_OCT_TIMING      // cycle split of the (level 0, frame 0) wave (tools/oct_timing.py); never defined in the product build
+__device__ unsigned long long d_oct_prof[8];
+#endif
 struct OctLds {
     short* ulx; short* uly; short* brx; short* bry;
     int* beg; int* cnt;
     short* pidx; short* freelist; short* order;
     short* plog;            // push log: the std::list order is the REVERSE of this array without its tombstones (-1)
     uint8_t* flg;           // bit0: bNoMore, bit1: keys live in buffer 1
-    SortNode* ex[2];
 };
 
+// LDS_KEYS: both ping-pong key buffers live in LDS (the host sizes them for the largest level, so the choice is static and
+// every key access is a ds_ instruction); otherwise they live in the L2-resident HBM scratch (global_ instructions).
+template <bool LDS_KEYS>
 __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
                                                const uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                const int* __restrict__ cell_count, int n_cells,
@@ -357,13 +362,16 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
     const int lane = threadIdx.x;
     const LevelDesc L = levels[level];
     const int N = L.nfeat;
+#ifdef ORBX_OCT_TIMING
+    const long long t_kernel0 = clock64();
+#endif
 
     // carve LDS
     OctLds S;
     {
         uint8_t* p = smem;
-        S.ex[0] = (SortNode*)p; p += sizeof(SortNode) * pool;
-        S.ex[1] = (SortNode*)p; p += sizeof(SortNode) * pool;
+        SortNode* const ex0 = (SortNode*)p; p += sizeof(SortNode) * pool;      // (named, not an indexed pointer array: a pointer
+        SortNode* const ex1 = (SortNode*)p; p += sizeof(SortNode) * pool;      //  picked with ?: keeps its LDS address space)
         S.beg = (int*)p; p += 4 * pool;
         S.cnt = (int*)p; p += 4 * pool;
         S.ulx = (short*)p; p += 2 * pool;  S.uly = (short*)p; p += 2 * pool;
@@ -385,8 +393,13 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
             total += v;
         }
         uint32_t* keys[2];
-        if (total <= lds_keys_cap) { keys[0] = lds_keys; keys[1] = lds_keys + lds_keys_cap; }
-        else {
+        if (LDS_KEYS) {
+            if (total > lds_keys_cap) {         // cannot happen: the host sizes the buffers for the largest level's capacity
+                if (lane == 0) { atomicExch(status + frame, ORBX_ERR_INTERNAL); sel_count[(size_t)frame * n_levels + level] = 0; }
+                return;
+            }
+            keys[0] = lds_keys; keys[1] = lds_keys + lds_keys_cap;
+        } else {
             uint32_t* g = scratch + (size_t)frame * scratch_frame_stride + 2 * (size_t)L.cand_off;
             keys[0] = g; keys[1] = g + L.cand_cap;
         }
@@ -431,7 +444,6 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
             S.plog[np] = (short)i; S.pidx[i] = (short)np;
             np++; size++;
         };
-        auto kill = [&](int i) { S.plog[S.pidx[i]] = -1; S.freelist[nfree++] = (short)i; size--; };
         auto compact = [&]() {          // drop tombstones, order preserved (wave-parallel, in place)
             int w = 0;
             for (int i0 = 0; i0 < np; i0 += 64) {
@@ -479,16 +491,27 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
         }
 
         int cur_ex = 0, n_ex = 0;
+#ifdef ORBX_OCT_TIMING
+        long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+        int n_div = 0;
+        const bool timed = level == 0 && frame == 0 && lane == 0;
+#define ORBX_OTICK(k) if (timed) { const long long t_now = clock64(); tq[k] += t_now - t_prev; t_prev = t_now; }
+#else
+#define ORBX_OTICK(k)
+#endif
         // DivideNode + push children to the FRONT in order n1..n4 (:480-536, :639-676); then erase the parent
         auto divide = [&](int id, int& n_to_expand) {
+#ifdef ORBX_OCT_TIMING
+            if (timed) { t_prev = clock64(); n_div++; }
+#endif
             const int ulx = S.ulx[id], uly = S.uly[id], brx = S.brx[id], bry = S.bry[id];
             const int beg = S.beg[id], cnt = S.cnt[id];
             const int src = (S.flg[id] >> 1) & 1;
             const int halfX = (brx - ulx + 1) >> 1;     // ceil(float(w)/2), w >= 0
             const int halfY = (bry - uly + 1) >> 1;
             const int midx = ulx + halfX, midy = uly + halfY;
-            const uint32_t* kin = keys[src];
-            uint32_t* kout = keys[src ^ 1];
+            const uint32_t* kin = src ? keys[1] : keys[0];
+            uint32_t* kout = src ? keys[0] : keys[1];
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             const unsigned long long lt = (1ull << lane) - 1ull;
             if (cnt <= 64) {
@@ -526,35 +549,41 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                     w0 += __popcll(m0); w1 += __popcll(m1); w2 += __popcll(m2); w3 += __popcll(m3);
                 }
             }
-            const int b0 = beg, b1 = b0 + c0, b2 = b1 + c1, b3 = b2 + c2;
-            const int cb[4] = {b0, b1, b2, b3}, cn[4] = {c0, c1, c2, c3};
-            const int cux[4] = {ulx, midx, ulx, midx}, cuy[4] = {uly, uly, midy, midy};
-            const int cbx[4] = {midx, brx, midx, brx}, cby[4] = {midy, midy, bry, bry};
-            if (nfree < 4) { overflow = true; return; }
-            const int fs[4] = {S.freelist[nfree - 1], S.freelist[nfree - 2], S.freelist[nfree - 3], S.freelist[nfree - 4]};    // independent reads
-            int used = 0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (cn[c] > 0) {
-                    const int ch = used == 0 ? fs[0] : used == 1 ? fs[1] : used == 2 ? fs[2] : fs[3];
-                    used++;
-                    S.ulx[ch] = (short)cux[c]; S.uly[ch] = (short)cuy[c]; S.brx[ch] = (short)cbx[c]; S.bry[ch] = (short)cby[c];
-                    S.beg[ch] = cb[c]; S.cnt[ch] = cn[c];
-                    S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn[c] == 1 ? 1 : 0));
-                    push(ch);
-                    if (cn[c] > 1) {
-                        n_to_expand++;
-                        SortNode sn; sn.count = cn[c]; sn.ulx = cux[c]; sn.node = ch;
-                        if (n_ex < pool) S.ex[cur_ex][n_ex] = sn;
-                        n_ex++;
-                    }
+            ORBX_OTICK(0)
+            // children: lane c (< 4) writes child c -- its slot in the free list, the push log and the to-expand array is
+            // its rank among the non-empty (resp. still divisible) children before it, so the four are independent
+            const int e0 = c0 > 0, e1 = c1 > 0, e2 = c2 > 0, e3 = c3 > 0;
+            const int x0 = c0 > 1, x1 = c1 > 1, x2 = c2 > 1, x3 = c3 > 1;
+            const int ne = e0 + e1 + e2 + e3, nx = x0 + x1 + x2 + x3;
+            if (nfree < 4 || np + ne > plog_cap) { overflow = true; return; }
+            if (lane < 4) {
+                const int cn_me = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
+                if (cn_me > 0) {
+                    const int r = (lane > 0 ? e0 : 0) + (lane > 1 ? e1 : 0) + (lane > 2 ? e2 : 0);
+                    const int rx = (lane > 0 ? x0 : 0) + (lane > 1 ? x1 : 0) + (lane > 2 ? x2 : 0);
+                    const int cb_me = beg + (lane > 0 ? c0 : 0) + (lane > 1 ? c1 : 0) + (lane > 2 ? c2 : 0);
+                    const int ch = S.freelist[nfree - 1 - r];
+                    const int ux = (lane & 1) ? midx : ulx, uy = (lane & 2) ? midy : uly;
+                    S.ulx[ch] = (short)ux; S.uly[ch] = (short)uy;
+                    S.brx[ch] = (short)((lane & 1) ? brx : midx); S.bry[ch] = (short)((lane & 2) ? bry : midy);
+                    S.beg[ch] = cb_me; S.cnt[ch] = cn_me;
+                    S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn_me == 1 ? 1 : 0));
+                    S.plog[np + r] = (short)ch; S.pidx[ch] = (short)(np + r);      // push(): children n1..n4 in order
+                    if (cn_me > 1 && n_ex + rx < pool) { SortNode sn; sn.count = cn_me; sn.ulx = ux; sn.node = ch; (cur_ex ? ex1 : ex0)[n_ex + rx] = sn; }
                 }
             }
-            nfree -= used;
-            kill(id);
+            np += ne; size += ne; nfree -= ne;
+            n_to_expand += nx; n_ex += nx;
+            if (lane == 0) { S.plog[S.pidx[id]] = -1; S.freelist[nfree] = (short)id; }       // kill(id)
+            nfree++; size--;
+            ORBX_OTICK(1)
             __syncthreads();        // key scatter visible to every lane before the children are read
+            ORBX_OTICK(2)
         };
 
+#ifdef ORBX_OCT_TIMING
+        if (timed) tq[3] = clock64() - t_kernel0;
+#endif
         bool finish = false;
         int guard = 0;
         while (!finish && !overflow && guard++ < 64) {
@@ -574,9 +603,13 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                     const int prev_size2 = size;
                     compact();
                     const int n_prev = min(n_ex, pool);
-                    SortNode* pv = S.ex[cur_ex];
+                    SortNode* pv = cur_ex ? ex1 : ex0;
+#ifdef ORBX_OCT_TIMING
+                    if (timed) t_prev = clock64();
+#endif
                     if (lane == 0) introsort_nodes(pv, n_prev);     // std::sort(..., compareNodes) (:700)
                     __syncthreads();
+                    ORBX_OTICK(5)
                     cur_ex ^= 1;
                     n_ex = 0;
                     int dummy = 0;
@@ -594,13 +627,16 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
         }
 
         // ---- final list order, then the best-response key of every node, first wins ties (:758-776)
+#ifdef ORBX_OCT_TIMING
+        if (timed) t_prev = clock64();
+#endif
         compact();
         for (int k = lane; k < np && k < pool; k += 64) S.order[k] = S.plog[np - 1 - k];
         __syncthreads();
         const int n_out = min(size, L.sel_cap);
         for (int k = lane; k < n_out; k += 64) {
             const int id = S.order[k];
-            const uint32_t* kb = keys[(S.flg[id] >> 1) & 1] + S.beg[id];
+            const uint32_t* kb = (((S.flg[id] >> 1) & 1) ? keys[1] : keys[0]) + S.beg[id];
             const int cnt = S.cnt[id];
             uint32_t best = kb[0];
             for (int i = 1; i < cnt; i++) {
@@ -613,6 +649,12 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
             *out_count = n_out;
             if (size > L.sel_cap) atomicExch(status + frame, ORBX_ERR_INTERNAL);
         }
+        ORBX_OTICK(6)
+#ifdef ORBX_OCT_TIMING
+        if (timed) { d_oct_prof[0] = (unsigned long long)tq[0]; d_oct_prof[1] = (unsigned long long)tq[1]; d_oct_prof[2] = (unsigned long long)tq[2];
+                     d_oct_prof[3] = (unsigned long long)n_div; d_oct_prof[4] = (unsigned long long)(clock64() - t_kernel0); d_oct_prof[5] = (unsigned long long)total;
+                     d_oct_prof[6] = (unsigned long long)tq[3]; d_oct_prof[7] = (unsigned long long)((tq[5] << 32) | (tq[6] & 0xFFFFFFFFll)); }
+#endif
     }
 }
 
