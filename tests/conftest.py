@@ -38,3 +38,9 @@ def pkg():
     except Exception:
         pass
     return importlib.import_module("orb_slam3-1_amd")
+
+
+@pytest.fixture(scope="session")
+def sm():
+    return importlib.import_module("orb_slam3-1_amd.synth_match")
+
