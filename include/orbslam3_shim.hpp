@@ -412,8 +412,66 @@ public:
         return n;
     }
 
-    // SearchBySim3 (src/ORBmatcher.cc:1457-1674) = the Fuse search core run in both directions (level window, first minimum,
-    // no chi2 gate) with TH_HIGH, followed by the agreement check; see INTEGRATION.md 3b for the flattening of each direction.
+    // SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (src/ORBmatcher.cc:1457-1674) = the Fuse search core (level window,
+    // first minimum, no chi2 gate) once per direction with TH_HIGH, followed by the agreement check.
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const Sophus::Sim3f& S12, const float th)
+    {
+        const float fx = pKF1->fx, fy = pKF1->fy, cx = pKF1->cx, cy = pKF1->cy;
+        const Sophus::SE3f T1w = pKF1->GetPose(), T2w = pKF2->GetPose();
+        const Sophus::Sim3f S21 = S12.inverse();
+        const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+        std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+        for (int i = 0; i < N1; i++) {                                              // :1480-1490
+            MapPoint* pMP = vpMatches12[i];
+            if (!pMP) continue;
+            vbAlreadyMatched1[i] = true;
+            const int idx2 = std::get<0>(pMP->GetIndexInKeyFrame(pKF2));
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+        }
+        // one direction: project the map points of `from` into `to` (prelude :1500-1540 / :1586-1626), search, accept <= TH_HIGH
+        auto direction = [&](const std::vector<MapPoint*>& pts, const std::vector<bool>& done, const Sophus::SE3f& Tfw, const Sophus::Sim3f& Sto,
+                             KeyFrame* to, std::vector<int>& vnMatch) {
+            const int n = (int)pts.size(), nK = to->N;
+            std::vector<uint8_t> valid(n, 0), desc((size_t)n * 32, 0);
+            std::vector<float> u(n, 0.f), v(n, 0.f);
+            std::vector<int32_t> lvl(n, 0), bestIdx(std::max(n, 1)), bestDist(std::max(n, 1));
+            for (int i = 0; i < n; i++) {
+                MapPoint* pMP = pts[i];
+                if (!pMP || done[i] || pMP->isBad()) continue;
+                const Eigen::Vector3f p3Dc = Sto * (Tfw * pMP->GetWorldPos());
+                if (p3Dc(2) < 0.0) continue;
+                const float invz = 1.0 / p3Dc(2);
+                const float uu = fx * (p3Dc(0) * invz) + cx, vv = fy * (p3Dc(1) * invz) + cy;
+                if (!to->IsInImage(uu, vv)) continue;
+                const float dist3D = p3Dc.norm();
+                if (dist3D < pMP->GetMinDistanceInvariance() || dist3D > pMP->GetMaxDistanceInvariance()) continue;
+                valid[i] = 1; u[i] = uu; v[i] = vv; lvl[i] = pMP->PredictScale(dist3D, to);
+                const cv::Mat d = pMP->GetDescriptor();
+                std::memcpy(&desc[(size_t)i * 32], d.data, 32);
+            }
+            x_.resize(nK); y_.resize(nK); o_.resize(nK);
+            for (int i = 0; i < nK; i++) { x_[i] = to->mvKeysUn[i].pt.x; y_[i] = to->mvKeysUn[i].pt.y; o_[i] = to->mvKeysUn[i].octave; }
+            OrbmFrame f;
+            f.n = nK; f.x = x_.data(); f.y = y_.data(); f.octave = o_.data(); f.angle = NULL; f.desc = to->mDescriptors.data;
+            f.min_x = to->mnMinX; f.min_y = to->mnMinY; f.max_x = to->mnMaxX; f.max_y = to->mnMaxY;
+            f.grid_cols = to->mnGridCols; f.grid_rows = to->mnGridRows;
+            f.scale_factors = to->mvScaleFactors.data(); f.n_levels = (int)to->mvScaleFactors.size();
+            orbslam3_hip::check(orbm_fuse_search(m_, &f, NULL, NULL, n, valid.data(), u.data(), v.data(), NULL, lvl.data(), desc.data(), th, 0,
+                                                 bestIdx.data(), bestDist.data()));
+            vnMatch.assign(n, -1);
+            for (int i = 0; i < n; i++) if (valid[i] && bestIdx[i] >= 0 && bestDist[i] <= 100 /* TH_HIGH */) vnMatch[i] = bestIdx[i];
+        };
+        std::vector<int> vnMatch1, vnMatch2;
+        direction(vpMapPoints1, vbAlreadyMatched1, T1w, S21, pKF2, vnMatch1);
+        direction(vpMapPoints2, vbAlreadyMatched2, T2w, S12, pKF1, vnMatch2);
+        int nFound = 0;                                                             // agreement :1655-1670
+        for (int i1 = 0; i1 < N1; i1++) {
+            const int idx2 = vnMatch1[i1];
+            if (idx2 >= 0 && vnMatch2[idx2] == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
+        }
+        return nFound;
+    }
 
 private:
     OrbmFrame frameView(Frame& F, std::vector<uint8_t>& occ)
