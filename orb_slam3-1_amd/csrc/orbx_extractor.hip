@@ -290,6 +290,8 @@ int orbx_extractor::setup_geometry(int w, int h)
     // octree kernel LDS
     oct_pool = max_nfeat + 16;
     if (oct_pool > 16000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree", max_nfeat);
+    if ((size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 14 + 2 * kOctLogFactor) + (size_t)((oct_pool + 15) & ~15) > 150 * 1024)
+        return fail(ORBX_ERR_ARG, "%d features on one pyramid level do not fit the octree's LDS node pool (limit about 2600 per level)", max_nfeat);
     const char* env = getenv("ORBX_OCT_LDS_KEYS");
     oct_lds_keys = env ? atoi(env) : 0;      // measured on MI355X: L2-resident HBM scratch + more resident waves beats LDS keys
     oct_keys_forced = env != nullptr;        // ... for large batches; small batches are latency-bound and take LDS keys (enqueue())
@@ -357,11 +359,13 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     // optional per-stage timing with HIP events on the launch stream (bench.py roofline leg)
     int mark_i = 0;
     auto mark = [&]() { if (profile && mark_i < kProfEvents) (void)hipEventRecord(prof_ev[mark_i++], st); };
+#define ORBX_LAUNCHED(name) do { const hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) return fail(ORBX_ERR_HIP, "launch of %s: %s", name, hipGetErrorString(le_)); } while (0)
     mark();
     if (!level0_ready) {
         const LevelDesc& L0 = levels[0];
         dim3 g((L0.w / 4 + 255) / 256, L0.h, B);
         hipLaunchKernelGGL(k_copy_level0, g, dim3(256), 0, st, d_imgs, row_stride, frame_stride, d_pyr.p, pyr_frame_bytes, L0);
+        ORBX_LAUNCHED("k_copy_level0");
     }
     mark();
     for (int l = 1; l < nlevels; l++) {
@@ -369,12 +373,14 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + 3) / 4)), B);
         hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, d_pyr.p, pyr_frame_bytes, levels[l - 1], D,
                            d_xofs[l].p, d_ialpha[l].p, d_yofs[l].p, d_ibeta[l].p);
+        ORBX_LAUNCHED("k_resize");
     }
     mark();
     const int n_cells = (int)cells.size();
     if (n_cells > 0)
         hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(n_cells), B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
                            ini_th, min_th, tile_pitch, tile_rows, m_pitch, surv_off, bits_off, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
+    ORBX_LAUNCHED("k_fast_cells");
     mark();
     // The octree is latency-bound (one wave per frame and level) and leaves most of the chip idle, while the blur only
     // needs the pyramid: run the blur on a side stream next to octree + index and join before the descriptors.
@@ -397,9 +403,11 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     hipLaunchKernelGGL(oct_kernel, dim3(nlevels, B), dim3(64), o_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
                        d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
                        d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status);
+    ORBX_LAUNCHED("k_octree / k_blur");
     mark();
     hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,
                        lap0, lap1, cap, d_kp_dst.p, sel_frame_entries, o_n, o_mono, o_status);
+    ORBX_LAUNCHED("k_index");
     mark();
     if (overlap) ORBX_HIP(hipStreamWaitEvent(st, ev_join, 0));
     else
