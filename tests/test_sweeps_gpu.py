@@ -94,3 +94,60 @@ def test_pose_and_vocab_sweep(pkg, oracle, synth, seed):
     (bi0, bv0), (fn0, fo0, ff0) = oracle_transform(oracle, voc, desc, levelsup)
     np.testing.assert_array_equal(bi1, bi0); np.testing.assert_array_equal(bv1, bv0)
     np.testing.assert_array_equal(fn1, fn0); np.testing.assert_array_equal(fo1, fo0); np.testing.assert_array_equal(ff1, ff0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_matcher_family_sweep(pkg, oracle, sm, seed):
+    rs = np.random.RandomState(2500 + seed)
+    n = int(rs.choice([40, 300, 1000, 2000])); npts = int(rs.choice([1, 100, 1000, 5000]))
+    th = float(rs.choice([2.0, 3.0, 4.0, 10.0])); ori = bool(rs.randint(0, 2))
+    m = pkg.Matcher(float(rs.choice([0.6, 0.8, 0.9])), ori)
+    try:
+        g, dKF, scale, u_right, inv_s2, pts = sm.make_fuse_case(70 + seed, n=n, n_pts=npts, stereo_frac=float(rs.uniform(0, 1)))
+        chi2 = bool(rs.randint(0, 2))
+        bi0, bd0 = oracle.fuse_search(g, dKF, scale, u_right, inv_s2, pts, th, chi2)
+        bi1, bd1 = m.FuseSearch(g, dKF, scale, u_right, inv_s2, pts, th, chi2)
+        np.testing.assert_array_equal(bi1, bi0); np.testing.assert_array_equal(bd1, bd0)
+        g, dF, angF, sc, p, assign, occ = sm.make_kf_projection_case(70 + seed, n=n, n_pts=min(npts, 2000))
+        a0, o0 = assign.copy(), occ.copy(); a1, o1 = assign.copy(), occ.copy()
+        dist = int(rs.choice([50, 64, 100]))
+        assert m.SearchByProjection_kf(g, dF, angF, sc, p, th, dist, a1, o1) == oracle.search_by_projection_kf(g, dF, angF, sc, p, th, dist, ori, a0, o0)
+        np.testing.assert_array_equal(a1, a0); np.testing.assert_array_equal(o1, o0)
+        a0, o0 = assign.copy(), occ.copy(); a1, o1 = assign.copy(), occ.copy()
+        ith = int(rs.choice([3, 8, 30])); rh = float(rs.choice([1.0, 1.5]))
+        assert m.SearchByProjection_sim3(g, dF, sc, p, ith, rh, a1, o1) == oracle.search_by_projection_sim3(g, dF, sc, p, ith, rh, a0, o0)
+        np.testing.assert_array_equal(a1, a0); np.testing.assert_array_equal(o1, o0)
+        k1, k2, ep, F12, sigma2, sc2 = sm.make_triangulation_case(70 + seed, n=n)
+        only_st, coarse = bool(rs.randint(0, 2)), bool(rs.randint(0, 2))
+        n0, m0 = oracle.search_for_triangulation(k1, k2, ep, F12, sigma2, sc2, only_st, coarse, ori)
+        n1, m1 = m.SearchForTriangulation(k1, k2, ep, F12, sigma2, sc2, only_st, coarse)
+        assert n1 == n0
+        np.testing.assert_array_equal(m1, m0)
+        f1, g2, d2, a2, sc3 = sm.make_initialization_case(70 + seed, n=n)
+        win = int(rs.choice([10, 50, 100]))
+        n0, m0 = oracle.search_for_initialization(f1, g2, d2, a2, win, m.nnratio, ori)
+        n1, m1 = m.SearchForInitialization(f1, g2, d2, a2, sc3, win)
+        assert n1 == n0
+        np.testing.assert_array_equal(m1, m0)
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_stereo_sweep(pkg, oracle, synth, seed):
+    from oracle_api import oracle_stereo_matches
+    rs = np.random.RandomState(2900 + seed)
+    w, h = int(rs.choice([320, 640, 752])), int(rs.choice([240, 480]))
+    nfeat = int(rs.choice([300, 1000, 2000])); nlev = int(rs.choice([4, 8])); scale = float(rs.choice([1.2, 1.3]))
+    left, right = synth.make_stereo_pair(80 + seed, w, h, band=int(rs.choice([30, 60, 120])), dmin=1, dmax=int(rs.choice([10, 40, 80])))
+    mb = float(rs.choice([0.05, 0.11, 0.5])); mbf = mb * float(rs.choice([300.0, 435.0]))
+    oL, oR = oracle.extractor(nfeat, scale, nlev, 20, 7), oracle.extractor(nfeat, scale, nlev, 20, 7)
+    _, kL0, dL0 = oL.extract(left, (0, 0)); _, kR0, dR0 = oR.extract(right, (0, 0))
+    _, ur0, dp0 = oracle_stereo_matches(oL, oR, kL0, dL0, kR0, dR0, mb, mbf)
+    exL, exR = pkg.Extractor(nfeat, scale, nlev, 20, 7), pkg.Extractor(nfeat, scale, nlev, 20, 7)
+    try:
+        _, kL, dL = exL(left, (0, 0)); _, kR, dR = exR(right, (0, 0))
+        ur1, dp1 = exL.stereo_matches(exR, kL, dL, kR, dR, mb, mbf)
+    finally:
+        exL.close(); exR.close()
+    np.testing.assert_array_equal(ur1, ur0); np.testing.assert_array_equal(dp1, dp0)
