@@ -848,7 +848,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
             sp[i] = *(const uint32_t*)(pbase + (size_t)r * L.stride + 4 * c);
         }
     }
-    __syncthreads();
+    // the LDS window is private to the wave: its own writes are ordered before its own reads by the LDS queue; only the
+    // compiler has to be kept from reordering them -- no workgroup barrier, so a wave never waits for its three neighbours
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!live) return;
 
     // ---- IC_Angle: lanes 0..30 take column u = lane-15 of rows v = 0..15, lanes 32..62 the same column of rows -1..-15
