@@ -378,7 +378,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     mark();
     const int n_cells = (int)cells.size();
     if (n_cells > 0)
-        hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(n_cells), B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
+        hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(n_cells), B), dim3(kFastThreads), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
                            ini_th, min_th, tile_pitch, tile_rows, m_pitch, surv_off, bits_off, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
     ORBX_LAUNCHED("k_fast_cells");
     mark();

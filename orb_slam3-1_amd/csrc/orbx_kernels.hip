@@ -155,7 +155,7 @@ __device__ unsigned long long d_fast_prof[8];
 #else
 #define ORBX_FTICK(k)
 #endif
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t frame_stride,
+__global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t frame_stride,
                                                     const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
                                                     int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch, int surv_off, int bits_off,
                                                     uint32_t* __restrict__ cand, size_t cand_frame_stride,
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 #endif
     if (tid == 0) s_nsurv = 0;
     // tile load: coalesced dword loads (rows are 64-B aligned in HBM), byte-realigned so that LDS column k = image column x0 + k
-    for (int i = tid; i < th * row_dw; i += 256) {
+    for (int i = tid; i < th * row_dw; i += kFastThreads) {
         const int r = i / row_dw, q = i - r * row_dw;
         const uint32_t* g = (const uint32_t*)(img + (size_t)(c.y0 + r) * L.stride + xa) + q;
         const uint32_t lo = g[0];
@@ -199,14 +199,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
         if (shift) v = __builtin_amdgcn_alignbyte(g[1], lo, (uint32_t)shift);
         *(uint32_t*)(tile + r * tile_pitch + 4 * q) = v;
     }
-    for (int i = tid; i < (ih + 2) * m_pitch / 4; i += 256) ((uint32_t*)mt)[i] = 0;
-    for (int i = tid; i < 512; i += 256) bits_ini[i] = 0;       // both masks
+    for (int i = tid; i < (ih + 2) * m_pitch / 4; i += kFastThreads) ((uint32_t*)mt)[i] = 0;
+    for (int i = tid; i < 512; i += kFastThreads) bits_ini[i] = 0;       // both masks
     __syncthreads();
     ORBX_FTICK(0)
 
     // ---- pass 1 ----
     const int ngx = (iw + 3) >> 2;
-    for (int gi = tid; gi < ngx * ih; gi += 256) {
+    for (int gi = tid; gi < ngx * ih; gi += kFastThreads) {
         const int y = gi / ngx, gx = gi - y * ngx;
         const uint32_t* base = (const uint32_t*)(tile + y * tile_pitch) + gx;      // window: rows y..y+6, bytes 4gx..4gx+11
         const int pd = tile_pitch >> 2;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     ORBX_FTICK(1)
     const int nsurv = s_nsurv;
     // ---- pass 2 ----
-    for (int i = tid; i < nsurv; i += 256) {
+    for (int i = tid; i < nsurv; i += kFastThreads) {
         const int q = surv[i];
         const int y = q / iw, x = q - y * iw;
         const int m = fast_m(tile + (y + 3) * tile_pitch + x + 3, tile_pitch);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     __syncthreads();
     ORBX_FTICK(2)
     // ---- pass 3 ----
-    for (int i = tid; i < nsurv; i += 256) {
+    for (int i = tid; i < nsurv; i += kFastThreads) {
         const int q = surv[i];
         const int y = q / iw, x = q - y * iw;
         const uint8_t* p = mt + (y + 1) * m_pitch + x + 1;
@@ -294,22 +294,28 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
     ORBX_FTICK(3)
     // ---- pass 4: which threshold, then exclusive prefix of the word popcounts (n_int <= 8192 -> <= 256 words) ----
     const int nwords = (n_int + 31) >> 5;
-    const int ini_any = __syncthreads_or(tid < nwords && bits_ini[tid] != 0);
+    bool any_l = false;
+    for (int i = tid; i < nwords; i += kFastThreads) any_l |= bits_ini[i] != 0;
+    const int ini_any = __syncthreads_or(any_l);
     const uint32_t* bits = ini_any ? bits_ini : bits_min;
-    const int my = (tid < nwords) ? __popc(bits[tid]) : 0;
-    int incl = my;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) s_wave_tot[wave] = incl;
-    __syncthreads();
-    int wave_base = 0;
-    for (int w = 0; w < wave; w++) wave_base += s_wave_tot[w];
-    wbase[tid] = (uint32_t)(wave_base + incl - my);
-    const int total = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-    __syncthreads();
+    int total = 0;
+    for (int w0 = 0; w0 < nwords; w0 += kFastThreads) {          // one round for 256 threads, up to four for a single wave
+        const int i = w0 + tid;
+        const int my = (i < nwords) ? __popc(bits[i]) : 0;
+        int incl = my;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_base = total, round_total = 0;
+        for (int w = 0; w < kFastThreads / 64; w++) { if (w < wave) wave_base += s_wave_tot[w]; round_total += s_wave_tot[w]; }
+        if (i < nwords) wbase[i] = (uint32_t)(wave_base + incl - my);
+        total += round_total;
+        __syncthreads();
+    }
     ORBX_FTICK(4)
     // ---- pass 5 ----
     uint32_t* out = cand + (size_t)frame * cand_frame_stride + c.slot_off;
-    for (int i = tid; i < nsurv; i += 256) {
+    for (int i = tid; i < nsurv; i += kFastThreads) {
         const int q = surv[i];
         const uint32_t wd = bits[q >> 5];
         if ((wd >> (q & 31)) & 1u) {
