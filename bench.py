@@ -272,6 +272,32 @@ def main():
                           "lba_solve_call_ms_incl_upload": 1e3 * dt_call, "chi2_initial": stats["chi2_initial"], "chi2_final": stats["chi2_final"]}
             sh.close(); solver.close()
 
+            # ---- independent windows side by side (one map per client session): every window has its own shard, stream and
+            # host thread; the factorisation kernels are single-workgroup, so concurrent windows fill the idle CUs ----
+            import threading
+            n_par = 8
+            shards = [pkg.LbaShard(synth.make_ba_window(10 + i), device=local_rank) for i in range(n_par)]
+            ads = [dmod.LocalHipShard(s_) for s_ in shards]
+            for a_ in ads:
+                dmod.sharded_bundle_adjustment(a_, None, None, max_iters=10)
+            it_par = [0] * n_par
+
+            def _solve(i_):
+                for _ in range(3):
+                    shards[i_].reset()
+                    it_par[i_] += dmod.sharded_bundle_adjustment(ads[i_], None, None, max_iters=10)["iterations"]
+            ths = [threading.Thread(target=_solve, args=(i_,)) for i_ in range(n_par)]
+            t0 = time.perf_counter()
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join()
+            dtp_ = time.perf_counter() - t0
+            out["lba"]["concurrent_windows"] = {"windows": n_par, "value": sum(it_par) / dtp_, "unit": "iters/s (aggregate)",
+                                                "gain_vs_one_window": (sum(it_par) / dtp_) / out["lba"]["value"]}
+            for s_ in shards:
+                s_.close()
+
             # ---- PoseOptimization leg: one workgroup per frame, a batch is one launch ----
             pose_ws = [synth.make_pose_problem(i, n=300, outlier_frac=0.1, stereo_frac=0.0) for i in range(64)] * 4
             ps = pkg.PoseSolver(device=local_rank)
