@@ -36,3 +36,16 @@ for B in (1, 4, 16, 64):
     ex.profile_enable(True); run(); torch.cuda.synchronize(); prof = ex.profile_read(); ex.profile_enable(False)
     print("B=%3d  %.3f ms per call (%.3f ms per frame)  stages %s" % (B, ms, ms / B, {k: round(v, 3) for k, v in prof.items()}))
     ex.close()
+
+# the literal drop-in call: host image in, host key points / descriptors out (ORBextractor::operator())
+import time
+ex = pkg.Extractor()
+img = host[0]
+for _ in range(5):
+    ex(img)
+t0 = time.perf_counter()
+for _ in range(50):
+    mono, kps, desc = ex(img)
+dt = (time.perf_counter() - t0) / 50
+print("host-buffer operator(): %.3f ms per 640x480 frame (%d key points), upload + kernels + download + sync" % (1e3 * dt, len(kps)))
+ex.close()
