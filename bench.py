@@ -388,6 +388,43 @@ def main():
                             "workload": "%d frames x %.0f descriptors through a k=10, L=6 tree (1.1 M nodes), levelsup 4, BowVector + FeatureVector" % (B, n_kp),
                             "ms_per_batch": 1e3 * dtv, "words_per_frame": float(v_nb.float().mean().item())}
 
+        # ---- edge-SLAM packet leg (wire format): packets written from / parsed into the device arrays ----
+        if not args.no_lba:
+            codec = pkg.PacketCodec(device=local_rank)
+            pstride = (codec.packet_bytes(cap, 0) + 3) & ~3
+            p_pay = torch.zeros(B * pstride, dtype=torch.uint8, device=dev)
+            p_len, p_st, p_n2, p_ni, p_st2 = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(5))
+            p_fid = torch.arange(B, dtype=torch.int32, device=dev); p_ts = torch.arange(B, dtype=torch.int64, device=dev) * 50000000
+            p_f2 = torch.zeros_like(p_fid); p_t2 = torch.zeros_like(p_ts)
+            p_k2 = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev); p_d2 = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+
+            def pk_pack():
+                codec.pack_batch_device(d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), B, cap, p_fid.data_ptr(), p_ts.data_ptr(), 0, 0,
+                                        p_pay.data_ptr(), pstride, p_len.data_ptr(), 0, p_st.data_ptr(), stream)
+
+            def pk_unpack():
+                codec.unpack_batch_device(p_pay.data_ptr(), pstride, p_len.data_ptr(), B, cap, 0, p_k2.data_ptr(), p_d2.data_ptr(), p_n2.data_ptr(),
+                                          p_f2.data_ptr(), p_t2.data_ptr(), 0, p_ni.data_ptr(), p_st2.data_ptr(), stream)
+            pk_pack(); pk_unpack(); torch.cuda.synchronize()
+            tms = []
+            for fn in (pk_pack, pk_unpack):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()                              # `stream` is torch's current stream: the events bracket the launches
+                for _ in range(20):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                tms.append(e0.elapsed_time(e1) / 20)
+            pts_total = float(d_n.sum().item())
+            ok = bool((p_st == 0).all().item() and (p_st2 == 0).all().item() and torch.equal(p_n2, d_n))
+            out["packets"] = {"metric": "edge-SLAM packets (SlamPktVI) frames/s, device-resident", "unit": "frames/s", "dtype": "u8",
+                              "pack": {"value": B / (1e-3 * tms[0]), "ms_per_batch": tms[0], "GBps": pts_total * 76 / (1e6 * tms[0])},
+                              "unpack": {"value": B / (1e-3 * tms[1]), "ms_per_batch": tms[1], "GBps": pts_total * 96 / (1e6 * tms[1])},
+                              "round_trip_ok": ok,
+                              "workload": "%d frames x %.0f key points: 16 B + 36 B/point packets written from the extractor's device arrays "
+                                          "(40 B read + 36 B written per point) and parsed back (36 B read + 60 B written per point)" % (B, n_kp)}
+            codec.close()
+
         # ---- CPU baseline leg (N=1 only, rank 0) ----
         if not args.no_cpu and world == 1:
             o, cb = cpu_baseline(synth, host_imgs, match_sets)

@@ -444,6 +444,47 @@ int  orbv_transform_batch_device(orbv_vocab* v, const uint8_t* d_desc, const int
                                  uint32_t* d_bow_id, double* d_bow_val, int32_t* d_n_bow,
                                  uint32_t* d_fv_node, int32_t* d_fv_off, uint32_t* d_fv_feat, int32_t* d_n_fv, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Edge-SLAM wire format (the fork's client <-> server packets).  Replaces the two constructors
+ * of class SlamPktVI, reference include/Socket/slampkt_vi.h:
+ *   :127-167  SlamPktVI(id, timestamp, kps, descriptors, imus)  -> orbe_pack_batch(_device)   (edge client: packets are
+ *             written straight from orbx_extract_batch_device's outputs);  getHead() :185-193 -> `head`
+ *   :85-125   SlamPktVI(buffer, packet_size)                    -> orbe_unpack_batch(_device) (server: key points /
+ *             descriptors land in the layout the matcher and vocabulary kernels read; src/Socket/client.cc:132-143)
+ * Packet = 16-byte info block {int32 frame id, int64 time stamp at byte 4, u16 BE #points, u16 BE #imu}, 36 B per key
+ * point {u16 BE (unsigned short)pt.x, u16 BE (unsigned short)pt.y, 32 descriptor bytes}, 32 B per IMU sample.
+ * Unpacked key points are KeyPoint(x, y, 1): size 1, angle -1, response 0, octave 0, class_id -1 (:101).
+ * Batch layout: frame b's key points at kps + b*cap, descriptors at desc + b*cap*32, packet at payload + b*stride
+ * (stride a multiple of 4).  Per-frame status: ORBX_OK; ORBX_ERR_CAPACITY (packet does not fit stride / counts exceed
+ * cap, imu_cap); ORBX_ERR_ARG (pack: packet larger than 65536 B, which getHead() cannot express; unpack: packet shorter
+ * than its own counts -- the reference would read past the buffer).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct OrbeImuSample {      /* class IMUData, include/Socket/imudata.h:10-20; the 32-byte wire record (:152-161) */
+    int64_t ts;
+    float gyro[3];
+    float acce[3];
+} OrbeImuSample;
+
+typedef struct orbe_codec orbe_codec;
+int  orbe_packet_bytes(int n_pts, int n_imu);                     /* total_len_ = 16 + 36 n_pts + 32 n_imu (:130) */
+int  orbe_create(int device, orbe_codec** out);
+void orbe_destroy(orbe_codec* c);
+/* imu / imu_off may both be NULL (no IMU samples); otherwise frame b owns imu[imu_off[b] .. imu_off[b+1]).  head
+ * (2 bytes per frame, may be NULL) receives getHead().  Host buffers. */
+int  orbe_pack_batch(orbe_codec* c, const OrbxKeyPoint* kps, const uint8_t* desc, const int32_t* n, int batch, int cap,
+                     const int32_t* frame_id, const int64_t* timestamp, const OrbeImuSample* imu, const int32_t* imu_off,
+                     uint8_t* payload, int stride, int32_t* len, uint8_t* head, int32_t* status);
+int  orbe_unpack_batch(orbe_codec* c, const uint8_t* payload, int stride, const int32_t* len, int batch, int cap, int imu_cap,
+                       OrbxKeyPoint* kps, uint8_t* desc, int32_t* n, int32_t* frame_id, int64_t* timestamp,
+                       OrbeImuSample* imu /* [batch][imu_cap] */, int32_t* n_imu, int32_t* status);
+/* Device-resident forms: every pointer is a device pointer; only enqueue on `stream`. */
+int  orbe_pack_batch_device(orbe_codec* c, const OrbxKeyPoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int batch, int cap,
+                            const int32_t* d_frame_id, const int64_t* d_timestamp, const OrbeImuSample* d_imu, const int32_t* d_imu_off,
+                            uint8_t* d_payload, int stride, int32_t* d_len, uint8_t* d_head, int32_t* d_status, void* stream);
+int  orbe_unpack_batch_device(orbe_codec* c, const uint8_t* d_payload, int stride, const int32_t* d_len, int batch, int cap, int imu_cap,
+                              OrbxKeyPoint* d_kps, uint8_t* d_desc, int32_t* d_n, int32_t* d_frame_id, int64_t* d_timestamp,
+                              OrbeImuSample* d_imu, int32_t* d_n_imu, int32_t* d_status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

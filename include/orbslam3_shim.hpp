@@ -97,6 +97,54 @@ struct FlatFeatVec {
     }
 };
 
+// One edge-SLAM packet (class SlamPktVI, include/Socket/slampkt_vi.h) through the device codec, POD in / POD out.
+class EdgePacketCodec {
+public:
+    explicit EdgePacketCodec(int device = 0) { check(orbe_create(device, &h_)); }
+    ~EdgePacketCodec() { orbe_destroy(h_); }
+    EdgePacketCodec(const EdgePacketCodec&) = delete;
+    EdgePacketCodec& operator=(const EdgePacketCodec&) = delete;
+
+    // SlamPktVI(id, timestamp, kps, descriptors, imus) :127-167; head = getHead() :185-193
+    std::vector<uint8_t> pack(int32_t frame_id, int64_t timestamp, const OrbxKeyPoint* kps, const uint8_t* desc, int n_pts,
+                              const OrbeImuSample* imu, int n_imu, uint8_t head[2] = nullptr)
+    {
+        const int total = orbe_packet_bytes(n_pts, n_imu), stride = (total + 3) & ~3;
+        std::vector<uint8_t> payload((size_t)stride);
+        const int32_t off[2] = {0, n_imu};
+        const OrbxKeyPoint none_k = {};
+        const uint8_t none_d[32] = {0};
+        int32_t n = n_pts, len = 0, status = 0;
+        check(orbe_pack_batch(h_, n_pts ? kps : &none_k, n_pts ? desc : none_d, &n, 1, n_pts ? n_pts : 1, &frame_id, &timestamp,
+                              n_imu ? imu : nullptr, n_imu ? off : nullptr, payload.data(), stride, &len, head, &status));
+        if (status == ORBX_ERR_CAPACITY) throw Error(status);
+        payload.resize((size_t)len);
+        return payload;
+    }
+
+    // SlamPktVI(buffer, packet_size) :85-125
+    void unpack(const uint8_t* buffer, int packet_size, int32_t& frame_id, int64_t& timestamp, std::vector<OrbxKeyPoint>& kps,
+                std::vector<uint8_t>& desc, std::vector<OrbeImuSample>& imu)
+    {
+        if (packet_size < 16) throw Error(ORBX_ERR_ARG);
+        const int n_pts = buffer[12] * 256 + buffer[13], n_imu = buffer[14] * 256 + buffer[15];      // capacities only
+        const int stride = (packet_size + 3) & ~3;
+        std::vector<uint8_t> padded((size_t)stride, 0);
+        std::memcpy(padded.data(), buffer, (size_t)packet_size);
+        kps.assign((size_t)(n_pts ? n_pts : 1), OrbxKeyPoint());
+        desc.assign((size_t)(n_pts ? n_pts : 1) * 32, 0);
+        imu.assign((size_t)(n_imu ? n_imu : 1), OrbeImuSample());
+        int32_t len = packet_size, n = 0, m = 0, status = 0;
+        check(orbe_unpack_batch(h_, padded.data(), stride, &len, 1, (int)kps.size(), (int)imu.size(), kps.data(), desc.data(), &n, &frame_id,
+                                &timestamp, imu.data(), &m, &status));
+        if (status < 0) throw Error(status);
+        kps.resize((size_t)n); desc.resize((size_t)n * 32); imu.resize((size_t)m);
+    }
+
+private:
+    orbe_codec* h_ = nullptr;
+};
+
 }  // namespace orbslam3_hip
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -713,5 +761,62 @@ inline int PoseOptimizationHIP(Frame* pFrame)
 }
 
 }  // namespace ORB_SLAM3
+
+// class SlamPktVI (include/Socket/slampkt_vi.h:14-212, global namespace there as well): same two constructors and
+// getters, the byte shuffling done by the device codec.  Needs "Socket/imudata.h" (IMUData).
+#include "Socket/imudata.h"
+class SlamPktVIHIP {
+public:
+    SlamPktVIHIP(unsigned char* buffer, int packet_size) : total_len_(packet_size)                                   // :85
+    {
+        std::vector<OrbxKeyPoint> k; std::vector<uint8_t> d; std::vector<OrbeImuSample> im;
+        int32_t id = 0; int64_t ts = 0;
+        codec().unpack(buffer, packet_size, id, ts, k, d, im);
+        frame_id_ = id; time_stamp_ = (long)ts;
+        payload_.assign(buffer, buffer + packet_size);
+        kps_.reserve(k.size());
+        for (const OrbxKeyPoint& p : k) kps_.push_back(cv::KeyPoint(p.x, p.y, p.size, p.angle, p.response, p.octave, p.class_id));
+        descriptors_ = cv::Mat((int)k.size(), 32, CV_8UC1);
+        if (!k.empty()) std::memcpy(descriptors_.data, d.data(), d.size());
+        for (const OrbeImuSample& s : im) {
+            std::vector<float> g(s.gyro, s.gyro + 3), a(s.acce, s.acce + 3);
+            imus_.push_back(IMUData((long)s.ts, g, a));
+        }
+    }
+    SlamPktVIHIP(int id, long timestamp, std::vector<cv::KeyPoint>& kps, cv::Mat& descriptors, std::vector<IMUData>& imus)   // :127
+        : frame_id_(id), time_stamp_(timestamp), kps_(kps), descriptors_(descriptors), imus_(imus)
+    {
+        std::vector<OrbxKeyPoint> k(kps.size());
+        for (size_t i = 0; i < kps.size(); i++) { k[i] = OrbxKeyPoint(); k[i].x = kps[i].pt.x; k[i].y = kps[i].pt.y; }
+        std::vector<OrbeImuSample> im(imus.size());
+        for (size_t i = 0; i < imus.size(); i++) {
+            im[i].ts = imus[i].ts_;
+            for (int j = 0; j < 3; j++) { im[i].gyro[j] = imus[i].gyro_[j]; im[i].acce[j] = imus[i].acce_[j]; }
+        }
+        cv::Mat d = descriptors.isContinuous() ? descriptors : descriptors.clone();
+        payload_ = codec().pack(id, timestamp, k.data(), d.data, (int)k.size(), im.data(), (int)im.size(), head_);
+        total_len_ = (int)payload_.size();
+    }
+    std::vector<cv::KeyPoint> getKeyPoints() { return kps_; }
+    cv::Mat getDescriptors() { return descriptors_; }
+    std::vector<IMUData> getIMUData() { return imus_; }
+    unsigned char* getPayload() { return payload_.data(); }
+    unsigned char* getHead() { if (total_len_ > 65536) return nullptr; unsigned char* h = new unsigned char[2]; h[0] = head_[0]; h[1] = head_[1]; return h; }   // :185
+    int getTotalLength() { return total_len_; }
+    int getNumPoints() { return (int)kps_.size(); }
+    int getNumIMUs() { return (int)imus_.size(); }
+    int getFrameId() { return frame_id_; }
+    long getTimeStamp() { return time_stamp_; }
+    std::vector<IMUData> imus_;                                                     // public in the reference (src/Socket/client.cc:138)
+
+private:
+    static orbslam3_hip::EdgePacketCodec& codec() { static thread_local orbslam3_hip::EdgePacketCodec c; return c; }
+    int total_len_ = 0, frame_id_ = 0;
+    long time_stamp_ = 0;
+    std::vector<cv::KeyPoint> kps_;
+    cv::Mat descriptors_;
+    std::vector<unsigned char> payload_;
+    unsigned char head_[2] = {0, 0};
+};
 
 #endif  // ORBSLAM3_HIP_WITH_REFERENCE

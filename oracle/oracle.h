@@ -219,6 +219,20 @@ int   lba_oracle_solve(const OracleLbaProblem* p, const volatile uint8_t* stop_f
                        double* poses_q_out, double* poses_t_out, double* points_out,
                        double* chi2_per_edge, uint8_t* depth_positive, OracleLbaStats* stats);
 
+/* Edge-SLAM wire format: class SlamPktVI (reference include/Socket/slampkt_vi.h), IMUData (include/Socket/imudata.h). */
+typedef struct OracleImuSample {
+    int64_t ts;
+    float gyro[3];
+    float acce[3];
+} OracleImuSample;
+/* returns total_len_ (or -total_len_ when it exceeds capacity; nothing is written then); head = getHead() */
+int   edge_oracle_pack(int32_t frame_id, int64_t timestamp, const OracleKeyPoint* kps, const uint8_t* desc, int n_pts,
+                       const OracleImuSample* imu, int n_imu, uint8_t* payload, int capacity, uint8_t head[2]);
+/* 0 ok; -1 packet shorter than its info block / its own counts; -2 counts exceed the caller's capacities */
+int   edge_oracle_unpack(const uint8_t* payload, int packet_size, int32_t* frame_id, int64_t* timestamp,
+                         OracleKeyPoint* kps, uint8_t* desc, int cap_pts, int* n_pts_out,
+                         OracleImuSample* imu, int cap_imu, int* n_imu_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -780,3 +780,77 @@ class Vocabulary:
         _check(lib.orbv_transform_batch_device(self._h, C.c_void_p(d_desc), C.c_void_p(d_n), int(batch), int(cap), int(levelsup),
                                                C.c_void_p(d_bow_id), C.c_void_p(d_bow_val), C.c_void_p(d_n_bow), C.c_void_p(d_fv_node),
                                                C.c_void_p(d_fv_off), C.c_void_p(d_fv_feat), C.c_void_p(d_n_fv), C.c_void_p(stream or 0)))
+
+
+IMU_DTYPE = np.dtype([("ts", "i8"), ("gyro", "f4", (3,)), ("acce", "f4", (3,))])      # OrbeImuSample, the 32-byte wire record
+
+
+class PacketCodec:
+    """The fork's edge-SLAM packets (class SlamPktVI, reference include/Socket/slampkt_vi.h) packed / unpacked on the device."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib.orbe_create(device, C.byref(h)))
+        self._h = h
+        lib.orbe_destroy.argtypes = [C.c_void_p]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.orbe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def packet_bytes(n_pts, n_imu=0):
+        return lib.orbe_packet_bytes(int(n_pts), int(n_imu))
+
+    def pack_batch(self, kps, desc, n, frame_id, timestamp, imu=None, imu_off=None, stride=None):
+        """kps [B][cap] KP_DTYPE, desc [B][cap][32], n [B]; returns (payload [B][stride] u8, len [B], head [B][2], status [B])"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        B, cap = kps.shape
+        n = np.ascontiguousarray(n, np.int32); frame_id = np.ascontiguousarray(frame_id, np.int32)
+        timestamp = np.ascontiguousarray(timestamp, np.int64)
+        assert desc.shape == (B, cap, 32) and n.shape == (B,) and frame_id.shape == (B,) and timestamp.shape == (B,)
+        if imu is not None:
+            imu = np.ascontiguousarray(imu, IMU_DTYPE); imu_off = np.ascontiguousarray(imu_off, np.int32)
+            assert imu_off.shape == (B + 1,) and imu_off[-1] <= len(imu)
+            max_imu = int(np.diff(imu_off).max()) if B else 0
+        else:
+            max_imu = 0
+        if stride is None:
+            stride = (self.packet_bytes(int(n.max()) if B else 0, max_imu) + 3) & ~3
+        payload = np.zeros((B, stride), np.uint8); ln = np.zeros(B, np.int32); head = np.zeros((B, 2), np.uint8); st = np.zeros(B, np.int32)
+        _check(lib.orbe_pack_batch(self._h, _p(kps), _p(desc), _p(n), B, cap, _p(frame_id), _p(timestamp),
+                                   _p(imu) if imu is not None else None, _p(imu_off) if imu is not None else None,
+                                   _p(payload), int(stride), _p(ln), _p(head), _p(st)))
+        return payload, ln, head, st
+
+    def unpack_batch(self, payload, ln, cap, imu_cap=0):
+        """payload [B][stride] u8, ln [B]; returns dict(kps, desc, n, frame_id, timestamp, imu, n_imu, status)"""
+        payload = np.ascontiguousarray(payload, np.uint8); ln = np.ascontiguousarray(ln, np.int32)
+        B, stride = payload.shape
+        kps = np.zeros((B, cap), KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); n = np.zeros(B, np.int32)
+        fid = np.zeros(B, np.int32); ts = np.zeros(B, np.int64); imu = np.zeros((B, max(imu_cap, 1)), IMU_DTYPE)
+        ni = np.zeros(B, np.int32); st = np.zeros(B, np.int32)
+        _check(lib.orbe_unpack_batch(self._h, _p(payload), int(stride), _p(ln), B, int(cap), int(imu_cap), _p(kps), _p(desc), _p(n),
+                                     _p(fid), _p(ts), _p(imu) if imu_cap > 0 else None, _p(ni), _p(st)))
+        return dict(kps=kps, desc=desc, n=n, frame_id=fid, timestamp=ts, imu=imu, n_imu=ni, status=st)
+
+    def pack_batch_device(self, d_kps, d_desc, d_n, batch, cap, d_frame_id, d_timestamp, d_imu, d_imu_off, d_payload, stride, d_len, d_head,
+                          d_status, stream=None):
+        _check(lib.orbe_pack_batch_device(self._h, C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_n), int(batch), int(cap),
+                                          C.c_void_p(d_frame_id), C.c_void_p(d_timestamp), C.c_void_p(d_imu or 0), C.c_void_p(d_imu_off or 0),
+                                          C.c_void_p(d_payload), int(stride), C.c_void_p(d_len), C.c_void_p(d_head or 0), C.c_void_p(d_status),
+                                          C.c_void_p(stream or 0)))
+
+    def unpack_batch_device(self, d_payload, stride, d_len, batch, cap, imu_cap, d_kps, d_desc, d_n, d_frame_id, d_timestamp, d_imu, d_n_imu,
+                            d_status, stream=None):
+        _check(lib.orbe_unpack_batch_device(self._h, C.c_void_p(d_payload), int(stride), C.c_void_p(d_len), int(batch), int(cap), int(imu_cap),
+                                            C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_n), C.c_void_p(d_frame_id),
+                                            C.c_void_p(d_timestamp), C.c_void_p(d_imu or 0), C.c_void_p(d_n_imu), C.c_void_p(d_status),
+                                            C.c_void_p(stream or 0)))

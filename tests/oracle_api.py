@@ -410,3 +410,29 @@ def oracle_stereo_matches(exL, exR, kpsL, descL, kpsR, descR, mb, mbf):
     r = exL.L.orb_oracle_stereo_matches(exL.h, exR.h, _p(kpsL), _p(descL), n, _p(kpsR), _p(descR), len(kpsR),
                                         C.c_float(mb), C.c_float(mbf), _p(ur), _p(dp))
     return r, ur[:n], dp[:n]
+
+
+IMU_DTYPE = np.dtype([("ts", "i8"), ("gyro", "f4", (3,)), ("acce", "f4", (3,))])
+assert IMU_DTYPE.itemsize == 32
+
+
+def oracle_pack_packet(orc, frame_id, timestamp, kps, desc, imu=None):
+    """SlamPktVI(id, timestamp, kps, descriptors, imus): (payload bytes, head bytes)"""
+    kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    imu = np.zeros(0, IMU_DTYPE) if imu is None else np.ascontiguousarray(imu, IMU_DTYPE)
+    total = 16 + 36 * len(kps) + 32 * len(imu)
+    out = np.zeros(total, np.uint8); head = np.zeros(2, np.uint8)
+    r = orc.lib.edge_oracle_pack(C.c_int32(int(frame_id)), C.c_int64(int(timestamp)), _p(kps), _p(desc), len(kps), _p(imu), len(imu),
+                                 _p(out), total, _p(head))
+    assert r == total
+    return out, head
+
+
+def oracle_unpack_packet(orc, payload, cap_pts=4096, cap_imu=256):
+    """SlamPktVI(buffer, packet_size): (status, frame_id, timestamp, kps, desc, imu)"""
+    payload = np.ascontiguousarray(payload, np.uint8)
+    kps = np.zeros(cap_pts, KP_DTYPE); desc = np.zeros((cap_pts, 32), np.uint8); imu = np.zeros(cap_imu, IMU_DTYPE)
+    fid, ts, n, m = C.c_int32(), C.c_int64(), C.c_int(), C.c_int()
+    r = orc.lib.edge_oracle_unpack(_p(payload), len(payload), C.byref(fid), C.byref(ts), _p(kps), _p(desc), cap_pts, C.byref(n),
+                                   _p(imu), cap_imu, C.byref(m))
+    return r, fid.value, ts.value, kps[:n.value], desc[:n.value], imu[:m.value]

@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "orbslam3_hip.h")
 def _declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b((?:orbx|orbm|orbv|lba|pose)_[a-z0-9_]+)\s*\(", src)
+    names = re.findall(r"\b((?:orbx|orbm|orbv|orbe|lba|pose)_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 
@@ -60,6 +60,10 @@ def test_no_device_fails_loudly(pkg):
     with pytest.raises(pkg.OrbxError) as e:
         pkg.Vocabulary(synth.make_vocabulary(0, k=4, L=2))
     assert e.value.code == -4
+    with pytest.raises(pkg.OrbxError) as e:
+        pkg.PacketCodec()
+    assert e.value.code == -4
+    assert pkg.PacketCodec.packet_bytes(1000, 20) == 16 + 36000 + 640        # total_len_ is host arithmetic
 
 
 def test_malformed_vocabulary_rejected(pkg):

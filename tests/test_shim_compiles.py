@@ -20,6 +20,17 @@ int main() {
     if (orbm_hamming(a, b) != 4) return 3;
     try { orbslam3_hip::Extractor ex(1000, 1.2f, 8, 20, 7); std::printf("device ok\\n"); }
     catch (const orbslam3_hip::Error& e) { std::printf("no device: %d\\n", e.code); if (e.code != ORBX_ERR_NO_DEVICE) return 4; }
+    try {
+        orbslam3_hip::EdgePacketCodec codec;
+        OrbxKeyPoint kp[2] = {}; kp[0].x = 258.75f; kp[0].y = 1.9f; kp[1].x = 3.f; kp[1].y = 479.f;
+        unsigned char d[64]; for (int i = 0; i < 64; i++) d[i] = (unsigned char)i;
+        unsigned char head[2];
+        std::vector<uint8_t> pkt = codec.pack(7, 99, kp, d, 2, nullptr, 0, head);
+        if (pkt.size() != 88 || pkt[13] != 2 || pkt[16] != 1 || pkt[17] != 2 || pkt[19] != 1 || head[1] != 88) return 5;
+        int32_t id; int64_t ts; std::vector<OrbxKeyPoint> k; std::vector<uint8_t> dd; std::vector<OrbeImuSample> im;
+        codec.unpack(pkt.data(), (int)pkt.size(), id, ts, k, dd, im);
+        if (id != 7 || ts != 99 || k.size() != 2 || k[0].x != 258.f || k[1].y != 479.f || dd[63] != 63 || !im.empty()) return 6;
+    } catch (const orbslam3_hip::Error& e) { if (e.code != ORBX_ERR_NO_DEVICE) return 7; }
     return 0;
 }
 ''')
