@@ -425,6 +425,30 @@ def main():
                                           "(40 B read + 36 B written per point) and parsed back (36 B read + 60 B written per point)" % (B, n_kp)}
             codec.close()
 
+        # ---- map-point upkeep leg: ComputeDistinctiveDescriptors + UpdateNormalAndDepth for the points of one BA window ----
+        if not args.no_lba:
+            rs_ = np.random.RandomState(11)
+            Pm = 2000; cnt_ = rs_.randint(2, 21, Pm); moff = np.concatenate([[0], np.cumsum(cnt_)]).astype(np.int32)
+            mdesc = np.repeat(rs_.randint(0, 256, (Pm, 32)).astype(np.uint8), cnt_, axis=0) ^ np.packbits(rs_.uniform(size=(moff[-1], 256)) < 0.08, axis=1)
+            mpos = rs_.uniform(-5, 5, (Pm, 3)).astype(np.float32)
+            mcen = (np.repeat(mpos, cnt_, axis=0) + rs_.normal(0, 4, (moff[-1], 3))).astype(np.float32)
+            mls = (np.float32(1.2) ** rs_.randint(0, 8, Pm)).astype(np.float32)
+            mm = pkg.Matcher(device=local_rank)
+            mm.DistinctiveDescriptors(mdesc, moff); mm.UpdateNormalAndDepth(mpos, mcen, moff, mcen[moff[:-1]], mls, 3.58)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                mm.DistinctiveDescriptors(mdesc, moff)
+            dtd = (time.perf_counter() - t0) / 10
+            t0 = time.perf_counter()
+            for _ in range(10):
+                mm.UpdateNormalAndDepth(mpos, mcen, moff, mcen[moff[:-1]], mls, 3.58)
+            dtn = (time.perf_counter() - t0) / 10
+            out["map_points"] = {"metric": "map points/s (host buffers in/out)", "unit": "points/s",
+                                 "distinctive_descriptors": {"value": Pm / dtd, "ms_per_call": 1e3 * dtd},
+                                 "normal_and_depth": {"value": Pm / dtn, "ms_per_call": 1e3 * dtn},
+                                 "workload": "%d map points, 2-20 observations each (%d descriptors)" % (Pm, int(moff[-1]))}
+            mm.close()
+
         # ---- CPU baseline leg (N=1 only, rank 0) ----
         if not args.no_cpu and world == 1:
             o, cb = cpu_baseline(synth, host_imgs, match_sets)

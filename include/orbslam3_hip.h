@@ -294,6 +294,24 @@ int orbm_search_for_initialization(orbm_matcher* m, const uint8_t* desc1, int n1
                                    const float* prev_x, const float* prev_y, const OrbmFrame* f2,
                                    int window_size, float nnratio, int check_orientation, int32_t* match12);
 
+/* Map-point upkeep that LocalMapping / Tracking run on every map point of a new key frame (src/LocalMapping.cc:708-710,
+ * :810-822, src/Tracking.cc:2530, :3457) and the BA epilogues run on every optimised point (src/Optimizer.cc:1494), batched.
+ *
+ * orbm_distinctive_descriptors = MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-402): map point p owns the
+ * descriptors desc[off[p] .. off[p+1]) in the reference's push order (observations in std::map order, left index before right
+ * index, bad key frames skipped, :348-363).  best_idx[p] = BestIdx (row with the least median Hamming distance to the rest,
+ * first one on ties, median = sorted row [0.5*(N-1)]), relative to off[p]; -1 for a point without descriptors (the reference
+ * returns early, :365).  best_median (may be NULL) = BestMedian.
+ *
+ * orbm_update_normal_and_depth = MapPoint::UpdateNormalAndDepth (:433-493): pos[p] = mWorldPos; centers[off[p] .. off[p+1]) =
+ * the camera centres of the observations in loop order (GetCameraCenter / GetRightCameraCenter, :451-468); ref_center[p] =
+ * pRefKF->GetCameraCenter(); level_scale[p] = pRefKF->mvScaleFactors[level] (:471-484); last_level_scale =
+ * mvScaleFactors[nLevels-1].  Outputs mNormalVector, mfMaxDistance, mfMinDistance in the reference's float expressions. */
+int orbm_distinctive_descriptors(orbm_matcher* m, const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median);
+int orbm_update_normal_and_depth(orbm_matcher* m, const float* pos, const float* centers, const int32_t* off, const float* ref_center,
+                                 const float* level_scale, float last_level_scale, int n_points,
+                                 float* normal, float* max_dist, float* min_dist);
+
 /* ------------------------------------------------------------------------------------------------
  * Local bundle adjustment -- replaces the numerical core of
  * Optimizer::LocalBundleAdjustment(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&)

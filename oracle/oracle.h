@@ -233,6 +233,13 @@ int   edge_oracle_unpack(const uint8_t* payload, int packet_size, int32_t* frame
                          OracleKeyPoint* kps, uint8_t* desc, int cap_pts, int* n_pts_out,
                          OracleImuSample* imu, int cap_imu, int* n_imu_out);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-402) and MapPoint::UpdateNormalAndDepth (:433-493), batched:
+ * point p owns rows off[p] .. off[p+1) of desc / centers. */
+void  map_oracle_distinctive(const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median);
+void  map_oracle_normal_and_depth(const float* pos, const float* centers, const int32_t* off, const float* ref_center,
+                                  const float* level_scale, float last_level_scale, int n_points,
+                                  float* normal, float* max_dist, float* min_dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -381,6 +381,24 @@ class Matcher:
                                     _p(pts["ur"]), _p(pts["level"]), _p(pts["desc"]), C.c_float(th), int(chi2_check), _p(bi), _p(bd)))
         return bi[:n], bd[:n]
 
+    def DistinctiveDescriptors(self, desc, off):
+        """MapPoint::ComputeDistinctiveDescriptors for a batch of map points: (BestIdx, BestMedian) per point"""
+        desc = np.ascontiguousarray(desc, np.uint8); off = np.ascontiguousarray(off, np.int32)
+        P = len(off) - 1
+        bi = np.zeros(max(P, 1), np.int32); bm = np.zeros(max(P, 1), np.int32)
+        _check(lib.orbm_distinctive_descriptors(self._h, _p(desc), _p(off), P, _p(bi), _p(bm)))
+        return bi[:P], bm[:P]
+
+    def UpdateNormalAndDepth(self, pos, centers, off, ref_center, level_scale, last_level_scale):
+        """MapPoint::UpdateNormalAndDepth for a batch of map points: (normal [P][3], max_dist, min_dist)"""
+        pos = np.ascontiguousarray(pos, np.float32); centers = np.ascontiguousarray(centers, np.float32); off = np.ascontiguousarray(off, np.int32)
+        ref_center = np.ascontiguousarray(ref_center, np.float32); level_scale = np.ascontiguousarray(level_scale, np.float32)
+        P = len(off) - 1
+        nrm = np.zeros((max(P, 1), 3), np.float32); mx = np.zeros(max(P, 1), np.float32); mn = np.zeros(max(P, 1), np.float32)
+        _check(lib.orbm_update_normal_and_depth(self._h, _p(pos), _p(centers), _p(off), _p(ref_center), _p(level_scale),
+                                                C.c_float(last_level_scale), P, _p(nrm), _p(mx), _p(mn)))
+        return nrm[:P], mx[:P], mn[:P]
+
     class _ProjQuery(C.Structure):
         _fields_ = [("frame", C.c_void_p), ("n_pts", C.c_int32), ("valid", C.c_void_p), ("proj_u", C.c_void_p), ("proj_v", C.c_void_p),
                     ("level", C.c_void_p), ("view_cos", C.c_void_p), ("track_depth", C.c_void_p), ("mp_bad", C.c_void_p), ("angle", C.c_void_p),

@@ -822,6 +822,73 @@ __global__ __launch_bounds__(64) void k_initialization(InitArgs A)
     if (lane == 0) *A.n_matches = nmatches;
 }
 
+// ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-402) for a batch of map points -------------------
+// One wave per map point.  The N observed descriptors are staged in LDS; lane i owns row i of the N x N distance matrix
+// (rows i, i + 64, ... when N > 64) and finds the row's median -- the reference's sort(vDists)[0.5 * (N - 1)] -- as the
+// smallest value v with #{j : d(i, j) <= v} > k by bisection over v in [0, 256] (9 passes over the row, every descriptor
+// read is an LDS broadcast), so no N x N buffer and no sort is needed.  The winner is the FIRST row with the least median
+// (strict < at :391): a DPP minimum over (median << 16 | row) keys.
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ off, int n_points,
+                                                    int32_t* __restrict__ best_idx, int32_t* __restrict__ best_median)
+{
+    extern __shared__ __align__(16) uint8_t s_dyn[];
+    unsigned long long* s_d = (unsigned long long*)s_dyn;              // [N][4]
+    const int p = blockIdx.x;
+    const int o0 = off[p], N = off[p + 1] - o0;
+    if (N <= 0) {
+        if (threadIdx.x == 0) { best_idx[p] = -1; best_median[p] = -1; }
+        return;
+    }
+    const unsigned long long* g = (const unsigned long long*)(desc + (size_t)o0 * 32);
+    for (int j = threadIdx.x; j < N * 4; j += 64) s_d[j] = g[j];
+    __syncthreads();
+    const int k = (N - 1) >> 1;                                         // (size_t)(0.5 * (N - 1))
+    unsigned key = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < N; i += 64) {
+        const unsigned long long a0 = s_d[4 * i], a1 = s_d[4 * i + 1], a2 = s_d[4 * i + 2], a3 = s_d[4 * i + 3];
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < N; j++) {
+                const int d = __popcll(a0 ^ s_d[4 * j]) + __popcll(a1 ^ s_d[4 * j + 1]) + __popcll(a2 ^ s_d[4 * j + 2]) + __popcll(a3 ^ s_d[4 * j + 3]);
+                c += d <= mid;
+            }
+            if (c > k) hi = mid; else lo = mid + 1;
+        }
+        key = min(key, ((unsigned)lo << 16) | (unsigned)i);            // rows of one lane ascend, so min keeps the first
+    }
+    key = wave_min_u32(key);
+    if (threadIdx.x == 0) { best_idx[p] = (int)(key & 0xFFFFu); best_median[p] = (int)(key >> 16); }
+}
+
+// ---- MapPoint::UpdateNormalAndDepth (src/MapPoint.cc:433-493) for a batch of map points ----------------------------
+// One thread per map point: the observation loop is a sequential float accumulation (normal += normali / |normali|), kept
+// in the reference's order and in its float expressions (no FMA contraction in this translation unit).
+__global__ __launch_bounds__(256) void k_normal_depth(const float* __restrict__ pos, const float* __restrict__ centers, const int32_t* __restrict__ off,
+                                                      const float* __restrict__ ref_center, const float* __restrict__ level_scale,
+                                                      float last_scale, int n_points,
+                                                      float* __restrict__ normal, float* __restrict__ max_dist, float* __restrict__ min_dist)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_points) return;
+    const float px = pos[3 * p], py = pos[3 * p + 1], pz = pos[3 * p + 2];
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    const int o0 = off[p], o1 = off[p + 1];
+    for (int o = o0; o < o1; o++) {
+        const float dx = px - centers[3 * o], dy = py - centers[3 * o + 1], dz = pz - centers[3 * o + 2];
+        const float nrm = sqrtf(dx * dx + (dy * dy + dz * dz));           // Eigen's fixed-size redux: x0 + (x1 + x2)
+        nx = nx + dx / nrm; ny = ny + dy / nrm; nz = nz + dz / nrm;
+    }
+    const float cx = px - ref_center[3 * p], cy = py - ref_center[3 * p + 1], cz = pz - ref_center[3 * p + 2];
+    const float dist = sqrtf(cx * cx + (cy * cy + cz * cz));
+    const float mx = dist * level_scale[p];                            // mfMaxDistance (:489)
+    max_dist[p] = mx;
+    min_dist[p] = mx / last_scale;                                     // (:490)
+    const float cnt = (float)(o1 - o0);
+    normal[3 * p] = nx / cnt; normal[3 * p + 1] = ny / cnt; normal[3 * p + 2] = nz / cnt;     // normal / n (:491)
+}
+
 }  // namespace orbm
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1587,6 +1654,74 @@ int orbm_fuse_search(orbm_matcher* m, const OrbmFrame* kf, const float* u_right,
     ORBM_HIP(hipGetLastError());
     ORBM_HIP(hipMemcpyAsync(best_idx, base + obi, sizeof(int32_t) * n_pts, hipMemcpyDeviceToHost, m->stream));
     ORBM_HIP(hipMemcpyAsync(best_dist, base + obd, sizeof(int32_t) * n_pts, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_distinctive_descriptors(orbm_matcher* m, const uint8_t* desc, const int32_t* off, int n_points, int32_t* best_idx, int32_t* best_median)
+{
+    if (!m || n_points < 0 || !off || (n_points > 0 && !best_idx)) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (n_points == 0) return ORBX_OK;
+    if (off[0] != 0) return fail(ORBX_ERR_ARG, "off[0] must be 0");
+    int max_n = 0;
+    for (int p = 0; p < n_points; p++) {
+        const int n = off[p + 1] - off[p];
+        if (n < 0) return fail(ORBX_ERR_ARG, "offsets of point %d decrease", p);
+        max_n = std::max(max_n, n);
+    }
+    const int total = off[n_points];
+    if (total > 0 && !desc) return fail(ORBX_ERR_ARG, "NULL descriptors");
+    if (max_n > 4096) return fail(ORBX_ERR_CAPACITY, "a map point with %d observations exceeds the LDS staging (4096)", max_n);
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    const size_t od = blob.put(desc, (size_t)total * 32), oo = blob.put(off, sizeof(int32_t) * (n_points + 1));
+    const size_t in_bytes = m->h_blob.size();
+    const size_t ob = blob.reserve(sizeof(int32_t) * n_points), om = blob.reserve(sizeof(int32_t) * n_points);
+    int r = m->ensure(m->h_blob.size());
+    if (r) return r;
+    uint8_t* b = m->d_blob;
+    const size_t lds = std::max((size_t)max_n * 32, (size_t)64);
+    ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_distinctive, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORBM_HIP(hipMemcpyAsync(b, m->h_blob.data(), in_bytes, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(orbm::k_distinctive, dim3(n_points), dim3(64), lds, m->stream, b + od, (const int32_t*)(b + oo), n_points,
+                       (int32_t*)(b + ob), (int32_t*)(b + om));
+    ORBM_HIP(hipGetLastError());
+    ORBM_HIP(hipMemcpyAsync(best_idx, b + ob, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, m->stream));
+    if (best_median) ORBM_HIP(hipMemcpyAsync(best_median, b + om, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_update_normal_and_depth(orbm_matcher* m, const float* pos, const float* centers, const int32_t* off, const float* ref_center,
+                                 const float* level_scale, float last_level_scale, int n_points,
+                                 float* normal, float* max_dist, float* min_dist)
+{
+    if (!m || n_points < 0 || !off || (n_points > 0 && (!pos || !ref_center || !level_scale || !normal || !max_dist || !min_dist)))
+        return fail(ORBX_ERR_ARG, "NULL argument");
+    if (n_points == 0) return ORBX_OK;
+    if (off[0] != 0) return fail(ORBX_ERR_ARG, "off[0] must be 0");
+    for (int p = 0; p < n_points; p++)
+        if (off[p + 1] <= off[p]) return fail(ORBX_ERR_ARG, "point %d has no observation (the reference returns before touching it)", p);
+    const int total = off[n_points];
+    if (!centers) return fail(ORBX_ERR_ARG, "NULL camera centres");
+    ORBM_HIP(hipSetDevice(m->device));
+    Blob blob(m->h_blob);
+    const size_t op = blob.put(pos, sizeof(float) * 3 * n_points), oc = blob.put(centers, sizeof(float) * 3 * total);
+    const size_t oo = blob.put(off, sizeof(int32_t) * (n_points + 1)), orc = blob.put(ref_center, sizeof(float) * 3 * n_points);
+    const size_t ol = blob.put(level_scale, sizeof(float) * n_points);
+    const size_t in_bytes = m->h_blob.size();
+    const size_t on = blob.reserve(sizeof(float) * 3 * n_points), omx = blob.reserve(sizeof(float) * n_points), omn = blob.reserve(sizeof(float) * n_points);
+    int r = m->ensure(m->h_blob.size());
+    if (r) return r;
+    uint8_t* b = m->d_blob;
+    ORBM_HIP(hipMemcpyAsync(b, m->h_blob.data(), in_bytes, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(orbm::k_normal_depth, dim3((n_points + 255) / 256), dim3(256), 0, m->stream, (const float*)(b + op), (const float*)(b + oc),
+                       (const int32_t*)(b + oo), (const float*)(b + orc), (const float*)(b + ol), last_level_scale, n_points,
+                       (float*)(b + on), (float*)(b + omx), (float*)(b + omn));
+    ORBM_HIP(hipGetLastError());
+    ORBM_HIP(hipMemcpyAsync(normal, b + on, sizeof(float) * 3 * n_points, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipMemcpyAsync(max_dist, b + omx, sizeof(float) * n_points, hipMemcpyDeviceToHost, m->stream));
+    ORBM_HIP(hipMemcpyAsync(min_dist, b + omn, sizeof(float) * n_points, hipMemcpyDeviceToHost, m->stream));
     ORBM_HIP(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }

@@ -436,3 +436,23 @@ def oracle_unpack_packet(orc, payload, cap_pts=4096, cap_imu=256):
     r = orc.lib.edge_oracle_unpack(_p(payload), len(payload), C.byref(fid), C.byref(ts), _p(kps), _p(desc), cap_pts, C.byref(n),
                                    _p(imu), cap_imu, C.byref(m))
     return r, fid.value, ts.value, kps[:n.value], desc[:n.value], imu[:m.value]
+
+
+def oracle_distinctive(orc, desc, off):
+    """MapPoint::ComputeDistinctiveDescriptors for a batch: (BestIdx, BestMedian) per point"""
+    desc = np.ascontiguousarray(desc, np.uint8); off = np.ascontiguousarray(off, np.int32)
+    P = len(off) - 1
+    bi = np.zeros(max(P, 1), np.int32); bm = np.zeros(max(P, 1), np.int32)
+    orc.lib.map_oracle_distinctive(_p(desc), _p(off), P, _p(bi), _p(bm))
+    return bi[:P], bm[:P]
+
+
+def oracle_normal_and_depth(orc, pos, centers, off, ref_center, level_scale, last_level_scale):
+    """MapPoint::UpdateNormalAndDepth for a batch: (normal [P][3], max_dist, min_dist)"""
+    pos = np.ascontiguousarray(pos, np.float32); centers = np.ascontiguousarray(centers, np.float32); off = np.ascontiguousarray(off, np.int32)
+    ref_center = np.ascontiguousarray(ref_center, np.float32); level_scale = np.ascontiguousarray(level_scale, np.float32)
+    P = len(off) - 1
+    nrm = np.zeros((max(P, 1), 3), np.float32); mx = np.zeros(max(P, 1), np.float32); mn = np.zeros(max(P, 1), np.float32)
+    orc.lib.map_oracle_normal_and_depth(_p(pos), _p(centers), _p(off), _p(ref_center), _p(level_scale), C.c_float(last_level_scale), P,
+                                        _p(nrm), _p(mx), _p(mn))
+    return nrm[:P], mx[:P], mn[:P]
