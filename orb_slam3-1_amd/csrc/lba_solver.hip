@@ -392,26 +392,21 @@ __global__ void k_add_lambda(double* S, int n, double lambda)
 // Per 60-column step: k_chol_diag factors the diagonal block AND inverts it (Gauss-Jordan on [L | I]) in LDS with
 // O(1)-depth steps; k_chol_panel then gets the rows below as a dense product X = A * Linv^T (no substitution chains);
 // k_chol_update applies the trailing update.  The substitutions in k_chol_solve also only need Linv.
-__global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
-                                                   double* __restrict__ Linv, double* __restrict__ scal)
+// Factor AND invert one diagonal block held in registers.  Thread (ty, tx) of a 16 x 16 grid owns the elements
+// (ty + 16a, tx + 16b), a, b < 4, of the 64 x 64-padded block L (identity beyond nb) and of X = L^-1.
+// TWO columns per barrier: the owners publish the raw columns j, j+1 of L and rows j, j+1 of X through double-buffered LDS
+// vectors; every thread then forms the 2x2 pivot factor itself and applies the rank-2 update
+// L -= u0 v0^T + u1 v1^T,  X -= u0 x0^T + u1 x1^T.  Returns false when the block is not positive definite.
+struct CholVec { double col0[2][64], col1[2][64], row0[2][64], row1[2][64]; };
+__device__ __forceinline__ bool chol_tile(double (&Lr)[4][4], int nb, double* __restrict__ Li, CholVec& sv)
 {
-    // Register-resident: thread (ty, tx) of a 16 x 16 grid owns the elements (ty + 16a, tx + 16b), a, b < 4, of the
-    // 64 x 64-padded block L and of X = L^-1.  Per column j one barrier: the owners publish column j of L, row j of X
-    // and the pivot through double-buffered LDS vectors; everybody then updates its registers.
-    // TWO columns per barrier: the owners publish the raw columns j, j+1 of L and rows j, j+1 of X; every thread then
-    // forms the 2x2 pivot factor itself and applies the rank-2 update  L -= u0 v0^T + u1 v1^T,  X -= u0 x0^T + u1 x1^T.
-    // (The block size nb is even: 6 rows per pose.)
-    __shared__ double s_col0[2][64], s_col1[2][64], s_row0[2][64], s_row1[2][64];
+    double (&s_col0)[2][64] = sv.col0; double (&s_col1)[2][64] = sv.col1; double (&s_row0)[2][64] = sv.row0; double (&s_row1)[2][64] = sv.row1;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    double Lr[4][4], Xr[4][4];
+    double Xr[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int r = ty + 16 * a, c = tx + 16 * b;
-            Lr[a][b] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
-            Xr[a][b] = (r == c) ? 1.0 : 0.0;
-        }
+        for (int b = 0; b < 4; b++) Xr[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
     bool failed = false;
     const int nb2 = (nb + 1) & ~1;          // an odd tail column pairs with the identity padding
 #pragma unroll
@@ -511,8 +506,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S,
             }
         }
     }
-    if (failed) { if (tid == 0) scal[5] = 1.0; return; }
-    double* Li = Linv + (size_t)(k0 / NB) * NB * NB;
+    if (failed) return false;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -520,6 +514,149 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S,
             const int r = ty + 16 * a, c = tx + 16 * b;
             if (r < nb && c < nb) Li[r * NB + c] = (c <= r) ? Xr[a][b] : 0.0;
         }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
+                                                   double* __restrict__ Linv, double* __restrict__ scal)
+{
+    __shared__ CholVec sv;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double Lr[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            Lr[a][b] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
+        }
+    if (!chol_tile(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+}
+
+// One launch per block column K (instead of panel + update + the next diagonal factorisation): the workgroup of trailing
+// tile (bi, bj), K < bj <= bi, recomputes the two panel blocks it needs, X_i = A_iK Linv_K^T and X_j (a 60^3 product each --
+// cheaper than a launch), applies T_ij -= X_i X_j^T to its register tile, and the workgroup of tile (K+1, K+1) goes straight
+// on to factor and invert it, while the other tiles are still being updated.  The tiles of block column K+1 also store their
+// X_i (= L_iK) into a second (n+1) x n buffer Lp, which the substitution kernel then reads.  The right-hand side (row n of the (n+1) x n buffer) rides along as a 61st row of the last block row.
+constexpr int kFusedMaxBlocks = 8;       // up to 480 reduced unknowns (80 key frames); larger systems keep panel / update launches
+constexpr int kStepLds = (NB * (NB + 1) + 2 * 64 * (NB + 1)) * 8 + (int)sizeof(CholVec);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_step(double* __restrict__ S, double* __restrict__ Lp, int n, int K, int nblk,
+                                                   double* __restrict__ Linv, double* __restrict__ scal)
+{
+    extern __shared__ __align__(16) double sm_step[];
+    constexpr int P = NB + 1;
+    double* sI = sm_step;
+    double* sXi = sI + NB * P;
+    double* sXj = sXi + 64 * P;
+    CholVec& sv = *(CholVec*)(sXj + 64 * P);
+    if (scal[5] != 0.0) return;         // an earlier diagonal block was not positive definite
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    int li = 0, t = blockIdx.x;
+    while (t > li) { t -= li + 1; li++; }
+    const int bi = K + 1 + li, bj = K + 1 + t;
+    const bool diag_tile = bi == bj;
+    const int k0 = K * NB;                                              // block K is a full one (it is not the last)
+    const int r0 = bi * NB, nri = min(NB, n - r0) + (bi == nblk - 1 ? 1 : 0);       // + the right-hand-side row
+    const int c0 = bj * NB, ncj = min(NB, n - c0);
+    const double* Lk = Linv + (size_t)K * NB * NB;
+    {
+        // staging: all loads of a thread are issued before the first LDS store (16-byte loads; n = 6 * poses is even and
+        // every row segment starts at an even column, so the double2 accesses are aligned)
+        constexpr int H = NB / 2, kIt = (64 * H + 255) / 256;          // 30 double2 per row, 8 rounds
+        double2 vI[kIt], vA[kIt], vB[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; it++) {
+            const int i = tid + 256 * it, r = i / H, q2 = i - r * H;
+            vI[it] = make_double2(0.0, 0.0); vA[it] = vI[it]; vB[it] = vI[it];
+            if (r < NB) vI[it] = *(const double2*)(Lk + r * NB + 2 * q2);
+            if (r < nri) vA[it] = *(const double2*)(S + (size_t)(r0 + r) * n + k0 + 2 * q2);
+            if (!diag_tile && r < ncj) vB[it] = *(const double2*)(S + (size_t)(c0 + r) * n + k0 + 2 * q2);
+        }
+#pragma unroll
+        for (int it = 0; it < kIt; it++) {
+            const int i = tid + 256 * it, r = i / H, q2 = i - r * H;
+            if (r < NB) { sI[r * P + 2 * q2] = vI[it].x; sI[r * P + 2 * q2 + 1] = vI[it].y; }
+            if (r < 64) {
+                sXi[r * P + 2 * q2] = vA[it].x; sXi[r * P + 2 * q2 + 1] = vA[it].y;
+                sXj[r * P + 2 * q2] = vB[it].x; sXj[r * P + 2 * q2 + 1] = vB[it].y;
+            }
+        }
+    }
+    __syncthreads();
+    // X = A Linv^T, X[r][c] = sum_{q <= c} A[r][q] Linv[c][q]: a 4 x 4 block per thread (16 row groups x 15 column groups)
+    double xi[4][4], xj[4][4];
+    const int rb = tid / 15, cg = tid - rb * 15;
+    if (tid < 240) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { xi[r][c] = 0.0; xj[r][c] = 0.0; }
+        const double* ai = sXi + (4 * rb) * P;
+        const double* aj = sXj + (4 * rb) * P;
+        const double* l = sI + (4 * cg) * P;
+        const int qmax = 4 * cg + 4;
+        for (int q = 0; q < qmax; q++) {
+            const double l0 = l[q], l1 = l[P + q], l2 = l[2 * P + q], l3 = l[3 * P + q];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double a = ai[r * P + q];
+                xi[r][0] = fma(a, l0, xi[r][0]); xi[r][1] = fma(a, l1, xi[r][1]); xi[r][2] = fma(a, l2, xi[r][2]); xi[r][3] = fma(a, l3, xi[r][3]);
+            }
+            if (!diag_tile) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double a = aj[r * P + q];
+                    xj[r][0] = fma(a, l0, xj[r][0]); xj[r][1] = fma(a, l1, xj[r][1]); xj[r][2] = fma(a, l2, xj[r][2]); xj[r][3] = fma(a, l3, xj[r][3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 240) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                sXi[(4 * rb + r) * P + 4 * cg + c] = xi[r][c];
+                if (!diag_tile) sXj[(4 * rb + r) * P + 4 * cg + c] = xj[r][c];
+            }
+    }
+    __syncthreads();
+    if (bj == K + 1) {      // this tile's X_i is L_iK: keep it -- in Lp, because the other tiles of this block row still read A_iK from S
+        for (int i = tid; i < nri * NB; i += 256) { const int r = i / NB, q = i - r * NB; Lp[(size_t)(r0 + r) * n + k0 + q] = sXi[r * P + q]; }
+    }
+    const double* sB = diag_tile ? sXi : sXj;
+    double Lr[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            Lr[a][b] = (r < nri && c < ncj) ? S[(size_t)(r0 + r) * n + c0 + c] : 0.0;
+        }
+    for (int q = 0; q < NB; q++) {
+        double va[4], vb[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { va[a] = sXi[(ty + 16 * a) * P + q]; vb[a] = sB[(tx + 16 * a) * P + q]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) Lr[a][b] = fma(-va[a], vb[b], Lr[a][b]);
+    }
+    const bool factor_here = diag_tile && bi == K + 1;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            const bool live = r < nri && c < ncj && (!diag_tile || c <= r);
+            // the tile that is factored next stays in registers, except a right-hand-side row riding along with it
+            if (live && (!factor_here || r >= ncj)) S[(size_t)(r0 + r) * n + c0 + c] = Lr[a][b];
+            if (factor_here && (r >= ncj || c >= ncj)) Lr[a][b] = (r == c) ? 1.0 : 0.0;
+        }
+    if (factor_here) {
+        if (!chol_tile(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+    }
 }
 
 constexpr int kPanelRows = 64;
@@ -591,7 +728,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
 // x = L^-T y by block back-substitution with the inverted diagonal blocks (y = L^-1 b was produced by the factorisation
 // itself, see k_chol_panel); one 1024-thread workgroup, 16 row groups x 64 columns, coalesced along the columns.
 __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ S, int n, const double* __restrict__ Linv,
-                                                     const double* __restrict__ yin, double* __restrict__ x, const double* __restrict__ scal)
+                                                     const double* __restrict__ yin, const double* __restrict__ yin_last,
+                                                     double* __restrict__ x, const double* __restrict__ scal, int last_forward)
 {
     extern __shared__ double sm[];      // y[n], t[64], part[16][64]
     double* y = sm;
@@ -599,9 +737,20 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
     double* part = t + 64;
     const int tid = threadIdx.x;
     if (scal[5] != 0.0) { for (int i = tid; i < n; i += 1024) x[i] = 0.0; return; }
-    for (int i = tid; i < n; i += 1024) y[i] = yin[i];
-    __syncthreads();
     const int nblk = (n + NB - 1) / NB;
+    // fused factorisation: S = the L panels, yin = their right-hand-side row, yin_last = the updated b of the last block
+    for (int i = tid; i < n; i += 1024) y[i] = (last_forward && i >= (nblk - 1) * NB) ? yin_last[i] : yin[i];
+    __syncthreads();
+    if (last_forward) {     // the fused factorisation stops at the last diagonal block: finish y = L^-1 b for that block here
+        const int k0 = (nblk - 1) * NB, nb = n - k0;
+        const double* Li = Linv + (size_t)(nblk - 1) * NB * NB;
+        double sv = 0;
+        if (tid < nb)
+            for (int q = 0; q <= tid; q++) sv += y[k0 + q] * Li[tid * NB + q];
+        __syncthreads();
+        if (tid < nb) y[k0 + tid] = sv;
+        __syncthreads();
+    }
     const int g64 = tid >> 6, r64 = tid & 63;       // 16 groups x 64 rows
     // backward sweep: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J)
     for (int K = nblk - 1; K >= 0; K--) {
@@ -715,6 +864,7 @@ struct lba_shard {
     int cur = 0;                // index of the accepted state; 1-cur holds the trial state
     double* reduce = nullptr;   // [n*n | bs n | bp n | diag n]
     double* Linv = nullptr;
+    double* Lp = nullptr;       // L panels of the fused factorisation, (n+1) x n like the reduce buffer's S | b_schur
     double* Ldiag = nullptr;
     bool sync_after_reduce = true;      // lba_solve() keeps everything on one stream and turns this off
     bool lambda_in_reduce = false;      // single-GPU: add lambda to diag(S) inside k_schur_blocks (no all-reduce in between)
@@ -879,6 +1029,8 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     LBA_TRY(s->dalloc(&s->reduce, (size_t)s->reduce_len));
     s->nblk = (d.n + lba::NB - 1) / lba::NB;
     LBA_TRY(s->dalloc(&s->Linv, (size_t)std::max(s->nblk, 1) * lba::NB * lba::NB));
+    if (s->nblk <= lba::kFusedMaxBlocks) LBA_TRY(s->dalloc(&s->Lp, ((size_t)d.n + 1) * (size_t)std::max(d.n, 1)));
+    LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
     LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
     if (s->owns_hscal && hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
@@ -1021,7 +1173,16 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
     LBA_HIP(hipMemsetAsync(d.scal + 5, 0, sizeof(double), s->stream));
     if (n > 0) {
         if (!s->lambda_added) hipLaunchKernelGGL(lba::k_add_lambda, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->S(), n, lambda);
-        for (int K = 0; K < s->nblk; K++) {
+        const bool fused = s->nblk <= lba::kFusedMaxBlocks;
+        if (fused) {
+            // one launch per block column: panel + trailing update + the next diagonal factorisation (k_chol_step)
+            hipLaunchKernelGGL(lba::k_chol_diag, dim3(1), dim3(256), 0, s->stream, (const double*)s->S(), n, 0, std::min(lba::NB, n), s->Linv, d.scal);
+            for (int K = 0; K + 1 < s->nblk; K++) {
+                const int T = s->nblk - 1 - K;
+                hipLaunchKernelGGL(lba::k_chol_step, dim3(T * (T + 1) / 2), dim3(256), lba::kStepLds, s->stream, s->S(), s->Lp, n, K, s->nblk, s->Linv, d.scal);
+            }
+        }
+        for (int K = 0; K < s->nblk && !fused; K++) {
             const int k0 = K * lba::NB, nb = std::min(lba::NB, n - k0);
             const int rows_below = (n + 1) - k0 - nb;       // includes the right-hand-side row n (always >= 1)
             hipLaunchKernelGGL(lba::k_chol_diag, dim3(1), dim3(256), 0, s->stream, (const double*)s->S(), n, k0, nb, s->Linv, d.scal);
@@ -1033,7 +1194,8 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
             }
         }
         hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), ((size_t)n + 64 + 16 * 64) * sizeof(double), s->stream,
-                           (const double*)s->S(), n, (const double*)s->Linv, (const double*)s->bs(), d.x, (const double*)d.scal);
+                           (const double*)(fused ? s->Lp : s->S()), n, (const double*)s->Linv,
+                           (const double*)(fused ? s->Lp + (size_t)n * n : s->bs()), (const double*)s->bs(), d.x, (const double*)d.scal, fused ? 1 : 0);
     }
     hipLaunchKernelGGL(lba::k_backsub_update, dim3((d.nL + d.nPoses + 63) / 64), dim3(64), 0, s->stream, d, lambda, s->bpf(), P, X, Pn, Xn);
     if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, (const double*)Pn, (const double*)Xn);
