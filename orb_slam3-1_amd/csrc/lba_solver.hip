@@ -731,34 +731,44 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
                                                      const double* __restrict__ yin, const double* __restrict__ yin_last,
                                                      double* __restrict__ x, const double* __restrict__ scal, int last_forward)
 {
-    extern __shared__ double sm[];      // y[n], t[64], part[16][64]
+    extern __shared__ double sm[];      // y[n], t[64], part[16][64], Linv block [NB][NB + 1]
+    constexpr int P = NB + 1;
     double* y = sm;
     double* t = sm + n;
     double* part = t + 64;
+    double* sL = part + 16 * 64;
     const int tid = threadIdx.x;
     if (scal[5] != 0.0) { for (int i = tid; i < n; i += 1024) x[i] = 0.0; return; }
     const int nblk = (n + NB - 1) / NB;
     // fused factorisation: S = the L panels, yin = their right-hand-side row, yin_last = the updated b of the last block
     for (int i = tid; i < n; i += 1024) y[i] = (last_forward && i >= (nblk - 1) * NB) ? yin_last[i] : yin[i];
-    __syncthreads();
-    if (last_forward) {     // the fused factorisation stops at the last diagonal block: finish y = L^-1 b for that block here
-        const int k0 = (nblk - 1) * NB, nb = n - k0;
-        const double* Li = Linv + (size_t)(nblk - 1) * NB * NB;
-        double sv = 0;
-        if (tid < nb)
-            for (int q = 0; q <= tid; q++) sv += y[k0 + q] * Li[tid * NB + q];
-        __syncthreads();
-        if (tid < nb) y[k0 + tid] = sv;
-        __syncthreads();
-    }
     const int g64 = tid >> 6, r64 = tid & 63;       // 16 groups x 64 rows
-    // backward sweep: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J)
+    // backward sweep: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J); the inverted diagonal block is staged in LDS (its loads
+    // are in flight together with those of the L_JK rows)
     for (int K = nblk - 1; K >= 0; K--) {
         const int k0 = K * NB, nb = min(NB, n - k0);
         {
+            const double* Li = Linv + (size_t)K * NB * NB;
+            double li[4];
+#pragma unroll
+            for (int it = 0; it < 4; it++) { const int i = tid + 1024 * it; li[it] = (i < NB * NB) ? Li[i] : 0.0; }
+            __syncthreads();            // y complete (first round) / previous block done with sL, t, part
+#pragma unroll
+            for (int it = 0; it < 4; it++) { const int i = tid + 1024 * it; if (i < NB * NB) { const int r = i / NB; sL[r * P + i - r * NB] = li[it]; } }
+        }
+        if (K == nblk - 1 && last_forward) {    // the fused factorisation stops at the last diagonal block: y = L^-1 b for that block
+            __syncthreads();
+            double sv = 0;
+            if (tid < nb)
+                for (int q = 0; q <= tid; q++) sv += y[k0 + q] * sL[tid * P + q];
+            __syncthreads();
+            if (tid < nb) y[k0 + tid] = sv;
+            __syncthreads();
+        }
+        {
             double sv = 0;
             if (r64 < nb) {
-#pragma unroll 4
+#pragma unroll 8
                 for (int q = k0 + nb + g64; q < n; q += 16) sv += S[(size_t)q * n + k0 + r64] * y[q];
             }
             part[g64 * 64 + r64] = sv;
@@ -771,14 +781,13 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
         }
         __syncthreads();
         if (tid < nb) {
-            const double* Li = Linv + (size_t)K * NB * NB;
             double sv = 0;
 #pragma unroll 4
-            for (int q = tid; q < nb; q++) sv += Li[q * NB + tid] * t[q];
+            for (int q = tid; q < nb; q++) sv += sL[q * P + tid] * t[q];
             y[k0 + tid] = sv;
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int i = tid; i < n; i += 1024) x[i] = y[i];
 }
 
@@ -1031,6 +1040,11 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     LBA_TRY(s->dalloc(&s->Linv, (size_t)std::max(s->nblk, 1) * lba::NB * lba::NB));
     if (s->nblk <= lba::kFusedMaxBlocks) LBA_TRY(s->dalloc(&s->Lp, ((size_t)d.n + 1) * (size_t)std::max(d.n, 1)));
     LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
+    {
+        const size_t solve_lds = ((size_t)d.n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
+        if (solve_lds > 160 * 1024) LBA_TRY(fail(ORBX_ERR_CAPACITY, "%d reduced unknowns exceed the substitution kernel's LDS", d.n));
+        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
+    }
     LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
     if (s->owns_hscal && hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
@@ -1193,7 +1207,7 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
                 hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, n + 1, k0, nb, (const double*)d.scal);
             }
         }
-        hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), ((size_t)n + 64 + 16 * 64) * sizeof(double), s->stream,
+        hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), ((size_t)n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double), s->stream,
                            (const double*)(fused ? s->Lp : s->S()), n, (const double*)s->Linv,
                            (const double*)(fused ? s->Lp + (size_t)n * n : s->bs()), (const double*)s->bs(), d.x, (const double*)d.scal, fused ? 1 : 0);
     }
