@@ -17,10 +17,14 @@
 // Every reduction is ordered (CSR gather or fixed tree), so results are reproducible run to run.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -262,7 +266,9 @@ __global__ __launch_bounds__(256) void k_lin_poses(Dev d, const double* __restri
 
 // ---- deterministic scalar reductions (single workgroup) ----
 // mode 0: chi2 = sum rho0, max diagonals.  mode 1: chi2 = sum rho0, scale = sum partials.
-__global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode)
+// The results also go to a host-mapped, coherent buffer followed by a sequence number (system-scope release), so that the
+// host reads them by polling that word instead of a device-to-host copy plus a stream synchronisation per LM trial.
+__global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode, double* __restrict__ hmap, unsigned long long seq)
 {
     __shared__ double s_a[1024], s_b[1024], s_c[1024];
     const int tid = threadIdx.x;
@@ -289,6 +295,13 @@ __global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode)
         d.scal[0] = s_a[0];
         if (mode == 0) { d.scal[1] = s_b[0]; d.scal[2] = s_c[0]; }
         else { d.scal[3] = s_b[0]; d.scal[4] = s_c[0]; }
+        if (hmap) {
+            hmap[0] = s_a[0];
+            if (mode == 0) { hmap[1] = s_b[0]; hmap[2] = s_c[0]; }
+            else { hmap[3] = s_b[0]; hmap[4] = s_c[0]; hmap[5] = d.scal[5]; }
+            __threadfence_system();
+            __hip_atomic_store((unsigned long long*)(hmap + 8), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -880,7 +893,9 @@ struct lba_shard {
     bool lambda_added = false;
     double* d_chi2 = nullptr;
     uint8_t* d_depth = nullptr;
-    double* h_scal = nullptr;   // pinned [16]
+    double* h_scal = nullptr;   // pinned, host-mapped and coherent [16]: [0..5] scalars, [8] sequence number of the last k_reduce
+    double* d_hmap = nullptr;   // the same buffer as the device sees it
+    unsigned long long seq = 0;
     int64_t reduce_len = 0;
     bool err_valid = false;
     bool err_current = false;           // d.err / d.rho0 belong to the accepted state poses[cur]
@@ -888,8 +903,12 @@ struct lba_shard {
 
     // optional bump arena owned by an lba_solver (avoids ~40 hipMalloc/hipFree per LocalBundleAdjustment call)
     uint8_t* arena = nullptr;
-    size_t arena_cap = 0, arena_off = 0, bytes_wanted = 0;
+    size_t arena_cap = 0, arena_off = 0, bytes_wanted = 0, upload_bytes = 0;
     bool owns_stream = true, owns_hscal = true;
+    // optional pinned mirror of the arena's prefix (also the solver's): the problem arrays are packed there and go up in ONE
+    // asynchronous copy instead of ~20 synchronous ones from pageable memory
+    uint8_t* stage = nullptr;
+    size_t stage_cap = 0, stage_end = 0;
 
     template <typename T>
     int dalloc(T** p, size_t count)
@@ -906,14 +925,44 @@ struct lba_shard {
         allocs.push_back(*p);
         return ORBX_OK;
     }
+#define LBA_TRY_RET(x) do { const int r_ = (x); if (r_) return r_; } while (0)
     template <typename T>
     int upload(const T** p, const std::vector<T>& v)
     {
         T* q;
         int r = dalloc(&q, v.size());
         if (r) return r;
-        if (!v.empty()) LBA_HIP(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (!v.empty()) LBA_TRY_RET(put(q, v.data(), v.size() * sizeof(T)));
         *p = q;
+        return ORBX_OK;
+    }
+    template <typename T>
+    int upload_raw(const T** p, const T* src, size_t count)
+    {
+        T* q;
+        int r = dalloc(&q, count);
+        if (r) return r;
+        if (count) LBA_TRY_RET(put(q, src, count * sizeof(T)));
+        *p = q;
+        return ORBX_OK;
+    }
+    // host -> device: through the pinned mirror when the destination lies in the mirrored arena prefix (flushed by flush_stage)
+    int put(void* dst, const void* src, size_t bytes)
+    {
+        const uint8_t* d8 = (const uint8_t*)dst;
+        if (stage && arena && d8 >= arena && (size_t)(d8 - arena) + bytes <= stage_cap) {
+            const size_t off = (size_t)(d8 - arena);
+            std::memcpy(stage + off, src, bytes);
+            stage_end = std::max(stage_end, off + bytes);
+            return ORBX_OK;
+        }
+        LBA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return ORBX_OK;
+    }
+    int flush_stage()
+    {
+        if (stage_end > 0) LBA_HIP(hipMemcpyAsync(arena, stage, stage_end, hipMemcpyHostToDevice, stream));
+        stage_end = 0;
         return ORBX_OK;
     }
     double* S() { return reduce; }
@@ -942,6 +991,8 @@ struct lba_solver {
     size_t arena_cap = 0;
     hipStream_t stream = nullptr;
     double* h_scal = nullptr;
+    uint8_t* stage = nullptr;       // pinned mirror of the arena prefix that holds the uploaded arrays
+    size_t stage_cap = 0;
 };
 
 extern "C" void lba_shard_destroy(lba_shard* s);
@@ -962,6 +1013,7 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
         s->arena = owner->arena; s->arena_cap = owner->arena_cap;
         s->stream = owner->stream; s->owns_stream = false;
         s->h_scal = owner->h_scal; s->owns_hscal = false;
+        s->stage = owner->stage; s->stage_cap = owner->stage_cap;
     }
     std::memset(&s->d, 0, sizeof(s->d));
     lba::Dev& d = s->d;
@@ -977,44 +1029,46 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     for (int c = 0; c < d.nP; c++) p_off[c + 1] += p_off[c];
     std::vector<int> l_edge(std::max(d.nE, 1)), p_edge(std::max(p_off[d.nP], 1)), lc(l_off.begin(), l_off.end() - 1), pc(p_off.begin(), p_off.end() - 1);
     for (int e = 0; e < d.nE; e++) { l_edge[lc[p->edge_point[e]]++] = e; const int c = pose_col[p->edge_pose[e]]; if (c >= 0) p_edge[pc[c]++] = e; }
-    // pair list per block (i <= j)
-    std::vector<int64_t> cnt((size_t)d.nP * d.nP, 0);
+    // pair list per block (i <= j): one gather of (column, edge) per landmark, then count and fill
+    std::vector<int> ecol(std::max(d.nE, 1));
+    for (int e = 0; e < d.nE; e++) ecol[e] = pose_col[p->edge_pose[e]];
+    std::vector<int> cnt((size_t)d.nP * d.nP, 0);
     for (int l = 0; l < d.nL; l++)
         for (int a = l_off[l]; a < l_off[l + 1]; a++) {
-            const int i = pose_col[p->edge_pose[l_edge[a]]];
+            const int i = ecol[l_edge[a]];
             if (i < 0) continue;
+            int* row = cnt.data() + (size_t)i * d.nP;
             for (int b = l_off[l]; b < l_off[l + 1]; b++) {
-                const int j = pose_col[p->edge_pose[l_edge[b]]];
-                if (j < 0 || j < i) continue;
-                cnt[(size_t)i * d.nP + j]++;
+                const int j = ecol[l_edge[b]];
+                if (j >= i) row[j]++;
             }
         }
-    std::vector<int> b_i, b_j, b_off(1, 0);
-    std::vector<int64_t> blk_of((size_t)d.nP * d.nP, -1);
-    for (int i = 0; i < d.nP; i++)
-        for (int j = i; j < d.nP; j++)
-            {       // every block of the upper triangle gets an entry (possibly with an empty pair list)
-                blk_of[(size_t)i * d.nP + j] = (int64_t)b_i.size();
-                b_i.push_back(i); b_j.push_back(j);
-                b_off.push_back(b_off.back() + (int)cnt[(size_t)i * d.nP + j]);
+    // every block of the upper triangle gets an entry (possibly with an empty pair list)
+    d.nBlocks = d.nP * (d.nP + 1) / 2;
+    std::vector<int> b_i(std::max(d.nBlocks, 1)), b_j(std::max(d.nBlocks, 1)), b_off(d.nBlocks + 1, 0), blk_of((size_t)d.nP * d.nP, -1);
+    {
+        int k = 0;
+        for (int i = 0; i < d.nP; i++)
+            for (int j = i; j < d.nP; j++, k++) {
+                blk_of[(size_t)i * d.nP + j] = k;
+                b_i[k] = i; b_j[k] = j;
+                b_off[k + 1] = b_off[k] + cnt[(size_t)i * d.nP + j];
             }
-    d.nBlocks = (int)b_i.size();
+    }
     std::vector<int2> pairs(std::max(b_off.back(), 1));
     std::vector<int> bc(b_off.begin(), b_off.end() - 1);
     for (int l = 0; l < d.nL; l++)
         for (int a = l_off[l]; a < l_off[l + 1]; a++) {
-            const int i = pose_col[p->edge_pose[l_edge[a]]];
+            const int ea = l_edge[a], i = ecol[ea];
             if (i < 0) continue;
+            const int* brow = blk_of.data() + (size_t)i * d.nP;
             for (int b = l_off[l]; b < l_off[l + 1]; b++) {
-                const int j = pose_col[p->edge_pose[l_edge[b]]];
-                if (j < 0 || j < i) continue;
-                int2 pr; pr.x = l_edge[a]; pr.y = l_edge[b];
-                pairs[bc[blk_of[(size_t)i * d.nP + j]]++] = pr;
+                const int eb = l_edge[b], j = ecol[eb];
+                if (j < i) continue;
+                int2 pr; pr.x = ea; pr.y = eb;
+                pairs[bc[brow[j]]++] = pr;
             }
         }
-    std::vector<int> e_point(p->edge_point, p->edge_point + d.nE), e_pose(p->edge_pose, p->edge_pose + d.nE);
-    std::vector<double> e_obs(p->edge_obs, p->edge_obs + 3 * (size_t)d.nE), e_w(p->edge_inv_sigma2, p->edge_inv_sigma2 + d.nE);
-    std::vector<uint8_t> e_st(p->edge_stereo, p->edge_stereo + d.nE);
     std::vector<double> poses(7 * (size_t)p->n_poses);
     for (int i = 0; i < p->n_poses; i++) {
         for (int k = 0; k < 4; k++) poses[7 * i + k] = p->pose_q[4 * i + k];
@@ -1022,10 +1076,13 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     }
 #define LBA_TRY(x) do { r = (x); if (r) { lba_shard_destroy(s); return r; } } while (0)
     LBA_TRY(s->upload(&d.pose_col, pose_col)); LBA_TRY(s->upload(&d.col_pose, col_pose));
-    LBA_TRY(s->upload(&d.e_point, e_point)); LBA_TRY(s->upload(&d.e_pose, e_pose)); LBA_TRY(s->upload(&d.e_obs, e_obs));
-    LBA_TRY(s->upload(&d.e_w, e_w)); LBA_TRY(s->upload(&d.e_stereo, e_st));
+    LBA_TRY(s->upload_raw(&d.e_point, p->edge_point, (size_t)d.nE)); LBA_TRY(s->upload_raw(&d.e_pose, p->edge_pose, (size_t)d.nE));
+    LBA_TRY(s->upload_raw(&d.e_obs, p->edge_obs, 3 * (size_t)d.nE));
+    LBA_TRY(s->upload_raw(&d.e_w, p->edge_inv_sigma2, (size_t)d.nE)); LBA_TRY(s->upload_raw(&d.e_stereo, p->edge_stereo, (size_t)d.nE));
     LBA_TRY(s->upload(&d.l_off, l_off)); LBA_TRY(s->upload(&d.l_edge, l_edge)); LBA_TRY(s->upload(&d.p_off, p_off)); LBA_TRY(s->upload(&d.p_edge, p_edge));
     LBA_TRY(s->upload(&d.b_i, b_i)); LBA_TRY(s->upload(&d.b_j, b_j)); LBA_TRY(s->upload(&d.b_off, b_off)); LBA_TRY(s->upload(&d.b_pair, pairs));
+    LBA_TRY(s->dalloc(&s->poses[0], 7 * (size_t)p->n_poses)); LBA_TRY(s->dalloc(&s->pts[0], 3 * (size_t)d.nL));
+    s->upload_bytes = s->bytes_wanted;      // everything the host writes lies in front of this offset
     LBA_TRY(s->dalloc(&d.Hll, 9 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.bl, 3 * (size_t)d.nL));
     LBA_TRY(s->dalloc(&d.Hpp, 36 * (size_t)d.nP)); LBA_TRY(s->dalloc(&d.bp, 6 * (size_t)d.nP));
     LBA_TRY(s->dalloc(&d.W, 18 * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.Z, 18 * (size_t)d.nE));
@@ -1033,7 +1090,7 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     LBA_TRY(s->dalloc(&d.err, 3 * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.rho0, (size_t)d.nE));
     LBA_TRY(s->dalloc(&d.x, (size_t)d.n + 3 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.part, (size_t)d.nL + d.nP));
     LBA_TRY(s->dalloc(&d.scal, 16));
-    for (int k = 0; k < 2; k++) { LBA_TRY(s->dalloc(&s->poses[k], 7 * (size_t)p->n_poses)); LBA_TRY(s->dalloc(&s->pts[k], 3 * (size_t)d.nL)); }
+    LBA_TRY(s->dalloc(&s->poses[1], 7 * (size_t)p->n_poses)); LBA_TRY(s->dalloc(&s->pts[1], 3 * (size_t)d.nL));
     s->reduce_len = (int64_t)d.n * d.n + 3 * (int64_t)d.n;
     LBA_TRY(s->dalloc(&s->reduce, (size_t)s->reduce_len));
     s->nblk = (d.n + lba::NB - 1) / lba::NB;
@@ -1047,21 +1104,26 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     }
     LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
-    if (s->owns_hscal && hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
+    if (s->owns_hscal && hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostMalloc failed"); }
+    if (hipHostGetDevicePointer((void**)&s->d_hmap, s->h_scal, 0) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "hipHostGetDevicePointer failed"); }
+    s->seq = *(const unsigned long long*)(s->h_scal + 8);      // a solver handle reuses the buffer across shards: continue its numbering
+    if (s->owns_hscal) { std::memset(s->h_scal, 0, 16 * sizeof(double)); s->seq = 0; }
     if (s->owns_stream && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { lba_shard_destroy(s); return fail(ORBX_ERR_HIP, "stream create failed"); }
 #undef LBA_TRY
-    LBA_HIP(hipMemcpy(s->poses[0], poses.data(), poses.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (d.nL > 0) LBA_HIP(hipMemcpy(s->pts[0], p->points, 3 * (size_t)d.nL * sizeof(double), hipMemcpyHostToDevice));
-    LBA_HIP(hipMemset(d.err, 0, 3 * (size_t)std::max(d.nE, 1) * sizeof(double)));
-    LBA_HIP(hipMemset(d.scal, 0, 16 * sizeof(double)));
+    if ((r = s->put(s->poses[0], poses.data(), poses.size() * sizeof(double))) || (d.nL > 0 && (r = s->put(s->pts[0], p->points, 3 * (size_t)d.nL * sizeof(double)))) ||
+        (r = s->flush_stage())) { lba_shard_destroy(s); return r; }
+    LBA_HIP(hipMemsetAsync(d.err, 0, 3 * (size_t)std::max(d.nE, 1) * sizeof(double), s->stream));
+    LBA_HIP(hipMemsetAsync(d.scal, 0, 16 * sizeof(double), s->stream));
     d.cam.fx = p->fx; d.cam.fy = p->fy; d.cam.cx = p->cx; d.cam.cy = p->cy; d.cam.bf = p->bf;
     d.cam.huber_mono = p->huber_mono; d.cam.huber_stereo = p->huber_stereo;
     d.cam.dsqr_mono = p->huber_mono * p->huber_mono; d.cam.dsqr_stereo = p->huber_stereo * p->huber_stereo;    // RobustKernelHuber::setDelta
     hipLaunchKernelGGL(lba::k_normalize_poses, dim3((p->n_poses + 63) / 64), dim3(64), 0, s->stream, s->poses[0], p->n_poses);
-    LBA_HIP(hipStreamSynchronize(s->stream));
-    if ((r = s->dalloc(&s->poses0, 7 * (size_t)p->n_poses)) || (r = s->dalloc(&s->pts0, 3 * (size_t)d.nL))) { lba_shard_destroy(s); return r; }
-    LBA_HIP(hipMemcpy(s->poses0, s->poses[0], 7 * (size_t)p->n_poses * sizeof(double), hipMemcpyDeviceToDevice));
-    if (d.nL > 0) LBA_HIP(hipMemcpy(s->pts0, s->pts[0], 3 * (size_t)d.nL * sizeof(double), hipMemcpyDeviceToDevice));
+    if (!owner) {       // a standalone shard can be reset to its initial estimates (lba_shard_reset); lba_solve never does that
+        if ((r = s->dalloc(&s->poses0, 7 * (size_t)p->n_poses)) || (r = s->dalloc(&s->pts0, 3 * (size_t)d.nL))) { lba_shard_destroy(s); return r; }
+        LBA_HIP(hipMemcpyAsync(s->poses0, s->poses[0], 7 * (size_t)p->n_poses * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        if (d.nL > 0) LBA_HIP(hipMemcpyAsync(s->pts0, s->pts[0], 3 * (size_t)d.nL * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        LBA_HIP(hipStreamSynchronize(s->stream));
+    }
     *out = s;
     return ORBX_OK;
 }
@@ -1075,6 +1137,7 @@ int lba_shard_reset(lba_shard* s)
 {
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
     LBA_HIP(hipSetDevice(s->device));
+    if (!s->poses0) return fail(ORBX_ERR_ARG, "this shard keeps no copy of its initial estimates");
     s->cur = 0;
     s->err_current = false;
     LBA_HIP(hipMemcpyAsync(s->poses[0], s->poses0, 7 * (size_t)s->d.nPoses * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
@@ -1116,8 +1179,19 @@ int lba_shard_set_reduce_buffer(lba_shard* s, double* device_buffer)
 
 static int read_scalars(lba_shard* s)
 {
-    LBA_HIP(hipMemcpyAsync(s->h_scal, s->d.scal, 16 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    LBA_HIP(hipStreamSynchronize(s->stream));
+    // k_reduce wrote the scalars into the host-mapped buffer and then published its sequence number: poll for it (a trial is
+    // a few hundred microseconds of kernels); after 20 ms fall back to a stream synchronisation, which also surfaces faults
+    const volatile unsigned long long* flag = (const volatile unsigned long long*)(s->h_scal + 8);
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (*flag != s->seq) {
+        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            LBA_HIP(hipStreamSynchronize(s->stream));
+            if (*flag != s->seq) return fail(ORBX_ERR_INTERNAL, "reduction results did not arrive");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return ORBX_OK;
 }
 
@@ -1138,7 +1212,7 @@ int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses
     if (d.nL > 0) hipLaunchKernelGGL(lba::k_lin_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, P, X);
     if (d.nP > 0) hipLaunchKernelGGL(lba::k_lin_poses, dim3(d.nP), dim3(256), 0, s->stream, d, P, X);
     if (!reuse) {
-        hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0);
+        hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0, s->d_hmap, ++s->seq);
         LBA_HIP(hipGetLastError());
         int r = read_scalars(s);
         if (r) return r;
@@ -1213,7 +1287,7 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
     }
     hipLaunchKernelGGL(lba::k_backsub_update, dim3((d.nL + d.nPoses + 63) / 64), dim3(64), 0, s->stream, d, lambda, s->bpf(), P, X, Pn, Xn);
     if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, (const double*)Pn, (const double*)Xn);
-    hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 1);
+    hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 1, s->d_hmap, ++s->seq);
     LBA_HIP(hipGetLastError());
     int r = read_scalars(s);
     if (r) return r;
@@ -1268,10 +1342,11 @@ int lba_create(int device, lba_solver** out)
     LBA_HIP(hipSetDevice(device));
     lba_solver* s = new lba_solver();
     s->device = device;
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double)) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || hipHostMalloc((void**)&s->h_scal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         delete s;
         return fail(ORBX_ERR_HIP, "stream / pinned buffer creation failed");
     }
+    std::memset(s->h_scal, 0, 16 * sizeof(double));
     *out = s;
     return ORBX_OK;
 }
@@ -1282,6 +1357,7 @@ void lba_destroy(lba_solver* s)
     (void)hipSetDevice(s->device);
     if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
     if (s->arena) (void)hipFree(s->arena);
+    if (s->stage) (void)hipHostFree(s->stage);
     if (s->h_scal) (void)hipHostFree(s->h_scal);
     delete s;
 }
@@ -1292,11 +1368,14 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
 {
     if (!sv) return fail(ORBX_ERR_ARG, "NULL solver");
     lba_shard* s = nullptr;
+    static const bool timing = std::getenv("ORBX_LBA_TIMING") != nullptr;      // phase times of the call on stderr (tools/lba_prof.py)
+    const auto t_start = std::chrono::steady_clock::now();
     int r = shard_create_impl(sv->device, problem, &s, sv);
     if (r) return r;
+    const auto t_created = std::chrono::steady_clock::now();
     s->sync_after_reduce = false;
     s->lambda_in_reduce = true;
-    const size_t wanted = s->bytes_wanted;
+    const size_t wanted = s->bytes_wanted, wanted_stage = s->upload_bytes;
     LbaStats st;
     std::memset(&st, 0, sizeof(st));
     double lambda = -1, ni = 2;
@@ -1351,13 +1430,26 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
         if (nBad >= 3) { st.stop_reason = 2; break; }
     }
     st.lambda = lambda;
+    const auto t_solved = std::chrono::steady_clock::now();
     if (!r) r = lba_shard_download(s, pose_q_out, pose_t_out, points_out, chi2_per_edge, depth_positive);
+    const auto t_down = std::chrono::steady_clock::now();
     lba_shard_destroy(s);
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[lba_solve] structure + upload %.3f ms, %d iterations / %d trials %.3f ms, epilogue + download %.3f ms, destroy %.3f ms\n",
+                     ms(t_start, t_created), st.iterations, st.trials, ms(t_created, t_solved), ms(t_solved, t_down), ms(t_down, std::chrono::steady_clock::now()));
+    }
     if (wanted > sv->arena_cap) {       // grow the arena so that the next window of this size needs no hipMalloc
         if (sv->arena) (void)hipFree(sv->arena);
         sv->arena = nullptr; sv->arena_cap = 0;
         const size_t cap = wanted + wanted / 4 + (1 << 20);
         if (hipMalloc((void**)&sv->arena, cap) == hipSuccess) sv->arena_cap = cap;
+    }
+    if (wanted_stage > sv->stage_cap) {
+        if (sv->stage) (void)hipHostFree(sv->stage);
+        sv->stage = nullptr; sv->stage_cap = 0;
+        const size_t cap = wanted_stage + wanted_stage / 4 + (1 << 16);
+        if (hipHostMalloc((void**)&sv->stage, cap) == hipSuccess) sv->stage_cap = cap;
     }
     if (stats_out) *stats_out = st;
     return r;
