@@ -407,13 +407,22 @@ __global__ void k_add_lambda(double* S, int n, double lambda)
 // k_chol_update applies the trailing update.  The substitutions in k_chol_solve also only need Linv.
 // Factor AND invert one diagonal block held in registers.  Thread (ty, tx) of a 16 x 16 grid owns the elements
 // (ty + 16a, tx + 16b), a, b < 4, of the 64 x 64-padded block L (identity beyond nb) and of X = L^-1.
-// TWO columns per barrier: the owners publish the raw columns j, j+1 of L and rows j, j+1 of X through double-buffered LDS
-// vectors; every thread then forms the 2x2 pivot factor itself and applies the rank-2 update
-// L -= u0 v0^T + u1 v1^T,  X -= u0 x0^T + u1 x1^T.  Returns false when the block is not positive definite.
-struct CholVec { double col0[2][64], col1[2][64], row0[2][64], row1[2][64]; };
-__device__ __forceinline__ bool chol_tile(double (&Lr)[4][4], int nb, double* __restrict__ Li, CholVec& sv)
+// (History: one column per barrier 33.7 us per 60-column block, two columns 27.5 us, four columns 19.1 us.)
+// FOUR columns per barrier.  The owners publish the raw columns j0..j0+3 of L and rows j0..j0+3 of X; every thread factors the
+// 4 x 4 pivot block P = Lp Lp^T itself and forms M = Lp^-1 (replicated: no broadcast), then
+//   U = A[:, j0..j0+3] M^T  (its rows / its columns),   Xn = M X[j0..j0+3][:],
+//   rows below the pivot block:  L -= U U^T,  X -= U Xn;   rows of the pivot block: X <- Xn.
+// L itself is not an output (only X = L^-1 is), so finished columns are never written back, and garbage above the diagonal of
+// the diagonal 16 x 16 tiles is never read (columns are consumed from their diagonal element downwards).
+struct CholVec4 { double col[2][4][64], row[2][4][64]; };
+__device__ __forceinline__ double rsqrt_newton(double d)
 {
-    double (&s_col0)[2][64] = sv.col0; double (&s_col1)[2][64] = sv.col1; double (&s_row0)[2][64] = sv.row0; double (&s_row1)[2][64] = sv.row1;
+    double inv = __builtin_amdgcn_rsq(d);
+    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+    return inv * fma(-0.5 * d * inv, inv, 1.5);
+}
+__device__ __forceinline__ bool chol_tile4(double (&Lr)[4][4], int nb, double* __restrict__ Li, CholVec4& sv)
+{
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     double Xr[4][4];
 #pragma unroll
@@ -421,101 +430,101 @@ __device__ __forceinline__ bool chol_tile(double (&Lr)[4][4], int nb, double* __
 #pragma unroll
         for (int b = 0; b < 4; b++) Xr[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
     bool failed = false;
-    const int nb2 = (nb + 1) & ~1;          // an odd tail column pairs with the identity padding
 #pragma unroll
     for (int ja = 0; ja < 4; ja++) {
-        for (int jy = 0; jy < 16; jy += 2) {
-            const int j0 = 16 * ja + jy, j1 = j0 + 1;
-            if (j0 >= nb2 || failed) break;
-            const int p = (jy >> 1) & 1;
-            if (tx == jy) {
+        for (int jy = 0; jy < 16; jy += 4) {
+            const int j0 = 16 * ja + jy;
+            if (j0 >= nb || failed) break;                  // a partial last group pairs with the identity padding
+            const int p = (jy >> 2) & 1;
+            const int ko = tx - jy, kr = ty - jy;           // 0..3: this thread owns a pivot column / a pivot row
+            if (ko >= 0 && ko < 4) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) s_col0[p][ty + 16 * a] = Lr[a][ja];
+                for (int a = 0; a < 4; a++) sv.col[p][ko][ty + 16 * a] = Lr[a][ja];
             }
-            if (tx == jy + 1) {
+            if (kr >= 0 && kr < 4) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) s_col1[p][ty + 16 * a] = Lr[a][ja];
-            }
-            if (ty == jy) {
-#pragma unroll
-                for (int b = 0; b < 4; b++) s_row0[p][tx + 16 * b] = Xr[ja][b];
-            }
-            if (ty == jy + 1) {
-#pragma unroll
-                for (int b = 0; b < 4; b++) s_row1[p][tx + 16 * b] = Xr[ja][b];
+                for (int b = 0; b < 4; b++) sv.row[p][kr][tx + 16 * b] = Xr[ja][b];
             }
             __syncthreads();
-            const double d0 = s_col0[p][j0], e10 = s_col0[p][j1], d1raw = s_col1[p][j1];
-            if (!(d0 > 0.0) || !isfinite(d0)) { failed = true; break; }        // uniform: same values in every thread
-            // 1/sqrt(d) from the hardware estimate + two Newton steps, sqrt(d) = d * (1/sqrt(d)) + one Heron correction
-            double inv0 = __builtin_amdgcn_rsq(d0);
-            inv0 = inv0 * fma(-0.5 * d0 * inv0, inv0, 1.5);
-            inv0 = inv0 * fma(-0.5 * d0 * inv0, inv0, 1.5);
-            double l00 = d0 * inv0;
-            l00 = fma(fma(-l00, l00, d0), 0.5 * inv0, l00);
-            const double l10 = e10 * inv0;
-            const double d1 = fma(-l10, l10, d1raw);
+            // pivot block (lower triangle): P[k][m] = column m, row j0 + k
+            const double P00 = sv.col[p][0][j0], P10 = sv.col[p][0][j0 + 1], P20 = sv.col[p][0][j0 + 2], P30 = sv.col[p][0][j0 + 3];
+            const double P11 = sv.col[p][1][j0 + 1], P21 = sv.col[p][1][j0 + 2], P31 = sv.col[p][1][j0 + 3];
+            const double P22 = sv.col[p][2][j0 + 2], P32 = sv.col[p][2][j0 + 3], P33 = sv.col[p][3][j0 + 3];
+            if (!(P00 > 0.0) || !isfinite(P00)) { failed = true; break; }          // uniform: same values in every thread
+            const double i0 = rsqrt_newton(P00);
+            const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
+            const double d1 = fma(-l10, l10, P11);
             if (!(d1 > 0.0) || !isfinite(d1)) { failed = true; break; }
-            double inv1 = __builtin_amdgcn_rsq(d1);
-            inv1 = inv1 * fma(-0.5 * d1 * inv1, inv1, 1.5);
-            inv1 = inv1 * fma(-0.5 * d1 * inv1, inv1, 1.5);
-            double l11 = d1 * inv1;
-            l11 = fma(fma(-l11, l11, d1), 0.5 * inv1, l11);
+            const double i1 = rsqrt_newton(d1);
+            const double l21 = fma(-l20, l10, P21) * i1, l31 = fma(-l30, l10, P31) * i1;
+            const double d2 = fma(-l21, l21, fma(-l20, l20, P22));
+            if (!(d2 > 0.0) || !isfinite(d2)) { failed = true; break; }
+            const double i2 = rsqrt_newton(d2);
+            const double l32 = fma(-l31, l21, fma(-l30, l20, P32)) * i2;
+            const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, P33)));
+            if (!(d3 > 0.0) || !isfinite(d3)) { failed = true; break; }
+            const double i3 = rsqrt_newton(d3);
+            // M = Lp^-1 (lower triangular)
+            const double M00 = i0, M11 = i1, M22 = i2, M33 = i3;
+            const double M10 = -(l10 * M00) * i1;
+            const double M20 = -fma(l21, M10, l20 * M00) * i2, M21 = -(l21 * M11) * i2;
+            const double M30 = -fma(l32, M20, fma(l31, M10, l30 * M00)) * i3, M31 = -fma(l32, M21, l31 * M11) * i3, M32 = -(l32 * M22) * i3;
             // ja is a compile-time constant inside the unrolled outer loop, so whole register tiles drop out
-            double u0[4], u1[4], v0[4], v1[4], x0[4], x1[4];
+            double u[4][4], v[4][4], xn[4][4];              // [k][a], [k][b], [k][b]
 #pragma unroll
             for (int a = 0; a < 4; a++) {
-                u0[a] = 0.0; u1[a] = 0.0;
-                if (a >= ja) {
-                    u0[a] = s_col0[p][ty + 16 * a] * inv0;
-                    u1[a] = fma(-u0[a], l10, s_col1[p][ty + 16 * a]) * inv1;
-                }
+                if (a < ja) continue;
+                const int r = ty + 16 * a;
+                const double c0 = sv.col[p][0][r], c1 = sv.col[p][1][r], c2 = sv.col[p][2][r], c3 = sv.col[p][3][r];
+                const bool below = r > j0 + 3;              // rows of the pivot block and above take no update
+                u[0][a] = below ? M00 * c0 : 0.0;
+                u[1][a] = below ? fma(M11, c1, M10 * c0) : 0.0;
+                u[2][a] = below ? fma(M22, c2, fma(M21, c1, M20 * c0)) : 0.0;
+                u[3][a] = below ? fma(M33, c3, fma(M32, c2, fma(M31, c1, M30 * c0))) : 0.0;
             }
 #pragma unroll
             for (int b = 0; b < 4; b++) {
-                v0[b] = 0.0; v1[b] = 0.0; x0[b] = 0.0; x1[b] = 0.0;
+                const int c = tx + 16 * b;
                 if (b >= ja) {
-                    v0[b] = s_col0[p][tx + 16 * b] * inv0;
-                    v1[b] = fma(-v0[b], l10, s_col1[p][tx + 16 * b]) * inv1;
+                    const double c0 = sv.col[p][0][c], c1 = sv.col[p][1][c], c2 = sv.col[p][2][c], c3 = sv.col[p][3][c];
+                    v[0][b] = M00 * c0;
+                    v[1][b] = fma(M11, c1, M10 * c0);
+                    v[2][b] = fma(M22, c2, fma(M21, c1, M20 * c0));
+                    v[3][b] = fma(M33, c3, fma(M32, c2, fma(M31, c1, M30 * c0)));
                 }
                 if (b <= ja) {
-                    x0[b] = s_row0[p][tx + 16 * b] * inv0;
-                    x1[b] = fma(-l10, x0[b], s_row1[p][tx + 16 * b]) * inv1;
+                    const double x0 = sv.row[p][0][c], x1 = sv.row[p][1][c], x2 = sv.row[p][2][c], x3 = sv.row[p][3][c];
+                    xn[0][b] = M00 * x0;
+                    xn[1][b] = fma(M11, x1, M10 * x0);
+                    xn[2][b] = fma(M22, x2, fma(M21, x1, M20 * x0));
+                    xn[3][b] = fma(M33, x3, fma(M32, x2, fma(M31, x1, M30 * x0)));
                 }
             }
 #pragma unroll
             for (int a = 0; a < 4; a++) {
                 if (a < ja) continue;
-                const int r = ty + 16 * a;
-                const bool ra = r > j1;             // rows below both pivots take the rank-2 update
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const int c = tx + 16 * b;
                     if (b > ja) {
-                        if (b <= a && ra && c <= r) Lr[a][b] -= fma(u1[a], v1[b], u0[a] * v0[b]);      // c > j1 holds for every b > ja
+                        if (b <= a) Lr[a][b] -= fma(u[3][a], v[3][b], fma(u[2][a], v[2][b], fma(u[1][a], v[1][b], u[0][a] * v[0][b])));
                     } else if (b < ja) {
-                        if (ra) Xr[a][b] -= fma(u1[a], x1[b], u0[a] * x0[b]);                          // c <= j0 holds for every b < ja
-                    } else if (ra) {
-                        if (c > j1) { if (c <= r) Lr[a][b] -= fma(u1[a], v1[b], u0[a] * v0[b]); }
-                        else Xr[a][b] -= fma(u1[a], x1[b], u0[a] * x0[b]);                             // x0[j1] = 0: column j1 only sees u1 x1
+                        Xr[a][b] -= fma(u[3][a], xn[3][b], fma(u[2][a], xn[2][b], fma(u[1][a], xn[1][b], u[0][a] * xn[0][b])));
+                    } else {
+                        // the 16-column block of the pivot: columns right of the pivot group belong to L, the others to X
+                        const double dl = fma(u[3][a], v[3][b], fma(u[2][a], v[2][b], fma(u[1][a], v[1][b], u[0][a] * v[0][b])));
+                        const double dx = fma(u[3][a], xn[3][b], fma(u[2][a], xn[2][b], fma(u[1][a], xn[1][b], u[0][a] * xn[0][b])));
+                        if (c > j0 + 3) Lr[a][b] -= dl; else Xr[a][b] -= dx;
                     }
                 }
             }
-            if (tx == jy) {
+            if (kr >= 0 && kr < 4) {                        // the pivot rows of X are final: X[j0 + k][:] = Xn[k][:]
 #pragma unroll
-                for (int a = 0; a < 4; a++) { const int r = ty + 16 * a; if (r > j0) Lr[a][ja] = u0[a]; else if (r == j0) Lr[a][ja] = l00; }
-            }
-            if (tx == jy + 1) {
-#pragma unroll
-                for (int a = 0; a < 4; a++) { const int r = ty + 16 * a; if (r > j1) Lr[a][ja] = u1[a]; else if (r == j1) Lr[a][ja] = l11; }
-            }
-            if (ty == jy) {
-#pragma unroll
-                for (int b = 0; b < 4; b++) { if (tx + 16 * b <= j0) Xr[ja][b] = x0[b]; }
-            }
-            if (ty == jy + 1) {
-#pragma unroll
-                for (int b = 0; b < 4; b++) { if (tx + 16 * b <= j1) Xr[ja][b] = x1[b]; }
+                for (int b = 0; b < 4; b++) {
+                    if (b > ja) continue;
+                    const double val = kr == 0 ? xn[0][b] : (kr == 1 ? xn[1][b] : (kr == 2 ? xn[2][b] : xn[3][b]));
+                    Xr[ja][b] = val;
+                }
             }
         }
     }
@@ -530,10 +539,10 @@ __device__ __forceinline__ bool chol_tile(double (&Lr)[4][4], int nb, double* __
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
                                                    double* __restrict__ Linv, double* __restrict__ scal)
 {
-    __shared__ CholVec sv;
+    __shared__ CholVec4 sv;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     double Lr[4][4];
 #pragma unroll
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S,
             const int r = ty + 16 * a, c = tx + 16 * b;
             Lr[a][b] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
         }
-    if (!chol_tile(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+    if (!chol_tile4(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
 }
 
 // One launch per block column K (instead of panel + update + the next diagonal factorisation): the workgroup of trailing
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const double* __restrict__ S,
 // on to factor and invert it, while the other tiles are still being updated.  The tiles of block column K+1 also store their
 // X_i (= L_iK) into a second (n+1) x n buffer Lp, which the substitution kernel then reads.  The right-hand side (row n of the (n+1) x n buffer) rides along as a 61st row of the last block row.
 constexpr int kFusedMaxBlocks = 8;       // up to 480 reduced unknowns (80 key frames); larger systems keep panel / update launches
-constexpr int kStepLds = (NB * (NB + 1) + 2 * 64 * (NB + 1)) * 8 + (int)sizeof(CholVec);
+constexpr int kStepLds = (NB * (NB + 1) + 2 * 64 * (NB + 1)) * 8 + (int)sizeof(CholVec4);
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_step(double* __restrict__ S, double* __restrict__ Lp, int n, int K, int nblk,
                                                    double* __restrict__ Linv, double* __restrict__ scal)
 {
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     double* sI = sm_step;
     double* sXi = sI + NB * P;
     double* sXj = sXi + 64 * P;
-    CholVec& sv = *(CholVec*)(sXj + 64 * P);
+    CholVec4& sv = *(CholVec4*)(sXj + 64 * P);
     if (scal[5] != 0.0) return;         // an earlier diagonal block was not positive definite
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     int li = 0, t = blockIdx.x;
@@ -668,7 +677,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (factor_here && (r >= ncj || c >= ncj)) Lr[a][b] = (r == c) ? 1.0 : 0.0;
         }
     if (factor_here) {
-        if (!chol_tile(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+        if (!chol_tile4(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
     }
 }
 
