@@ -414,6 +414,7 @@ __global__ void k_add_lambda(double* S, int n, double lambda)
 //   rows below the pivot block:  L -= U U^T,  X -= U Xn;   rows of the pivot block: X <- Xn.
 // L itself is not an output (only X = L^-1 is), so finished columns are never written back, and garbage above the diagonal of
 // the diagonal 16 x 16 tiles is never read (columns are consumed from their diagonal element downwards).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 struct CholVec4 { double col[2][4][64], row[2][4][64]; };
 __device__ __forceinline__ double rsqrt_newton(double d)
 {
@@ -560,6 +561,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // cheaper than a launch), applies T_ij -= X_i X_j^T to its register tile, and the workgroup of tile (K+1, K+1) goes straight
 // on to factor and invert it, while the other tiles are still being updated.  The tiles of block column K+1 also store their
 // X_i (= L_iK) into a second (n+1) x n buffer Lp, which the substitution kernel then reads.  The right-hand side (row n of the (n+1) x n buffer) rides along as a 61st row of the last block row.
+#ifdef LBA_STEP_TIMING       // phase times (wall clock ticks, 100 MHz) of the factoring workgroup of k_chol_step, summed (tools/lba_step_timing.py)
+__device__ unsigned long long d_step_prof[8];
+#define LBA_STICK(k) if (bi == K + 1 && bj == K + 1 && threadIdx.x == 0) { const unsigned long long t_now = wall_clock64(); d_step_prof[k] += t_now - t_prev; t_prev = t_now; }
+#else
+#define LBA_STICK(k)
+#endif
 constexpr int kFusedMaxBlocks = 8;       // up to 480 reduced unknowns (80 key frames); larger systems keep panel / update launches
 constexpr int kStepLds = (NB * (NB + 1) + 2 * 64 * (NB + 1)) * 8 + (int)sizeof(CholVec4);
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_step(double* __restrict__ S, double* __restrict__ Lp, int n, int K, int nblk,
@@ -581,6 +588,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int r0 = bi * NB, nri = min(NB, n - r0) + (bi == nblk - 1 ? 1 : 0);       // + the right-hand-side row
     const int c0 = bj * NB, ncj = min(NB, n - c0);
     const double* Lk = Linv + (size_t)K * NB * NB;
+#ifdef LBA_STEP_TIMING
+    unsigned long long t_prev = wall_clock64();
+#endif
     {
         // staging: all loads of a thread are issued before the first LDS store (16-byte loads; n = 6 * poses is even and
         // every row segment starts at an even column, so the double2 accesses are aligned)
@@ -605,48 +615,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
     }
     __syncthreads();
-    // X = A Linv^T, X[r][c] = sum_{q <= c} A[r][q] Linv[c][q]: a 4 x 4 block per thread (16 row groups x 15 column groups)
-    double xi[4][4], xj[4][4];
-    const int rb = tid / 15, cg = tid - rb * 15;
-    if (tid < 240) {
+    LBA_STICK(0)
+    // X = A Linv^T, X[r][c] = sum_{q <= c} A[r][q] Linv[c][q], on the f64 matrix pipe (v_mfma_f64_16x16x4: lane l feeds
+    // A[l & 15][k = l >> 4] and B[k = l >> 4][l & 15], 1/8 of the LDS bytes of a register-blocked VALU product).  Wave w owns
+    // rows 16w .. 16w+15 (it reads and overwrites only those, so the product is done in place); column block C needs the
+    // k-steps up to its last column only (Linv is lower triangular).
+    {
+        const int wv = tid >> 6, ln = tid & 63, lr = ln & 15, lk = ln >> 4;
+        mfma_d4 xa[4], xb[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int C = 0; C < 4; C++) { xa[C] = mfma_d4{0.0, 0.0, 0.0, 0.0}; xb[C] = xa[C]; }
+        const double* pa = sXi + (16 * wv + lr) * P + lk;
+        const double* pb = sXj + (16 * wv + lr) * P + lk;
 #pragma unroll
-            for (int c = 0; c < 4; c++) { xi[r][c] = 0.0; xj[r][c] = 0.0; }
-        const double* ai = sXi + (4 * rb) * P;
-        const double* aj = sXj + (4 * rb) * P;
-        const double* l = sI + (4 * cg) * P;
-        const int qmax = 4 * cg + 4;
-        for (int q = 0; q < qmax; q++) {
-            const double l0 = l[q], l1 = l[P + q], l2 = l[2 * P + q], l3 = l[3 * P + q];
+        for (int ks = 0; ks < NB / 4; ks++) {
+            const double av = pa[4 * ks];
+            const double bv = diag_tile ? 0.0 : pb[4 * ks];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double a = ai[r * P + q];
-                xi[r][0] = fma(a, l0, xi[r][0]); xi[r][1] = fma(a, l1, xi[r][1]); xi[r][2] = fma(a, l2, xi[r][2]); xi[r][3] = fma(a, l3, xi[r][3]);
-            }
-            if (!diag_tile) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double a = aj[r * P + q];
-                    xj[r][0] = fma(a, l0, xj[r][0]); xj[r][1] = fma(a, l1, xj[r][1]); xj[r][2] = fma(a, l2, xj[r][2]); xj[r][3] = fma(a, l3, xj[r][3]);
-                }
+            for (int C = 0; C < 4; C++) {
+                if (ks >= 4 * C + 4) continue;              // compile-time: above the diagonal of Linv
+                const int c = 16 * C + lr;
+                const double lv = (c < NB) ? sI[c * P + 4 * ks + lk] : 0.0;
+                xa[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lv, xa[C], 0, 0, 0);
+                if (!diag_tile) xb[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, lv, xb[C], 0, 0, 0);
             }
         }
-    }
-    __syncthreads();
-    if (tid < 240) {
+        // results: lane l, component i = row (l >> 4) + 4 i, column l & 15 of the 16 x 16 block
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int C = 0; C < 4; C++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                sXi[(4 * rb + r) * P + 4 * cg + c] = xi[r][c];
-                if (!diag_tile) sXj[(4 * rb + r) * P + 4 * cg + c] = xj[r][c];
+            for (int i = 0; i < 4; i++) {
+                const int c = 16 * C + lr;
+                if (c < NB) {
+                    sXi[(16 * wv + lk + 4 * i) * P + c] = xa[C][i];
+                    if (!diag_tile) sXj[(16 * wv + lk + 4 * i) * P + c] = xb[C][i];
+                }
             }
     }
     __syncthreads();
+    LBA_STICK(1)
     if (bj == K + 1) {      // this tile's X_i is L_iK: keep it -- in Lp, because the other tiles of this block row still read A_iK from S
         for (int i = tid; i < nri * NB; i += 256) { const int r = i / NB, q = i - r * NB; Lp[(size_t)(r0 + r) * n + k0 + q] = sXi[r * P + q]; }
     }
+    LBA_STICK(2)
     const double* sB = diag_tile ? sXi : sXj;
     double Lr[4][4];
 #pragma unroll
@@ -656,15 +667,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const int r = ty + 16 * a, c = tx + 16 * b;
             Lr[a][b] = (r < nri && c < ncj) ? S[(size_t)(r0 + r) * n + c0 + c] : 0.0;
         }
-    for (int q = 0; q < NB; q++) {
-        double va[4], vb[4];
+    LBA_STICK(3)
+    {
+        // T -= X_i X_j^T on the matrix pipe.  Wave w feeds the 16 rows its threads own (local row m = global row
+        // 4w + (m & 3) + 16 (m >> 2)), so component i of column block C of the result IS this thread's element (ty + 16 i, tx + 16 C).
+        const int wv = tid >> 6, ln = tid & 63, lr = ln & 15, lk = ln >> 4;
+        const double* pa = sXi + (4 * wv + (lr & 3) + 16 * (lr >> 2)) * P + lk;
+        const double* pb = sB + lr * P + lk;
+        mfma_d4 acc[4];
 #pragma unroll
-        for (int a = 0; a < 4; a++) { va[a] = sXi[(ty + 16 * a) * P + q]; vb[a] = sB[(tx + 16 * a) * P + q]; }
+        for (int C = 0; C < 4; C++) acc[C] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ks++) {
+            const double av = pa[4 * ks];
+#pragma unroll
+            for (int C = 0; C < 4; C++) acc[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[16 * C * P + 4 * ks], acc[C], 0, 0, 0);
+        }
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) Lr[a][b] = fma(-va[a], vb[b], Lr[a][b]);
+            for (int b = 0; b < 4; b++) Lr[a][b] -= acc[b][a];
     }
+    LBA_STICK(4)
     const bool factor_here = diag_tile && bi == K + 1;
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -676,9 +700,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (live && (!factor_here || r >= ncj)) S[(size_t)(r0 + r) * n + c0 + c] = Lr[a][b];
             if (factor_here && (r >= ncj || c >= ncj)) Lr[a][b] = (r == c) ? 1.0 : 0.0;
         }
+    LBA_STICK(5)
     if (factor_here) {
         if (!chol_tile4(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
     }
+    LBA_STICK(6)
+#ifdef LBA_STEP_TIMING
+    if (bi == K + 1 && bj == K + 1 && threadIdx.x == 0) d_step_prof[7] += 1;
+#endif
 }
 
 constexpr int kPanelRows = 64;
@@ -1136,6 +1165,16 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     *out = s;
     return ORBX_OK;
 }
+
+#ifdef LBA_STEP_TIMING
+extern "C" int lba_debug_step_prof(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lba::d_step_prof), sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lba::d_step_prof), z, sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    return ORBX_OK;
+}
+#endif
 
 extern "C" int lba_shard_create(int device, const LbaProblem* p, lba_shard** out) { return shard_create_impl(device, p, out, nullptr); }
 
