@@ -568,6 +568,7 @@ __device__ unsigned long long d_step_prof[8];
 #define LBA_STICK(k)
 #endif
 constexpr int kFusedMaxBlocks = 8;       // up to 480 reduced unknowns (80 key frames); larger systems keep panel / update launches
+static_assert(NB + 16 * 28 >= kFusedMaxBlocks * NB, "k_chol_solve<true> prefetches at most 28 rows per row group");
 constexpr int kStepLds = (NB * (NB + 1) + 2 * 64 * (NB + 1)) * 8 + (int)sizeof(CholVec4);
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_step(double* __restrict__ S, double* __restrict__ Lp, int n, int K, int nblk,
                                                    double* __restrict__ Linv, double* __restrict__ scal)
@@ -778,6 +779,15 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
 
 // x = L^-T y by block back-substitution with the inverted diagonal blocks (y = L^-1 b was produced by the factorisation
 // itself, see k_chol_panel); one 1024-thread workgroup, 16 row groups x 64 columns, coalesced along the columns.
+__device__ __forceinline__ double row16_sum(double v)          // sum over the 16 lanes of a DPP row (every lane gets it)
+{
+    v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
+    return v;
+}
+// PRE (the fused path, n <= 480): the L_JK rows of block K-1 are fetched into registers while block K is being processed, so the
+// serial sweep never waits for global memory.
+constexpr int kSolvePre = 28;       // rows below the first block of a 480-unknown system / 16 row groups, rounded up
+template <bool PRE>
 __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ S, int n, const double* __restrict__ Linv,
                                                      const double* __restrict__ yin, const double* __restrict__ yin_last,
                                                      double* __restrict__ x, const double* __restrict__ scal, int last_forward)
@@ -796,46 +806,65 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
     const int g64 = tid >> 6, r64 = tid & 63;       // 16 groups x 64 rows
     // backward sweep: x_K = Linv_KK^T (y_K - sum_{J>K} L_JK^T x_J); the inverted diagonal block is staged in LDS (its loads
     // are in flight together with those of the L_JK rows)
+    double pre[PRE ? kSolvePre : 1];
+    double li[4];                       // the inverted diagonal block on its way to LDS (PRE: fetched one block ahead)
     for (int K = nblk - 1; K >= 0; K--) {
         const int k0 = K * NB, nb = min(NB, n - k0);
         {
-            const double* Li = Linv + (size_t)K * NB * NB;
-            double li[4];
+            if (K == nblk - 1 || !PRE) {
+                const double* Li = Linv + (size_t)K * NB * NB;
 #pragma unroll
-            for (int it = 0; it < 4; it++) { const int i = tid + 1024 * it; li[it] = (i < NB * NB) ? Li[i] : 0.0; }
+                for (int it = 0; it < 4; it++) { const int i = tid + 1024 * it; li[it] = (i < NB * NB) ? Li[i] : 0.0; }
+            }
             __syncthreads();            // y complete (first round) / previous block done with sL, t, part
 #pragma unroll
             for (int it = 0; it < 4; it++) { const int i = tid + 1024 * it; if (i < NB * NB) { const int r = i / NB; sL[r * P + i - r * NB] = li[it]; } }
         }
+        const int col = tid >> 4, sub = tid & 15;       // 16 lanes per column for the small matrix-vector products (row-wide reductions)
         if (K == nblk - 1 && last_forward) {    // the fused factorisation stops at the last diagonal block: y = L^-1 b for that block
             __syncthreads();
             double sv = 0;
-            if (tid < nb)
-                for (int q = 0; q <= tid; q++) sv += y[k0 + q] * sL[tid * P + q];
+            if (col < nb)
+                for (int q = sub; q <= col; q += 16) sv += y[k0 + q] * sL[col * P + q];
+            sv = row16_sum(sv);
             __syncthreads();
-            if (tid < nb) y[k0 + tid] = sv;
+            if (col < nb && sub == 0) y[k0 + col] = sv;
             __syncthreads();
         }
         {
             double sv = 0;
-            if (r64 < nb) {
+            if (PRE) {
+#pragma unroll
+                for (int j = 0; j < kSolvePre; j++) { const int q = k0 + nb + g64 + 16 * j; if (q < n) sv += pre[j] * y[q]; }
+            } else if (r64 < nb) {
 #pragma unroll 8
                 for (int q = k0 + nb + g64; q < n; q += 16) sv += S[(size_t)q * n + k0 + r64] * y[q];
             }
             part[g64 * 64 + r64] = sv;
+            if (PRE && K > 0) {         // rows k0 + g64 + 16 j of block column K-1 (a full block): in flight during the rest of this block
+                const double* Li = Linv + (size_t)(K - 1) * NB * NB;
+#pragma unroll
+                for (int it = 0; it < 4; it++) { const int i = tid + 1024 * it; li[it] = (i < NB * NB) ? Li[i] : 0.0; }
+#pragma unroll
+                for (int j = 0; j < kSolvePre; j++) {
+                    const int q = k0 + g64 + 16 * j;
+                    pre[j] = 0.0;
+                    if (q < n && r64 < NB) pre[j] = S[(size_t)q * n + (k0 - NB) + r64];
+                }
+            }
         }
         __syncthreads();
-        if (tid < nb) {
-            double sv = 0;
-            for (int g = 0; g < 16; g++) sv += part[g * 64 + tid];
-            t[tid] = y[k0 + tid] - sv;
+        {
+            const double tot = row16_sum(part[sub * 64 + col]);
+            if (sub == 0 && col < nb) t[col] = y[k0 + col] - tot;
         }
         __syncthreads();
-        if (tid < nb) {
+        {
             double sv = 0;
-#pragma unroll 4
-            for (int q = tid; q < nb; q++) sv += sL[q * P + tid] * t[q];
-            y[k0 + tid] = sv;
+            if (col < nb)
+                for (int q = col + sub; q < nb; q += 16) sv += sL[q * P + col] * t[q];
+            sv = row16_sum(sv);
+            if (sub == 0 && col < nb) y[k0 + col] = sv;
         }
     }
     __syncthreads();
@@ -1138,7 +1167,8 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     {
         const size_t solve_lds = ((size_t)d.n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
         if (solve_lds > 160 * 1024) LBA_TRY(fail(ORBX_ERR_CAPACITY, "%d reduced unknowns exceed the substitution kernel's LDS", d.n));
-        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
+        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
+        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
     }
     LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
@@ -1329,7 +1359,8 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
                 hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, n + 1, k0, nb, (const double*)d.scal);
             }
         }
-        hipLaunchKernelGGL(lba::k_chol_solve, dim3(1), dim3(1024), ((size_t)n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double), s->stream,
+        hipLaunchKernelGGL(fused ? lba::k_chol_solve<true> : lba::k_chol_solve<false>, dim3(1), dim3(1024),
+                           ((size_t)n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double), s->stream,
                            (const double*)(fused ? s->Lp : s->S()), n, (const double*)s->Linv,
                            (const double*)(fused ? s->Lp + (size_t)n * n : s->bs()), (const double*)s->bs(), d.x, (const double*)d.scal, fused ? 1 : 0);
     }
