@@ -261,9 +261,11 @@ def main():
                 iters += s2["iterations"]; trials += s2["trials"]
             dt = time.perf_counter() - t0
             solver = pkg.LbaSolver(device=local_rank)
+            solver.solve(w, 10)                       # the first call sizes the solver's device arena and pinned staging buffer
             t1 = time.perf_counter()
-            r = solver.solve(w, 10)
-            dt_call = time.perf_counter() - t1
+            for _ in range(5):
+                r = solver.solve(w, 10)
+            dt_call = (time.perf_counter() - t1) / 5
             out["lba"] = {"metric": "LocalBA outer iterations/s", "value": iters / dt, "unit": "iters/s", "dtype": "f64",
                           "workload": "50 opt + 10 fixed KF, 2000 MP, %d mono edges, optimize(10)" % len(w["edge_point"]),
                           "iterations_per_solve": stats["iterations"], "trials_per_solve": stats["trials"],
