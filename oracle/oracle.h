@@ -240,6 +240,47 @@ void  map_oracle_normal_and_depth(const float* pos, const float* centers, const 
                                   const float* level_scale, float last_level_scale, int n_points,
                                   float* normal, float* max_dist, float* min_dist);
 
+/* Optimizer::LocalInertialBA (reference src/Optimizer.cc:2383-2958), flattened.  GROUNDWORK: oracle only, no HIP path yet. */
+typedef struct OracleInertialLink {     /* EdgeInertial + EdgeGyroRW + EdgeAccRW between key frames kf1 (earlier) and kf2 */
+    int32_t kf1, kf2;
+    float dR[9], dV[3], dP[3];          /* IMU::Preintegrated: dR, dV, dP */
+    float JRg[9], JVg[9], JVa[9], JPg[9], JPa[9];
+    float dT;
+    float bias0[6];                     /* the bias the pre-integration was linearised at: bax bay baz bwx bwy bwz */
+    double info9[81];                   /* EdgeInertial information (symmetrised, eigenvalue-clamped; x 1e-2 for the link to the fixed key frame) */
+    double info_gyro[9], info_acc[9];   /* C.block<3,3>(9,9)^-1, C.block<3,3>(12,12)^-1 */
+    uint8_t robust;                     /* Huber kernel on the inertial edge (i == N-1 || bRecInit) */
+} OracleInertialLink;
+typedef struct OracleInertialProblem {
+    int32_t n_kf;
+    const double* Rwb;                  /* n_kf x 9, row major */
+    const double* twb;                  /* n_kf x 3 */
+    const double* vel;                  /* n_kf x 3 */
+    const double* bg;                   /* n_kf x 3 */
+    const double* ba;                   /* n_kf x 3 */
+    const uint8_t* pose_fixed;          /* VertexPose::setFixed */
+    const uint8_t* has_imu;             /* velocity / bias vertices exist (pKFi->bImu) */
+    const uint8_t* imu_fixed;
+    double Rcb[9], tcb[3], tbc[3];      /* mImuCalib */
+    double fx, fy, cx, cy, bf;
+    int32_t n_points;
+    const double* points;
+    int32_t n_edges;                    /* EdgeMono / EdgeStereo in addEdge order */
+    const int32_t* edge_kf;
+    const int32_t* edge_point;
+    const double* edge_obs;             /* n_edges x 3 */
+    const double* edge_inv_sigma2;
+    const uint8_t* edge_stereo;
+    int32_t n_links;
+    const OracleInertialLink* links;
+    double huber_mono, huber_stereo, huber_inertial;     /* (float)sqrt(5.991), (float)sqrt(7.815), sqrt(16.92) */
+    double lambda_init;                 /* setUserLambdaInit: 1e0, or 1e-2 when bLarge */
+    int32_t max_iters;                  /* opt_it: 10, or 4 when bLarge */
+} OracleInertialProblem;
+int    inertial_oracle_solve(const OracleInertialProblem* P, double* Rwb_out, double* twb_out, double* vel_out, double* bg_out,
+                             double* ba_out, double* points_out, double* chi2_per_edge, uint8_t* depth_positive, OracleLbaStats* stats);
+double inertial_oracle_jacobian_check(const OracleInertialProblem* P, int link, double h);
+
 #ifdef __cplusplus
 }
 #endif

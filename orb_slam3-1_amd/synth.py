@@ -324,3 +324,80 @@ def make_stereo_pair(seed, w=640, h=480, band=60, dmin=3, dmax=40):
         right[y0:y0 + band, :w - d] = left[y0:y0 + band, d:]
         right[y0:y0 + band, w - d:] = left[y0:y0 + band, w - d:]
     return left, right
+
+
+def _so3_exp(w):
+    th = np.linalg.norm(w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-9:
+        return np.eye(3) + W
+    return np.eye(3) + W * (np.sin(th) / th) + W @ W * ((1 - np.cos(th)) / th ** 2)
+
+
+def make_inertial_window(seed, n_opt=6, n_points=150, obs_per_point=4, dt=0.25, noise_px=0.5, perturb=True, bias_error=0.0):
+    """A LocalInertialBA window (reference src/Optimizer.cc:2383-2958) with consistent synthetic data: key frame 0 is the fixed
+    one in front of the temporal window (pose and IMU states fixed), key frames 1..n_opt are optimised; every consecutive pair
+    is linked by a pre-integrated measurement computed from the ground-truth states (plus noise), so that the ground truth is a
+    minimum of the inertial cost; mono observations of a point cloud.  Returns (problem dict, ground truth dict)."""
+    rs = np.random.RandomState(seed)
+    n = n_opt + 1
+    g = np.array([0.0, 0.0, -9.81])
+    # smooth body trajectory: constant-acceleration segments
+    Rwb = [np.eye(3)]; pwb = [np.zeros(3)]; vel = [np.array([0.6, 0.1, 0.0])]
+    acc_w = rs.normal(0, 0.4, (n, 3)); omg = rs.normal(0, 0.15, (n, 3))
+    for i in range(1, n):
+        Rwb.append(Rwb[-1] @ _so3_exp(omg[i] * dt))
+        pwb.append(pwb[-1] + vel[-1] * dt + 0.5 * acc_w[i] * dt * dt)
+        vel.append(vel[-1] + acc_w[i] * dt)
+    bg_true = rs.normal(0, 0.01, 3); ba_true = rs.normal(0, 0.05, 3)
+    Rcb = _so3_exp(np.array([0.01, -0.02, 0.015])) @ np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0.0]])   # camera looks along the body x axis
+    tcb = np.array([0.02, -0.01, 0.03]); tbc = -Rcb.T @ tcb
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    links = []
+    for i in range(1, n):
+        R1, R2 = Rwb[i - 1], Rwb[i]
+        dR = R1.T @ R2
+        dV = R1.T @ (vel[i] - vel[i - 1] - g * dt)
+        dP = R1.T @ (pwb[i] - pwb[i - 1] - vel[i - 1] * dt - 0.5 * g * dt * dt)
+        sig_r, sig_v, sig_p = 2e-3, 1e-2, 5e-3
+        dR = dR @ _so3_exp(rs.normal(0, sig_r * 0.2, 3)); dV = dV + rs.normal(0, sig_v * 0.2, 3); dP = dP + rs.normal(0, sig_p * 0.2, 3)
+        info9 = np.diag([1 / sig_r ** 2] * 3 + [1 / sig_v ** 2] * 3 + [1 / sig_p ** 2] * 3)
+        last = i == 1                      # the link to the fixed key frame (i == N-1 in the reference's reversed ordering)
+        if last:
+            info9 = info9 * 1e-2
+        links.append(dict(kf1=i - 1, kf2=i, dR=dR.astype(np.float32), dV=dV.astype(np.float32), dP=dP.astype(np.float32),
+                          JRg=(-dt * np.eye(3)).astype(np.float32), JVg=(rs.normal(0, 0.01, (3, 3))).astype(np.float32),
+                          JVa=(-dt * dR).astype(np.float32), JPg=(rs.normal(0, 0.003, (3, 3))).astype(np.float32),
+                          JPa=(-0.5 * dt * dt * dR).astype(np.float32), dT=np.float32(dt),
+                          bias0=np.concatenate([ba_true, bg_true]).astype(np.float32),
+                          info9=info9, info_gyro=np.eye(3) * 1e6 / dt, info_acc=np.eye(3) * 1e4 / dt, robust=np.uint8(last)))
+    # points in front of the cameras
+    centre = np.mean(pwb, axis=0)
+    pts = centre + np.array([6.0, 0, 0]) + rs.uniform(-1, 1, (n_points, 3)) * np.array([2.0, 3.0, 2.0])
+    e_kf, e_pt, e_obs, e_w = [], [], [], []
+    for l in range(n_points):
+        for i in sorted(rs.choice(n, min(obs_per_point, n), replace=False)):
+            Rcw = Rcb @ Rwb[i].T; tcw = Rcb @ (-Rwb[i].T @ pwb[i]) + tcb
+            Xc = Rcw @ pts[l] + tcw
+            if Xc[2] < 0.5:
+                continue
+            octave = rs.randint(0, 4)
+            sig = 1.2 ** octave
+            uv = np.array([fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy]) + rs.normal(0, noise_px * sig, 2)
+            e_kf.append(i); e_pt.append(l); e_obs.append([np.float32(uv[0]), np.float32(uv[1]), -1.0]); e_w.append(np.float32(1.0 / sig ** 2))
+    gt = dict(Rwb=np.array(Rwb), twb=np.array(pwb), vel=np.array(vel), points=pts.copy())
+    Rwb0 = np.array(Rwb); twb0 = np.array(pwb); vel0 = np.array(vel); pts0 = pts.copy()
+    bg0 = np.tile(bg_true, (n, 1)) + bias_error; ba0 = np.tile(ba_true, (n, 1)) + bias_error
+    if perturb:
+        for i in range(1, n):
+            Rwb0[i] = Rwb0[i] @ _so3_exp(rs.normal(0, 0.01, 3)); twb0[i] = twb0[i] + rs.normal(0, 0.02, 3); vel0[i] = vel0[i] + rs.normal(0, 0.03, 3)
+        pts0 = pts0 + rs.normal(0, 0.03, pts0.shape)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)       # the reference loads float members into double vertices
+    pr = dict(n_kf=n, Rwb=f32(Rwb0), twb=f32(twb0), vel=f32(vel0), bg=f32(bg0), ba=f32(ba0),
+              pose_fixed=np.array([1] + [0] * n_opt, np.uint8), has_imu=np.ones(n, np.uint8), imu_fixed=np.array([1] + [0] * n_opt, np.uint8),
+              Rcb=f32(Rcb), tcb=f32(tcb), tbc=f32(tbc), fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)), bf=0.0,
+              points=f32(pts0), edge_kf=np.array(e_kf, np.int32), edge_point=np.array(e_pt, np.int32), edge_obs=np.array(e_obs, np.float64),
+              edge_inv_sigma2=np.array(e_w, np.float64), edge_stereo=np.zeros(len(e_kf), np.uint8), links=links,
+              huber_mono=float(np.float32(np.sqrt(5.991))), huber_stereo=float(np.float32(np.sqrt(7.815))), huber_inertial=float(np.sqrt(16.92)),
+              lambda_init=1.0, max_iters=10)
+    return pr, gt
