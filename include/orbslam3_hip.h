@@ -463,6 +463,58 @@ int  orbv_transform_batch_device(orbv_vocab* v, const uint8_t* d_desc, const int
                                  uint32_t* d_fv_node, int32_t* d_fv_off, uint32_t* d_fv_feat, int32_t* d_n_fv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Visual-inertial local BA -- the numerical core of
+ * Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&, int&, int&, int&, bool bLarge, bool bRecInit)
+ * (include/Optimizer.h, src/Optimizer.cc:2383-2958).  The graph walk (:2383-2500) and the map
+ * write-back (:2862-2957) stay in the host shim, which also reads the pre-integrated terms off IMU::Preintegrated
+ * (IntegrateNewMeasurement stays on the host) and forms the information matrices (G2oTypes.cc:510-518, Optimizer.cc:2651-2668).
+ * Vertices: per key frame a body pose (VertexPose / ImuCamPose, 6), velocity, gyro bias, accelerometer bias (3 each);
+ * landmarks marginalised.  Edges: EdgeMono / EdgeStereo, EdgeInertial, EdgeGyroRW, EdgeAccRW.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct LibaLink {           /* one pre-integrated link kf1 -> kf2: EdgeInertial + EdgeGyroRW + EdgeAccRW */
+    int32_t kf1, kf2;
+    float dR[9], dV[3], dP[3];      /* IMU::Preintegrated dR, dV, dP (row major) */
+    float JRg[9], JVg[9], JVa[9], JPg[9], JPa[9];
+    float dT;
+    float bias0[6];                 /* the bias of the pre-integration: bax bay baz bwx bwy bwz */
+    double info9[81];               /* EdgeInertial information, symmetrised and eigenvalue-clamped (x 1e-2 on the link to the fixed key frame) */
+    double info_gyro[9], info_acc[9];
+    uint8_t robust;                 /* Huber kernel on the inertial edge (i == N-1 || bRecInit, Optimizer.cc:2643-2653) */
+} LibaLink;
+typedef struct LibaProblem {
+    int32_t n_kf;
+    const double* Rwb;              /* [n_kf][9] GetImuRotation() */
+    const double* twb;              /* [n_kf][3] GetImuPosition() */
+    const double* vel;              /* [n_kf][3] */
+    const double* bg;               /* [n_kf][3] */
+    const double* ba;               /* [n_kf][3] */
+    const uint8_t* pose_fixed;      /* VertexPose::setFixed */
+    const uint8_t* has_imu;         /* pKFi->bImu: velocity / bias vertices exist */
+    const uint8_t* imu_fixed;
+    double Rcb[9], tcb[3], tbc[3];  /* mImuCalib.mTcb, mTbc translation */
+    double fx, fy, cx, cy, bf;
+    int32_t n_points;
+    const double* points;
+    int32_t n_edges;                /* in addEdge order */
+    const int32_t* edge_kf;
+    const int32_t* edge_point;
+    const double* edge_obs;         /* [n_edges][3] */
+    const double* edge_inv_sigma2;
+    const uint8_t* edge_stereo;
+    int32_t n_links;                /* <= 64 */
+    const LibaLink* links;
+    double huber_mono, huber_stereo, huber_inertial;    /* (float)sqrt(5.991), (float)sqrt(7.815), sqrt(16.92) */
+    double lambda_init;             /* setUserLambdaInit: 1e0, or 1e-2 when bLarge */
+    int32_t max_iters;              /* opt_it: 10, or 4 when bLarge */
+} LibaProblem;
+typedef struct liba_solver liba_solver;
+int  liba_create(int device, liba_solver** out);
+void liba_destroy(liba_solver* s);
+/* outputs: per key frame Rwb / twb / velocity / biases (any may be NULL), points, per visual edge chi2 and depth sign */
+int  liba_solve(liba_solver* s, const LibaProblem* problem, double* Rwb_out, double* twb_out, double* vel_out, double* bg_out,
+                double* ba_out, double* points_out, double* chi2_per_edge, uint8_t* depth_positive, LbaStats* stats);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Edge-SLAM wire format (the fork's client <-> server packets).  Replaces the two constructors
  * of class SlamPktVI, reference include/Socket/slampkt_vi.h:
  *   :127-167  SlamPktVI(id, timestamp, kps, descriptors, imus)  -> orbe_pack_batch(_device)   (edge client: packets are

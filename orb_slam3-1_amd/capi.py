@@ -872,3 +872,82 @@ class PacketCodec:
                                             C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_n), C.c_void_p(d_frame_id),
                                             C.c_void_p(d_timestamp), C.c_void_p(d_imu or 0), C.c_void_p(d_n_imu), C.c_void_p(d_status),
                                             C.c_void_p(stream or 0)))
+
+
+class _LibaLink(C.Structure):
+    _fields_ = [("kf1", C.c_int32), ("kf2", C.c_int32), ("dR", C.c_float * 9), ("dV", C.c_float * 3), ("dP", C.c_float * 3),
+                ("JRg", C.c_float * 9), ("JVg", C.c_float * 9), ("JVa", C.c_float * 9), ("JPg", C.c_float * 9), ("JPa", C.c_float * 9),
+                ("dT", C.c_float), ("bias0", C.c_float * 6), ("info9", C.c_double * 81), ("info_gyro", C.c_double * 9), ("info_acc", C.c_double * 9),
+                ("robust", C.c_uint8)]
+
+
+class _LibaProblem(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("Rwb", C.c_void_p), ("twb", C.c_void_p), ("vel", C.c_void_p), ("bg", C.c_void_p), ("ba", C.c_void_p),
+                ("pose_fixed", C.c_void_p), ("has_imu", C.c_void_p), ("imu_fixed", C.c_void_p),
+                ("Rcb", C.c_double * 9), ("tcb", C.c_double * 3), ("tbc", C.c_double * 3),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("n_points", C.c_int32), ("points", C.c_void_p), ("n_edges", C.c_int32), ("edge_kf", C.c_void_p), ("edge_point", C.c_void_p),
+                ("edge_obs", C.c_void_p), ("edge_inv_sigma2", C.c_void_p), ("edge_stereo", C.c_void_p),
+                ("n_links", C.c_int32), ("links", C.c_void_p),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("huber_inertial", C.c_double), ("lambda_init", C.c_double), ("max_iters", C.c_int32)]
+
+
+class _LibaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("stop_reason", C.c_int32),
+                ("lambda_", C.c_double), ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("chi2_trace", C.c_double * 16)]
+
+
+def _liba_problem(pr):
+    dt = dict(Rwb=np.float64, twb=np.float64, vel=np.float64, bg=np.float64, ba=np.float64, pose_fixed=np.uint8, has_imu=np.uint8, imu_fixed=np.uint8,
+              points=np.float64, edge_kf=np.int32, edge_point=np.int32, edge_obs=np.float64, edge_inv_sigma2=np.float64, edge_stereo=np.uint8)
+    keep = {k: np.ascontiguousarray(pr[k], t) for k, t in dt.items()}
+    links = (_LibaLink * max(len(pr["links"]), 1))()
+    for L, d in zip(links, pr["links"]):
+        L.kf1, L.kf2, L.dT, L.robust = int(d["kf1"]), int(d["kf2"]), float(d["dT"]), int(d["robust"])
+        for name in ("dR", "dV", "dP", "JRg", "JVg", "JVa", "JPg", "JPa", "bias0"):
+            getattr(L, name)[:] = np.asarray(d[name], np.float32).ravel().tolist()
+        for name in ("info9", "info_gyro", "info_acc"):
+            getattr(L, name)[:] = np.asarray(d[name], np.float64).ravel().tolist()
+    s = _LibaProblem()
+    s.n_kf = int(pr["n_kf"])
+    for k in dt:
+        setattr(s, k, keep[k].ctypes.data)
+    s.Rcb[:] = np.asarray(pr["Rcb"], np.float64).ravel().tolist(); s.tcb[:] = list(map(float, pr["tcb"])); s.tbc[:] = list(map(float, pr["tbc"]))
+    s.fx, s.fy, s.cx, s.cy, s.bf = pr["fx"], pr["fy"], pr["cx"], pr["cy"], pr["bf"]
+    s.n_points = len(keep["points"]); s.n_edges = len(keep["edge_kf"]); s.n_links = len(pr["links"]); s.links = C.addressof(links)
+    s.huber_mono, s.huber_stereo, s.huber_inertial = pr["huber_mono"], pr["huber_stereo"], pr["huber_inertial"]
+    s.lambda_init, s.max_iters = float(pr["lambda_init"]), int(pr["max_iters"])
+    s._keep = (keep, links)
+    return s
+
+
+class InertialSolver:
+    """The numerical core of Optimizer::LocalInertialBA (reference src/Optimizer.cc:2383-2958) on the device."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib.liba_create(device, C.byref(h)))
+        self._h = h
+        lib.liba_destroy.argtypes = [C.c_void_p]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.liba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, pr):
+        s = _liba_problem(pr)
+        n, m, ne = s.n_kf, s.n_points, s.n_edges
+        Rwb = np.zeros((n, 3, 3)); twb = np.zeros((n, 3)); vel = np.zeros((n, 3)); bg = np.zeros((n, 3)); ba = np.zeros((n, 3))
+        pts = np.zeros((max(m, 1), 3)); chi2 = np.zeros(max(ne, 1)); dpos = np.zeros(max(ne, 1), np.uint8)
+        st = _LibaStats()
+        _check(lib.liba_solve(self._h, C.byref(s), _p(Rwb), _p(twb), _p(vel), _p(bg), _p(ba), _p(pts), _p(chi2), _p(dpos), C.byref(st)))
+        stats = dict(iterations=st.iterations, trials=st.trials, stop_reason=st.stop_reason, lambda_=st.lambda_, chi2_initial=st.chi2_initial,
+                     chi2_final=st.chi2_final)
+        return dict(Rwb=Rwb, twb=twb, vel=vel, bg=bg, ba=ba, points=pts[:m], chi2=chi2[:ne], depth_positive=dpos[:ne], stats=stats)

@@ -1535,3 +1535,5 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
 }
 
 }  // extern "C"
+
+#include "inertial_solver.inc"

@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "orbslam3_hip.h")
 def _declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b((?:orbx|orbm|orbv|orbe|lba|pose)_[a-z0-9_]+)\s*\(", src)
+    names = re.findall(r"\b((?:orbx|orbm|orbv|orbe|lba|liba|pose)_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 

@@ -1,0 +1,58 @@
+"""LocalInertialBA on the device (liba_solve; reference src/Optimizer.cc:2383-2958) against the oracle: same Levenberg control
+flow (iterations, trials, stop reason), states within 1e-4 relative of the update, identical depth signs.  PARITY UNPINNED."""
+import numpy as np
+import pytest
+
+from oracle_api import oracle_inertial_solve
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(r0, r1, pr, tag):
+    s0, s1 = r0["stats"], r1["stats"]
+    assert (s1["iterations"], s1["trials"], s1["stop_reason"]) == (s0["iterations"], s0["trials"], s0["stop_reason"]), tag
+    np.testing.assert_allclose(s1["chi2_initial"], s0["chi2_initial"], rtol=1e-9)
+    np.testing.assert_allclose(s1["chi2_final"], s0["chi2_final"], rtol=1e-6)
+    for key in ("twb", "vel", "bg", "ba", "points"):
+        d0, d1 = r0[key] - np.asarray(pr[key]), r1[key] - np.asarray(pr[key])
+        assert np.abs(d0 - d1).max() <= 1e-4 * max(np.abs(d0).max(), 1e-9), (tag, key)
+    assert np.abs(r0["Rwb"] - r1["Rwb"]).max() < 1e-7, tag
+    np.testing.assert_array_equal(r1["depth_positive"], r0["depth_positive"])
+    np.testing.assert_allclose(r1["chi2"], r0["chi2"], rtol=1e-5, atol=1e-9)
+
+
+def test_inertial_ba_matches_oracle(pkg, oracle, synth):
+    s = pkg.InertialSolver()
+    try:
+        for seed, kw in ((0, dict(n_opt=6, n_points=200, obs_per_point=5)), (1, dict(n_opt=3, n_points=40)), (2, dict(n_opt=10, n_points=400, obs_per_point=4)),
+                         (3, dict(n_opt=8, n_points=150, bias_error=0.002)), (4, dict(n_opt=25, n_points=600, obs_per_point=6))):
+            pr, _ = synth.make_inertial_window(seed, **kw)
+            if seed == 3:
+                pr["lambda_init"] = 1e-2; pr["max_iters"] = 4          # bLarge
+            _compare(oracle_inertial_solve(oracle, pr), s.solve(pr), pr, seed)
+    finally:
+        s.close()
+
+
+def test_inertial_ba_converges_and_keeps_the_fixed_key_frame(pkg, synth):
+    pr, gt = synth.make_inertial_window(7, n_opt=6, n_points=200, obs_per_point=5, noise_px=0.3)
+    s = pkg.InertialSolver()
+    r = s.solve(pr)
+    s.close()
+    assert r["stats"]["chi2_final"] < 0.05 * r["stats"]["chi2_initial"]
+    assert np.abs(r["twb"] - gt["twb"]).max() < 0.01
+    assert np.array_equal(r["Rwb"][0], pr["Rwb"][0]) and np.array_equal(r["twb"][0], pr["twb"][0])
+    for R in r["Rwb"]:
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+
+
+def test_inertial_ba_bad_arguments(pkg, synth):
+    pr, _ = synth.make_inertial_window(8, n_opt=3, n_points=30)
+    s = pkg.InertialSolver()
+    bad = dict(pr); bad["edge_kf"] = pr["edge_kf"].copy(); bad["edge_kf"][0] = 99
+    with pytest.raises(pkg.OrbxError):
+        s.solve(bad)
+    bad = dict(pr); bad["lambda_init"] = 0.0
+    with pytest.raises(pkg.OrbxError):
+        s.solve(bad)
+    s.close()
