@@ -461,6 +461,23 @@ def main():
                                  "workload": "%d map points, 2-20 observations each (%d descriptors)" % (Pm, int(moff[-1]))}
             mm.close()
 
+        # ---- visual-inertial local BA leg: Optimizer::LocalInertialBA's numerical core, one window per call ----
+        if not args.no_lba:
+            iw, _ = synth.make_inertial_window(0, n_opt=10, n_points=800, obs_per_point=6, n_covisible_fixed=10)
+            isol = pkg.InertialSolver(device=local_rank)
+            ri = isol.solve(iw)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ri = isol.solve(iw)
+            dti = (time.perf_counter() - t0) / 5
+            out["inertial_ba"] = {"metric": "LocalInertialBA outer iterations/s (one call = structure build + upload + iterations + download)",
+                                  "value": ri["stats"]["iterations"] / dti, "unit": "iters/s", "dtype": "f64", "ms_per_call": 1e3 * dti,
+                                  "iterations_per_solve": ri["stats"]["iterations"], "trials_per_solve": ri["stats"]["trials"],
+                                  "workload": "10 temporal key frames (15 unknowns each) + 1 fixed + 10 covisible fixed, 800 map points, %d mono edges, "
+                                              "10 inertial links, optimize(10), lambda 1" % len(iw["edge_kf"]),
+                                  "chi2_initial": ri["stats"]["chi2_initial"], "chi2_final": ri["stats"]["chi2_final"]}
+            isol.close()
+
         # ---- CPU baseline leg (N=1 only, rank 0) ----
         if not args.no_cpu and world == 1:
             o, cb = cpu_baseline(synth, host_imgs, match_sets)
@@ -520,6 +537,16 @@ def main():
                 dtc = time.perf_counter() - t0
                 out["pose"]["cpu_baseline"] = {"value": 64 / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "64 frames"}
                 out["pose"]["speedup_vs_cpu_1core"] = out["pose"]["value"] / (64 / dtc)
+            if "inertial_ba" in out:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from oracle_api import oracle_inertial_solve
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    rc = oracle_inertial_solve(o, iw)
+                dtc = (time.perf_counter() - t0) / 3
+                out["inertial_ba"]["cpu_baseline"] = {"value": rc["stats"]["iterations"] / dtc, "unit": "iters/s", "cores": 1, "kind": "port",
+                                                      "sample": "3 solves of the same window"}
+                out["inertial_ba"]["speedup_vs_cpu_1core"] = out["inertial_ba"]["value"] / (rc["stats"]["iterations"] / dtc)
 
     # ---- sharded global BA with one RCCL all-reduce per LM trial (N>1) ----
     if world > 1 and not args.no_lba:

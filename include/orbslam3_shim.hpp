@@ -15,6 +15,7 @@
 //   int  ORBmatcher::SearchByProjection(Frame&, const Frame&, float, bool)               :47
 //   static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)            :40
 //   static void Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&, int&, int&, int&)     include/Optimizer.h:58
+//   static void Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&, int&, int&, int&, bool, bool)   include/Optimizer.h (src/Optimizer.cc:2383)
 #pragma once
 
 #include <cstdint>
@@ -659,6 +660,189 @@ inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap,
         pKFi->SetPose(Sophus::SE3f(qd.cast<float>(), Eigen::Vector3d(to[3 * i], to[3 * i + 1], to[3 * i + 2]).cast<float>()));
     }
     for (MapPoint* pMP : lLocalMapPoints) {
+        const int i = mpIndex[pMP];
+        pMP->SetWorldPos(Eigen::Vector3d(Xo[3 * i], Xo[3 * i + 1], Xo[3 * i + 2]).cast<float>());
+        pMP->UpdateNormalAndDepth();
+    }
+    pMap->IncreaseChangeIndex();
+}
+
+// void Optimizer::LocalInertialBA(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&, bool bLarge, bool bRecInit)
+// (src/Optimizer.cc:2383-2958), conventional cameras (pKF->mpCamera2 == nullptr): the graph walk and the write-back follow the
+// reference statement by statement; the g2o part is liba_solve.  Needs "G2oTypes.h" / "ImuTypes.h" of the reference.
+inline void LocalInertialBAHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges,
+                               bool bLarge = false, bool bRecInit = false)
+{
+    (void)pbStopFlag; (void)num_MPs;                                                // the reference sets the stop flag only AFTER optimize() (:2846)
+    if (pKF->mpCamera2) { Optimizer::LocalInertialBA(pKF, pbStopFlag, pMap, num_fixedKF, num_OptKF, num_MPs, num_edges, bLarge, bRecInit); return; }
+    Map* pCurrentMap = pKF->GetMap();
+    const int maxOpt = bLarge ? 25 : 10, opt_it = bLarge ? 4 : 10;
+    const int Nd = std::min((int)pCurrentMap->KeyFramesInMap() - 2, maxOpt);
+    std::vector<KeyFrame*> vpOptimizableKFs;                                        // :2397-2413
+    vpOptimizableKFs.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    for (int i = 1; i < Nd; i++) {
+        if (!vpOptimizableKFs.back()->mPrevKF) break;
+        vpOptimizableKFs.push_back(vpOptimizableKFs.back()->mPrevKF);
+        vpOptimizableKFs.back()->mnBALocalForKF = pKF->mnId;
+    }
+    std::list<MapPoint*> lLocalMapPoints;                                           // :2418-2435
+    for (KeyFrame* pKFi : vpOptimizableKFs)
+        for (MapPoint* pMP : pKFi->GetMapPointMatches())
+            if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pKF->mnId) { lLocalMapPoints.push_back(pMP); pMP->mnBALocalForKF = pKF->mnId; }
+    std::list<KeyFrame*> lFixedKeyFrames;                                           // :2438-2450
+    if (vpOptimizableKFs.back()->mPrevKF) {
+        lFixedKeyFrames.push_back(vpOptimizableKFs.back()->mPrevKF);
+        vpOptimizableKFs.back()->mPrevKF->mnBAFixedForKF = pKF->mnId;
+    } else {
+        vpOptimizableKFs.back()->mnBALocalForKF = 0;
+        vpOptimizableKFs.back()->mnBAFixedForKF = pKF->mnId;
+        lFixedKeyFrames.push_back(vpOptimizableKFs.back());
+        vpOptimizableKFs.pop_back();
+    }
+    // maxCovKF = 0: no optimisable covisible key frames (:2453-2484).  Fixed key frames seeing the local points (:2487-2507)
+    const size_t maxFixKF = 200;
+    for (MapPoint* pMP : lLocalMapPoints) {
+        for (auto& obs : pMP->GetObservations()) {
+            KeyFrame* pKFi = obs.first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                pKFi->mnBAFixedForKF = pKF->mnId;
+                if (!pKFi->isBad()) { lFixedKeyFrames.push_back(pKFi); break; }
+            }
+        }
+        if (lFixedKeyFrames.size() >= maxFixKF) break;
+    }
+    const int N = (int)vpOptimizableKFs.size();
+    num_OptKF = N; num_fixedKF = (int)lFixedKeyFrames.size();
+
+    std::vector<KeyFrame*> kfs(vpOptimizableKFs.begin(), vpOptimizableKFs.end());
+    kfs.insert(kfs.end(), lFixedKeyFrames.begin(), lFixedKeyFrames.end());
+    std::map<KeyFrame*, int> kfIndex;
+    const int nKF = (int)kfs.size();
+    std::vector<double> Rwb(9 * nKF), twb(3 * nKF), vel(3 * nKF, 0.0), bg(3 * nKF, 0.0), ba(3 * nKF, 0.0);
+    std::vector<uint8_t> poseFixed(nKF), hasImu(nKF), imuFixed(nKF);
+    for (int i = 0; i < nKF; i++) {
+        KeyFrame* k = kfs[i];
+        kfIndex[k] = i;
+        const Eigen::Matrix3d R = k->GetImuRotation().cast<double>();
+        const Eigen::Vector3d t = k->GetImuPosition().cast<double>();
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rwb[9 * i + 3 * r + c] = R(r, c); twb[3 * i + r] = t(r); }
+        poseFixed[i] = imuFixed[i] = i >= N;                                        // :2541-2600
+        hasImu[i] = k->bImu;
+        if (k->bImu) {
+            const Eigen::Vector3d v = k->GetVelocity().cast<double>(), g = k->GetGyroBias().cast<double>(), a = k->GetAccBias().cast<double>();
+            for (int r = 0; r < 3; r++) { vel[3 * i + r] = v(r); bg[3 * i + r] = g(r); ba[3 * i + r] = a(r); }
+        }
+    }
+    std::vector<LibaLink> links;                                                    // :2603-2672
+    for (int i = 0; i < N; i++) {
+        KeyFrame* pKFi = vpOptimizableKFs[i];
+        if (!pKFi->mPrevKF || !kfIndex.count(pKFi->mPrevKF)) continue;
+        if (!(pKFi->bImu && pKFi->mPrevKF->bImu && pKFi->mpImuPreintegrated)) continue;
+        IMU::Preintegrated* pInt = pKFi->mpImuPreintegrated;
+        pInt->SetNewBias(pKFi->mPrevKF->GetImuBias());
+        LibaLink L;
+        std::memset(&L, 0, sizeof(L));
+        L.kf1 = kfIndex[pKFi->mPrevKF]; L.kf2 = kfIndex[pKFi];
+        auto put3x3 = [](float* dst, const Eigen::Matrix3f& M) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) dst[3 * r + c] = M(r, c); };
+        put3x3(L.dR, pInt->dR); put3x3(L.JRg, pInt->JRg); put3x3(L.JVg, pInt->JVg); put3x3(L.JVa, pInt->JVa); put3x3(L.JPg, pInt->JPg); put3x3(L.JPa, pInt->JPa);
+        for (int r = 0; r < 3; r++) { L.dV[r] = pInt->dV(r); L.dP[r] = pInt->dP(r); }
+        L.dT = pInt->dT;
+        const IMU::Bias b = pInt->GetOriginalBias();
+        L.bias0[0] = b.bax; L.bias0[1] = b.bay; L.bias0[2] = b.baz; L.bias0[3] = b.bwx; L.bias0[4] = b.bwy; L.bias0[5] = b.bwz;
+        Eigen::Matrix<double, 9, 9> Info = pInt->C.block<9, 9>(0, 0).cast<double>().inverse();   // EdgeInertial ctor, G2oTypes.cc:510-518
+        Info = (Info + Info.transpose()) / 2;
+        Eigen::SelfAdjointEigenSolver<Eigen::Matrix<double, 9, 9> > es(Info);
+        Eigen::Matrix<double, 9, 1> eigs = es.eigenvalues();
+        for (int k = 0; k < 9; k++) if (eigs[k] < 1e-12) eigs[k] = 0;
+        Info = es.eigenvectors() * eigs.asDiagonal() * es.eigenvectors().transpose();
+        L.robust = (i == N - 1 || bRecInit);
+        if (i == N - 1) Info *= 1e-2;                                               // :2651
+        const Eigen::Matrix3d InfoG = pInt->C.block<3, 3>(9, 9).cast<double>().inverse(), InfoA = pInt->C.block<3, 3>(12, 12).cast<double>().inverse();
+        for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) L.info9[9 * r + c] = Info(r, c);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { L.info_gyro[3 * r + c] = InfoG(r, c); L.info_acc[3 * r + c] = InfoA(r, c); }
+        links.push_back(L);
+    }
+    std::vector<MapPoint*> mps(lLocalMapPoints.begin(), lLocalMapPoints.end());     // :2714-2840
+    std::map<MapPoint*, int> mpIndex;
+    std::vector<double> X(3 * mps.size());
+    for (size_t i = 0; i < mps.size(); i++) {
+        mpIndex[mps[i]] = (int)i;
+        const Eigen::Vector3d Xd = mps[i]->GetWorldPos().cast<double>();
+        X[3 * i] = Xd.x(); X[3 * i + 1] = Xd.y(); X[3 * i + 2] = Xd.z();
+    }
+    std::vector<int32_t> eKFi, ePt;
+    std::vector<double> eObs, eW;
+    std::vector<uint8_t> eStereo;
+    std::vector<KeyFrame*> eKF;
+    std::vector<MapPoint*> eMP;
+    for (MapPoint* pMP : lLocalMapPoints)
+        for (auto& obs : pMP->GetObservations()) {
+            KeyFrame* pKFi = obs.first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) continue;
+            if (pKFi->isBad() || pKFi->GetMap() != pCurrentMap || !kfIndex.count(pKFi)) continue;
+            const int leftIndex = std::get<0>(obs.second);
+            if (leftIndex == -1) continue;
+            const cv::KeyPoint& kpUn = pKFi->mvKeysUn[leftIndex];
+            const float ur = pKFi->mvuRight[leftIndex];
+            Eigen::Matrix<double, 2, 1> o2; o2 << kpUn.pt.x, kpUn.pt.y;
+            const float unc2 = pKFi->mpCamera->uncertainty2(o2);
+            const float invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave] / unc2;
+            eKFi.push_back(kfIndex[pKFi]); ePt.push_back(mpIndex[pMP]);
+            eObs.push_back(kpUn.pt.x); eObs.push_back(kpUn.pt.y); eObs.push_back(ur >= 0 ? (double)ur : -1.0);
+            eW.push_back((double)invSigma2); eStereo.push_back(ur >= 0);
+            eKF.push_back(pKFi); eMP.push_back(pMP);
+        }
+    num_edges = (int)eKFi.size();
+
+    LibaProblem pr;
+    std::memset(&pr, 0, sizeof(pr));
+    pr.n_kf = nKF; pr.Rwb = Rwb.data(); pr.twb = twb.data(); pr.vel = vel.data(); pr.bg = bg.data(); pr.ba = ba.data();
+    pr.pose_fixed = poseFixed.data(); pr.has_imu = hasImu.data(); pr.imu_fixed = imuFixed.data();
+    const Eigen::Matrix3d Rcb = pKF->mImuCalib.mTcb.rotationMatrix().cast<double>();
+    const Eigen::Vector3d tcb = pKF->mImuCalib.mTcb.translation().cast<double>(), tbc = pKF->mImuCalib.mTbc.translation().cast<double>();
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pr.Rcb[3 * r + c] = Rcb(r, c); pr.tcb[r] = tcb(r); pr.tbc[r] = tbc(r); }
+    pr.fx = pKF->fx; pr.fy = pKF->fy; pr.cx = pKF->cx; pr.cy = pKF->cy; pr.bf = pKF->mbf;
+    pr.n_points = (int)mps.size(); pr.points = X.data();
+    pr.n_edges = num_edges; pr.edge_kf = eKFi.data(); pr.edge_point = ePt.data(); pr.edge_obs = eObs.data(); pr.edge_inv_sigma2 = eW.data(); pr.edge_stereo = eStereo.data();
+    pr.n_links = (int)links.size(); pr.links = links.data();
+    const float thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815);             // :2694-2697 (through float)
+    pr.huber_mono = thHuberMono; pr.huber_stereo = thHuberStereo; pr.huber_inertial = sqrt(16.92);
+    pr.lambda_init = bLarge ? 1e-2 : 1e0; pr.max_iters = opt_it;
+    static thread_local liba_solver* solver = nullptr;
+    if (!solver) orbslam3_hip::check(liba_create(0, &solver));
+    std::vector<double> Ro(Rwb.size()), to(twb.size()), vo(vel.size()), go(bg.size()), ao(ba.size()), Xo(X.size()), chi2(num_edges);
+    std::vector<uint8_t> depthPos(num_edges);
+    LbaStats st;
+    orbslam3_hip::check(liba_solve(solver, &pr, Ro.data(), to.data(), vo.data(), go.data(), ao.data(), Xo.data(), chi2.data(), depthPos.data(), &st));
+    const float err = (float)st.chi2_initial, err_end = (float)st.chi2_final;       // :2843-2845
+
+    const float chi2Mono2 = 5.991, chi2Stereo2 = 7.815;                             // :2849-2884
+    std::vector<std::pair<KeyFrame*, MapPoint*> > vToErase;
+    for (int e = 0; e < num_edges; e++) {
+        if (eMP[e]->isBad()) continue;
+        if (eStereo[e]) { if (chi2[e] > chi2Stereo2) vToErase.push_back(std::make_pair(eKF[e], eMP[e])); continue; }
+        const bool bClose = eMP[e]->mTrackDepth < 10.f;
+        if ((chi2[e] > chi2Mono2 && !bClose) || (chi2[e] > 1.5f * chi2Mono2 && bClose) || !depthPos[e]) vToErase.push_back(std::make_pair(eKF[e], eMP[e]));
+    }
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                       // :2887
+    if ((2 * err < err_end || std::isnan(err) || std::isnan(err_end)) && !bLarge) return;        // :2891-2895
+    for (auto& er : vToErase) { er.first->EraseMapPointMatch(er.second); er.second->EraseObservation(er.first); }
+    for (KeyFrame* k : lFixedKeyFrames) k->mnBAFixedForKF = 0;
+    for (int i = 0; i < N; i++) {                                                   // :2913-2934
+        KeyFrame* pKFi = vpOptimizableKFs[i];
+        Eigen::Matrix3d R; Eigen::Vector3d t;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R(r, c) = Ro[9 * i + 3 * r + c]; t(r) = to[3 * i + r]; }
+        const Eigen::Matrix3d Rcw = Rcb * R.transpose();                            // ImuCamPose: Rcw = Rcb Rbw, tcw = Rcb tbw + tcb
+        const Eigen::Vector3d tcw = Rcb * (-R.transpose() * t) + tcb;
+        pKFi->SetPose(Sophus::SE3f(Rcw.cast<float>(), tcw.cast<float>()));
+        pKFi->mnBALocalForKF = 0;
+        if (pKFi->bImu) {
+            pKFi->SetVelocity(Eigen::Vector3d(vo[3 * i], vo[3 * i + 1], vo[3 * i + 2]).cast<float>());
+            pKFi->SetNewBias(IMU::Bias(ao[3 * i], ao[3 * i + 1], ao[3 * i + 2], go[3 * i], go[3 * i + 1], go[3 * i + 2]));
+        }
+    }
+    for (MapPoint* pMP : lLocalMapPoints) {                                         // :2947-2954
         const int i = mpIndex[pMP];
         pMP->SetWorldPos(Eigen::Vector3d(Xo[3 * i], Xo[3 * i + 1], Xo[3 * i + 2]).cast<float>());
         pMP->UpdateNormalAndDepth();

@@ -334,7 +334,8 @@ def _so3_exp(w):
     return np.eye(3) + W * (np.sin(th) / th) + W @ W * ((1 - np.cos(th)) / th ** 2)
 
 
-def make_inertial_window(seed, n_opt=6, n_points=150, obs_per_point=4, dt=0.25, noise_px=0.5, perturb=True, bias_error=0.0):
+def make_inertial_window(seed, n_opt=6, n_points=150, obs_per_point=4, dt=0.25, noise_px=0.5, perturb=True, bias_error=0.0, stereo_frac=0.0,
+                         n_covisible_fixed=0):
     """A LocalInertialBA window (reference src/Optimizer.cc:2383-2958) with consistent synthetic data: key frame 0 is the fixed
     one in front of the temporal window (pose and IMU states fixed), key frames 1..n_opt are optimised; every consecutive pair
     is linked by a pre-integrated measurement computed from the ground-truth states (plus noise), so that the ground truth is a
@@ -374,7 +375,8 @@ def make_inertial_window(seed, n_opt=6, n_points=150, obs_per_point=4, dt=0.25, 
     # points in front of the cameras
     centre = np.mean(pwb, axis=0)
     pts = centre + np.array([6.0, 0, 0]) + rs.uniform(-1, 1, (n_points, 3)) * np.array([2.0, 3.0, 2.0])
-    e_kf, e_pt, e_obs, e_w = [], [], [], []
+    e_kf, e_pt, e_obs, e_w, e_st = [], [], [], [], []
+    bf = 47.9 if stereo_frac > 0 else 0.0
     for l in range(n_points):
         for i in sorted(rs.choice(n, min(obs_per_point, n), replace=False)):
             Rcw = Rcb @ Rwb[i].T; tcw = Rcb @ (-Rwb[i].T @ pwb[i]) + tcb
@@ -384,20 +386,38 @@ def make_inertial_window(seed, n_opt=6, n_points=150, obs_per_point=4, dt=0.25, 
             octave = rs.randint(0, 4)
             sig = 1.2 ** octave
             uv = np.array([fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy]) + rs.normal(0, noise_px * sig, 2)
-            e_kf.append(i); e_pt.append(l); e_obs.append([np.float32(uv[0]), np.float32(uv[1]), -1.0]); e_w.append(np.float32(1.0 / sig ** 2))
+            st = rs.uniform() < stereo_frac
+            ur = np.float32(uv[0] - bf / Xc[2] + rs.normal(0, noise_px * sig)) if st else -1.0
+            e_kf.append(i); e_pt.append(l); e_obs.append([np.float32(uv[0]), np.float32(uv[1]), ur]); e_w.append(np.float32(1.0 / sig ** 2)); e_st.append(int(st))
+    # extra fixed key frames that only observe points (lFixedKeyFrames from the covisibility graph: pose only, no IMU states)
+    for c in range(n_covisible_fixed):
+        Rc = Rwb[1 + c % n_opt] @ _so3_exp(rs.normal(0, 0.05, 3)); pc = pwb[1 + c % n_opt] + rs.normal(0, 0.3, 3)
+        Rwb.append(Rc); pwb.append(pc); vel.append(np.zeros(3))
+        for l in rs.choice(n_points, min(40, n_points), replace=False):
+            Rcw = Rcb @ Rc.T; tcw = Rcb @ (-Rc.T @ pc) + tcb
+            Xc = Rcw @ pts[l] + tcw
+            if Xc[2] < 0.5:
+                continue
+            uv = np.array([fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy]) + rs.normal(0, noise_px, 2)
+            e_kf.append(n + c); e_pt.append(int(l)); e_obs.append([np.float32(uv[0]), np.float32(uv[1]), -1.0]); e_w.append(np.float32(1.0)); e_st.append(0)
+    # LocalInertialBA adds the edges per map point (Optimizer.cc:2720-2840): keep them grouped by point
+    order = np.argsort(np.array(e_pt), kind="stable")
+    e_kf = [e_kf[i] for i in order]; e_pt = [e_pt[i] for i in order]; e_obs = [e_obs[i] for i in order]; e_w = [e_w[i] for i in order]; e_st = [e_st[i] for i in order]
+    nc = n_covisible_fixed
     gt = dict(Rwb=np.array(Rwb), twb=np.array(pwb), vel=np.array(vel), points=pts.copy())
     Rwb0 = np.array(Rwb); twb0 = np.array(pwb); vel0 = np.array(vel); pts0 = pts.copy()
-    bg0 = np.tile(bg_true, (n, 1)) + bias_error; ba0 = np.tile(ba_true, (n, 1)) + bias_error
+    bg0 = np.tile(bg_true, (n + nc, 1)) + bias_error; ba0 = np.tile(ba_true, (n + nc, 1)) + bias_error
     if perturb:
         for i in range(1, n):
             Rwb0[i] = Rwb0[i] @ _so3_exp(rs.normal(0, 0.01, 3)); twb0[i] = twb0[i] + rs.normal(0, 0.02, 3); vel0[i] = vel0[i] + rs.normal(0, 0.03, 3)
         pts0 = pts0 + rs.normal(0, 0.03, pts0.shape)
     f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)       # the reference loads float members into double vertices
-    pr = dict(n_kf=n, Rwb=f32(Rwb0), twb=f32(twb0), vel=f32(vel0), bg=f32(bg0), ba=f32(ba0),
-              pose_fixed=np.array([1] + [0] * n_opt, np.uint8), has_imu=np.ones(n, np.uint8), imu_fixed=np.array([1] + [0] * n_opt, np.uint8),
-              Rcb=f32(Rcb), tcb=f32(tcb), tbc=f32(tbc), fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)), bf=0.0,
+    pr = dict(n_kf=n + nc, Rwb=f32(Rwb0), twb=f32(twb0), vel=f32(vel0), bg=f32(bg0), ba=f32(ba0),
+              pose_fixed=np.array([1] + [0] * n_opt + [1] * nc, np.uint8), has_imu=np.array([1] * n + [0] * nc, np.uint8),
+              imu_fixed=np.array([1] + [0] * n_opt + [1] * nc, np.uint8),
+              Rcb=f32(Rcb), tcb=f32(tcb), tbc=f32(tbc), fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)), bf=float(np.float32(bf)),
               points=f32(pts0), edge_kf=np.array(e_kf, np.int32), edge_point=np.array(e_pt, np.int32), edge_obs=np.array(e_obs, np.float64),
-              edge_inv_sigma2=np.array(e_w, np.float64), edge_stereo=np.zeros(len(e_kf), np.uint8), links=links,
+              edge_inv_sigma2=np.array(e_w, np.float64), edge_stereo=np.array(e_st, np.uint8), links=links,
               huber_mono=float(np.float32(np.sqrt(5.991))), huber_stereo=float(np.float32(np.sqrt(7.815))), huber_inertial=float(np.sqrt(16.92)),
               lambda_init=1.0, max_iters=10)
     return pr, gt

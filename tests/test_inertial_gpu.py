@@ -34,6 +34,22 @@ def test_inertial_ba_matches_oracle(pkg, oracle, synth):
         s.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_inertial_ba_sweep(pkg, oracle, synth, seed):
+    """seeded sweep over window size, observation count, stereo share, covisible fixed key frames, bLarge settings"""
+    rs = np.random.RandomState(900 + seed)
+    kw = dict(n_opt=int(rs.randint(2, 26)), n_points=int(rs.randint(30, 700)), obs_per_point=int(rs.randint(3, 8)),
+              stereo_frac=float(rs.choice([0.0, 0.0, 0.4, 1.0])), n_covisible_fixed=int(rs.choice([0, 0, 3, 10])), bias_error=float(rs.choice([0.0, 0.001])))
+    pr, _ = synth.make_inertial_window(50 + seed, **kw)
+    if seed & 1:
+        pr["lambda_init"] = 1e-2; pr["max_iters"] = 4
+    s = pkg.InertialSolver()
+    try:
+        _compare(oracle_inertial_solve(oracle, pr), s.solve(pr), pr, kw)
+    finally:
+        s.close()
+
+
 def test_inertial_ba_converges_and_keeps_the_fixed_key_frame(pkg, synth):
     pr, gt = synth.make_inertial_window(7, n_opt=6, n_points=200, obs_per_point=5, noise_px=0.3)
     s = pkg.InertialSolver()
