@@ -1,5 +1,7 @@
 """LocalInertialBA on the device (liba_solve; reference src/Optimizer.cc:2383-2958) against the oracle: same Levenberg control
 flow (iterations, trials, stop reason), states within 1e-4 relative of the update, identical depth signs.  PARITY UNPINNED."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,3 +94,16 @@ def test_inertial_ba_degenerate_windows(pkg, oracle, synth):
         _compare(oracle_inertial_solve(oracle, pr), s.solve(pr), pr, "one key frame")
     finally:
         s.close()
+
+
+def test_golden_inertial_window_on_device(pkg, synth):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "inertial_5kf_120mp.npz"))
+    pr = synth.make_inertial_window(45, n_opt=5, n_points=120, obs_per_point=4, stereo_frac=0.3, n_covisible_fixed=2)[0]
+    s = pkg.InertialSolver()
+    r = s.solve(pr)
+    s.close()
+    assert (r["stats"]["iterations"], r["stats"]["trials"]) == (int(g["iterations"]), int(g["trials"]))
+    np.testing.assert_allclose(r["stats"]["chi2_final"], float(g["chi2_final"]), rtol=1e-6)
+    for k in ("twb", "vel", "points"):
+        d0, d1 = g[k] - np.asarray(pr[k]), r[k] - np.asarray(pr[k])
+        assert np.abs(d0 - d1).max() <= 1e-4 * np.abs(d0).max(), k

@@ -2,6 +2,8 @@
 there is no HIP counterpart yet.  PARITY UNPINNED; what can be checked without the reference is checked here: the restated
 analytic Jacobians of EdgeInertial against central differences through the restated update rule, that consistent data is a
 fixed point, and that a perturbed window converges back to the ground truth."""
+import os
+
 import numpy as np
 
 from oracle_api import oracle_inertial_jacobian_check, oracle_inertial_solve
@@ -56,3 +58,16 @@ def test_large_window_settings_and_bias_recovery(oracle, synth):
     pr["lambda_init"] = 1e-2; pr["max_iters"] = 4
     r = oracle_inertial_solve(oracle, pr)
     assert r["stats"]["iterations"] <= 4 and r["stats"]["chi2_final"] < r["stats"]["chi2_initial"]
+
+
+def _golden_window(synth):
+    return synth.make_inertial_window(45, n_opt=5, n_points=120, obs_per_point=4, stereo_frac=0.3, n_covisible_fixed=2)[0]
+
+
+def test_golden_inertial_window(oracle, synth):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "inertial_5kf_120mp.npz"))
+    r = oracle_inertial_solve(oracle, _golden_window(synth))
+    assert (r["stats"]["iterations"], r["stats"]["trials"]) == (int(g["iterations"]), int(g["trials"]))
+    np.testing.assert_allclose(r["stats"]["chi2_final"], float(g["chi2_final"]), rtol=1e-9)
+    for k in ("Rwb", "twb", "vel", "bg", "ba", "points"):
+        np.testing.assert_allclose(r[k], g[k], rtol=0, atol=1e-9)
