@@ -379,6 +379,9 @@ void lba_shard_destroy(lba_shard* s);
  * [ S (n x n, row-major) | b_schur (n) | b_p (n) | diag(Hpp) (n) ] -- every section is additive over shards. */
 int64_t lba_shard_reduce_len(const lba_shard* s);
 double* lba_shard_reduce_buffer(lba_shard* s);
+/* optional: announce the lambda of the first trial after the NEXT lba_shard_linearize (known from the second LM iteration on);
+ * the linearisation then also does the landmark side of the Schur complement and lba_shard_reduce skips that launch */
+int lba_shard_hint_lambda(lba_shard* s, double lambda);
 /* optional: use a caller-owned device buffer of lba_shard_reduce_len() doubles (e.g. a torch CUDA tensor) instead */
 int lba_shard_set_reduce_buffer(lba_shard* s, double* device_buffer);
 /* local != 0: world size 1, no all-reduce between reduce() and finish() -> lambda is folded into the Schur kernel, no sync */

@@ -630,6 +630,10 @@ class LbaShard:
         lib.lba_shard_set_reduce_buffer.argtypes = [C.c_void_p, C.c_void_p]
         _check(lib.lba_shard_set_reduce_buffer(self._h, device_ptr))
 
+    def hint_lambda(self, lam):
+        """the lambda of the first trial after the next linearize(): lets it fold the landmark side of the Schur complement in"""
+        _check(lib.lba_shard_hint_lambda(self._h, C.c_double(lam)))
+
     def linearize(self):
         """returns (chi2_local, max_diag_poses_local, max_diag_landmarks_local)"""
         chi, mp, ml = C.c_double(), C.c_double(), C.c_double()

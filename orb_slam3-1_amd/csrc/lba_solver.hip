@@ -142,9 +142,34 @@ __global__ __launch_bounds__(256) void k_errors(Dev d, const double* __restrict_
 
 // ---- buildSystem, landmark side: Hll, bl and the Hpl blocks W_e = B^T (rho1 Omega) A (6x3) ----
 // 8 lanes per landmark (a landmark has ~10 edges): lane q takes edges q, q+8, ...; fixed butterfly reduction.
-__global__ __launch_bounds__(64) void k_lin_landmarks(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+// Schur, landmark side, for one landmark held by 8 lanes: D^-1 of A = Hll + lambda I, db = D^-1 bl, Z_e = W_e D^-1 of its edges
+__device__ __forceinline__ void schur_landmark(const Dev& d, int l, int sub, const double* A, double b0, double b1, double b2)
 {
-    const int l = blockIdx.x * 8 + (threadIdx.x >> 3);
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    const double id = 1.0 / det;
+    double Di[9];
+    Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+    if (sub == 0) {
+        for (int k = 0; k < 9; k++) d.Dinv[9 * (size_t)l + k] = Di[k];
+        for (int a = 0; a < 3; a++) d.db[3 * (size_t)l + a] = Di[a * 3] * b0 + Di[a * 3 + 1] * b1 + Di[a * 3 + 2] * b2;
+    }
+    for (int k = d.l_off[l] + sub; k < d.l_off[l + 1]; k += 8) {
+        const int e = d.l_edge[k];
+        if (d.pose_col[d.e_pose[e]] < 0) continue;
+        const double* W = d.W + 18 * (size_t)e;
+        double* Z = d.Z + 18 * (size_t)e;
+        for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 3; c++) Z[r * 3 + c] = W[r * 3] * Di[c] + W[r * 3 + 1] * Di[3 + c] + W[r * 3 + 2] * Di[6 + c];
+    }
+}
+
+// (device function: the merged launch k_lin_all runs it in the workgroups behind the pose ones; lambda >= 0 also performs the landmark side of
+// the Schur complement for that lambda -- the W_e of a landmark's edges are written and read back by the same lanes)
+__device__ __forceinline__ void lin_landmarks_body(const Dev& d, const double* __restrict__ poses, const double* __restrict__ pts, int l, double lambda)
+{
     const int sub = threadIdx.x & 7;
     const bool live = l < d.nL;
     double acc[9];      // Hll upper triangle (6) + bl (3)
@@ -206,12 +231,20 @@ __global__ __launch_bounds__(64) void k_lin_landmarks(Dev d, const double* __res
         H[6] = acc[2]; H[7] = acc[4]; H[8] = acc[5];
         d.bl[3 * (size_t)l] = acc[6]; d.bl[3 * (size_t)l + 1] = acc[7]; d.bl[3 * (size_t)l + 2] = acc[8];
     }
+    if (live && lambda >= 0.0) {
+        const double A[9] = {acc[0] + lambda, acc[1], acc[2], acc[1], acc[3] + lambda, acc[4], acc[2], acc[4], acc[5] + lambda};
+        schur_landmark(d, l, sub, A, acc[6], acc[7], acc[8]);
+    }
 }
 
 // ---- buildSystem, pose side: Hpp (6x6) and bp; one 256-thread workgroup per non-fixed pose, fixed reduction tree ----
-__global__ __launch_bounds__(256) void k_lin_poses(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+__global__ __launch_bounds__(256) void k_lin_all(Dev d, const double* __restrict__ poses, const double* __restrict__ pts, double lambda)
 {
     __shared__ double s_part[4][27];
+    if ((int)blockIdx.x >= d.nP) {          // landmark workgroups: 32 landmarks x 8 lanes
+        lin_landmarks_body(d, poses, pts, ((int)blockIdx.x - d.nP) * 32 + (threadIdx.x >> 3), lambda);
+        return;
+    }
     const int col = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ip = d.col_pose[col];
     const double* T = poses + 7 * (size_t)ip;
@@ -313,26 +346,8 @@ __global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
     if (l >= d.nL) return;
     double A[9];
     for (int k = 0; k < 9; k++) A[k] = d.Hll[9 * (size_t)l + k] + ((k % 4 == 0) ? lambda : 0.0);
-    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
-    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
-    const double id = 1.0 / det;
-    double Di[9];
-    Di[0] = c00 * id; Di[1] = (A[2] * A[7] - A[1] * A[8]) * id; Di[2] = (A[1] * A[5] - A[2] * A[4]) * id;
-    Di[3] = c01 * id; Di[4] = (A[0] * A[8] - A[2] * A[6]) * id; Di[5] = (A[2] * A[3] - A[0] * A[5]) * id;
-    Di[6] = c02 * id; Di[7] = (A[1] * A[6] - A[0] * A[7]) * id; Di[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-    if (sub == 0) {
-        for (int k = 0; k < 9; k++) d.Dinv[9 * (size_t)l + k] = Di[k];
-        const double* b = d.bl + 3 * (size_t)l;
-        for (int a = 0; a < 3; a++) d.db[3 * (size_t)l + a] = Di[a * 3] * b[0] + Di[a * 3 + 1] * b[1] + Di[a * 3 + 2] * b[2];
-    }
-    for (int k = d.l_off[l] + sub; k < d.l_off[l + 1]; k += 8) {
-        const int e = d.l_edge[k];
-        if (d.pose_col[d.e_pose[e]] < 0) continue;
-        const double* W = d.W + 18 * (size_t)e;
-        double* Z = d.Z + 18 * (size_t)e;
-        for (int r = 0; r < 6; r++)
-            for (int c = 0; c < 3; c++) Z[r * 3 + c] = W[r * 3] * Di[c] + W[r * 3 + 1] * Di[3 + c] + W[r * 3 + 2] * Di[6 + c];
-    }
+    const double* b = d.bl + 3 * (size_t)l;
+    schur_landmark(d, l, sub, A, b[0], b[1], b[2]);
 }
 
 // ---- Schur, pose side: one workgroup per 6x6 block (i<=j) of the reduced camera system ----
@@ -954,6 +969,8 @@ struct lba_shard {
     double* reduce = nullptr;   // [n*n | bs n | bp n | diag n]
     double* Linv = nullptr;
     double* Lp = nullptr;       // L panels of the fused factorisation, (n+1) x n like the reduce buffer's S | b_schur
+    double hint_lambda = -1.0;  // lambda the next linearisation may pre-compute the landmark side of the Schur complement for
+    double schur_lambda = -1.0; // lambda that pre-computation is valid for (consumed by the next lba_shard_reduce)
     double* Ldiag = nullptr;
     bool sync_after_reduce = true;      // lba_solve() keeps everything on one stream and turns this off
     bool lambda_in_reduce = false;      // single-GPU: add lambda to diag(S) inside k_schur_blocks (no all-reduce in between)
@@ -1273,6 +1290,15 @@ static int read_scalars(lba_shard* s)
     return ORBX_OK;
 }
 
+// Optional: the lambda the first trial after the NEXT lba_shard_linearize will use (known from the second iteration on, or with a
+// user lambda).  The linearisation then also performs the landmark side of the Schur complement, saving a dependent launch.
+int lba_shard_hint_lambda(lba_shard* s, double lambda)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    s->hint_lambda = lambda;
+    return ORBX_OK;
+}
+
 // computeActiveErrors + activeRobustChi2 + buildSystem on the accepted state
 int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses_local, double* max_diag_landmarks_local)
 {
@@ -1287,8 +1313,11 @@ int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses
     // synchronising path (they are needed for lambda initialisation at the first iteration only).
     const bool reuse = s->err_current;
     if (!reuse && d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, P, X);
-    if (d.nL > 0) hipLaunchKernelGGL(lba::k_lin_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, P, X);
-    if (d.nP > 0) hipLaunchKernelGGL(lba::k_lin_poses, dim3(d.nP), dim3(256), 0, s->stream, d, P, X);
+    // one launch for both sides; with a lambda hint (lba_shard_hint_lambda) the landmark workgroups also do their part of the Schur complement
+    const double hint = s->hint_lambda;
+    s->hint_lambda = -1.0;
+    if (d.nP + d.nL > 0) hipLaunchKernelGGL(lba::k_lin_all, dim3(d.nP + (d.nL + 31) / 32), dim3(256), 0, s->stream, d, P, X, hint);
+    s->schur_lambda = hint;
     if (!reuse) {
         hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0, s->d_hmap, ++s->seq);
         LBA_HIP(hipGetLastError());
@@ -1314,7 +1343,9 @@ int lba_shard_reduce(lba_shard* s, double lambda)
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
     LBA_HIP(hipSetDevice(s->device));
     const lba::Dev& d = s->d;
-    if (d.nL > 0) hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, lambda);
+    if (d.nL > 0 && !(s->schur_lambda >= 0.0 && s->schur_lambda == lambda))
+        hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, lambda);
+    s->schur_lambda = -1.0;                 // W / Dinv / Z now belong to this lambda only until the next trial changes it
     if (d.nBlocks + d.nP > 0)
         hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks + d.nP), dim3(256), 0, s->stream, d, s->S(),
                            s->lambda_in_reduce ? lambda : 0.0, s->bs(), s->bpf(), s->diag());
@@ -1464,6 +1495,8 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
     for (int it = 0; it < max_iters; it++) {
         if (terminate()) { st.stop_reason = 3; break; }
         double currentChi = 0, mdp = 0, mdl = 0;
+        if (it > 0) lba_shard_hint_lambda(s, lambda);
+        else if (lambda_init > 0) lba_shard_hint_lambda(s, lambda_init);
         if ((r = lba_shard_linearize(s, &currentChi, &mdp, &mdl))) break;
         const double iniChi = currentChi;
         if (it == 0) {

@@ -98,6 +98,9 @@ def sharded_bundle_adjustment(shard, reduce_tensor, comm=None, max_iters=10, lam
         if terminate():
             stats["stop_reason"] = 3
             break
+        hint = getattr(shard, "hint_lambda", None)
+        if hint is not None and (it > 0 or lambda_init > 0):    # the lambda of the coming first trial is already known
+            hint(lam if it > 0 else lambda_init)
         chi_l, mdp_l, mdl_l = shard.linearize()
         current_chi = comm.sum_scalars([chi_l])[0]
         ini_chi = current_chi
@@ -161,6 +164,9 @@ class LocalHipShard:
         self._mdp = 0.0
         lba_shard.set_local(True)       # no collective between reduce() and finish()
 
+    def hint_lambda(self, lam):
+        self.s.hint_lambda(lam)
+
     def linearize(self):
         chi, mdp, mdl = self.s.linearize()
         self._mdp = mdp
@@ -190,6 +196,9 @@ class HipShard:
         lba_shard.set_reduce_buffer(self.tensor.data_ptr())
         # n*n + 3n = n_red  ->  n
         self.n = int(round((-3 + math.sqrt(9 + 4 * self.n_red)) / 2))
+
+    def hint_lambda(self, lam):
+        self.s.hint_lambda(lam)
 
     def linearize(self):
         return self.s.linearize()
