@@ -569,3 +569,180 @@ extern "C" double inertial_oracle_jacobian_check(const OracleInertialProblem* P,
         }
     return worst;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Optimizer::PoseInertialOptimizationLastKeyFrame (reference src/Optimizer.cc:4491-4873): the per-frame optimisation of the
+ * inertial tracker.  15 unknowns (body pose, velocity, gyro bias, accelerometer bias of the current frame); the last key
+ * frame's states are fixed.  Edges: EdgeMonoOnlyPose / EdgeStereoOnlyPose (unary, Huber), EdgeInertial, EdgeGyroRW, EdgeAccRW.
+ * g2o Gauss-Newton (optimization_algorithm_gauss_newton.cpp:49-90: errors -> build -> dense solve -> update; NO step control),
+ * 4 rounds x 10 iterations with re-classification of the observations after every round.  Quirk replicated: e->chi2() of an
+ * ACTIVE edge is the error computed at the start of the last iteration (before the last update; nothing recomputes it), while
+ * an outlier edge is recomputed at the current state (:4723-4726).  GROUNDWORK: oracle only, no HIP path yet.  PARITY UNPINNED.
+ * Deviation: if the dense solve fails the round stops without applying an update (g2o applies the stale solution vector).
+ * --------------------------------------------------------------------------------------------------------------------------- */
+extern "C" int pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P, double* Rwb_out, double* twb_out, double* vel_out,
+                                             double* bg_out, double* ba_out, uint8_t* outlier, double* H15_out, int* n_bad_out)
+{
+    Problem pr;
+    OracleInertialProblem dummy;
+    std::memset(&dummy, 0, sizeof(dummy));
+    pr.p = &dummy;
+    std::memcpy(pr.Rcb, P->Rcb, sizeof(pr.Rcb)); std::memcpy(pr.tcb, P->tcb, sizeof(pr.tcb)); std::memcpy(pr.tbc, P->tbc, sizeof(pr.tbc));
+    mat_tr(pr.Rcb, pr.Rbc);
+    pr.kf.resize(2);                                        /* 0: last key frame (fixed), 1: current frame */
+    for (int i = 0; i < 2; i++) {
+        KF& k = pr.kf[i];
+        std::memcpy(k.Rwb, P->Rwb + 9 * i, 72); std::memcpy(k.twb, P->twb + 3 * i, 24); std::memcpy(k.v, P->vel + 3 * i, 24);
+        std::memcpy(k.bg, P->bg + 3 * i, 24); std::memcpy(k.ba, P->ba + 3 * i, 24);
+        k.its = 0;
+        pr.camera_from_body(k);
+    }
+    const OracleInertialLink& L = P->link;
+    const int n = P->n;
+    std::vector<double> err(3 * (size_t)std::max(n, 1), 0.0);
+    std::vector<uint8_t> level(std::max(n, 1), 0);
+    for (int i = 0; i < n; i++) outlier[i] = 0;
+    bool robust = true;
+    KF& F = pr.kf[1];
+    auto edge_error = [&](int i, double* r) {
+        double Xc[3];
+        pr.project(F, P->Xw + 3 * (size_t)i, Xc);
+        const double u = P->fx * Xc[0] / Xc[2] + P->cx, v = P->fy * Xc[1] / Xc[2] + P->cy;
+        r[0] = P->obs[3 * i] - u; r[1] = P->obs[3 * i + 1] - v; r[2] = 0;
+        if (P->stereo[i]) r[2] = P->obs[3 * i + 2] - (u - P->bf * (1 / Xc[2]));
+    };
+    auto edge_chi2 = [&](int i) { const double* r = &err[3 * (size_t)i]; return P->inv_sigma2[i] * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]); };
+    auto edge_jac = [&](int i, double* Jj) {                /* EdgeMonoOnlyPose / EdgeStereoOnlyPose::linearizeOplus (G2oTypes.cc:380-450) */
+        double Xc[3], Xb[3];
+        pr.project(F, P->Xw + 3 * (size_t)i, Xc);
+        mat_vec(pr.Rbc, Xc, Xb);
+        for (int q = 0; q < 3; q++) Xb[q] += pr.tbc[q];
+        const double iz = 1.0 / Xc[2], iz2 = 1.0 / (Xc[2] * Xc[2]);
+        double pj[9] = {P->fx * iz, 0, -P->fx * Xc[0] * iz2, 0, P->fy * iz, -P->fy * Xc[1] * iz2, 0, 0, 0};
+        if (P->stereo[i]) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + P->bf * iz2; }
+        double prb[9];
+        mat_mul(pj, pr.Rcb, prb);
+        const double x = Xb[0], y = Xb[1], z = Xb[2];
+        const double D[18] = {0, z, -y, 1, 0, 0, -z, 0, x, 0, 1, 0, y, -x, 0, 0, 0, 1};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 6; c++) Jj[6 * r + c] = prb[3 * r] * D[c] + prb[3 * r + 1] * D[6 + c] + prb[3 * r + 2] * D[12 + c];
+    };
+    const float chi2Mono[4] = {12, 7.5, 5.991, 5.991}, chi2Stereo[4] = {15.6, 9.8, 7.815, 7.815};
+    int nBad = 0, nInliers = 0;
+    for (int it = 0; it < 4; it++) {
+        for (int k = 0; k < 10; k++) {                       /* optimize(its[it]): Gauss-Newton */
+            double H[225], b[15];
+            std::memset(H, 0, sizeof(H)); std::memset(b, 0, sizeof(b));
+            for (int i = 0; i < n; i++) {
+                if (level[i]) continue;
+                edge_error(i, &err[3 * (size_t)i]);
+                const int ne = P->stereo[i] ? 3 : 2;
+                const double c = edge_chi2(i), delta = P->stereo[i] ? P->huber_stereo : P->huber_mono;
+                const double rho1 = (robust && c > delta * delta) ? delta / std::sqrt(c) : 1.0;
+                const double w = P->inv_sigma2[i] * rho1;
+                double Jj[18];
+                edge_jac(i, Jj);
+                const double* r = &err[3 * (size_t)i];
+                for (int a = 0; a < 6; a++) {
+                    for (int c2 = 0; c2 < 6; c2++) { double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * Jj[6 * q + c2]; H[15 * a + c2] += w * s2; }
+                    double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * r[q];
+                    b[a] -= w * s2;
+                }
+            }
+            double e9[9], J[6][54];
+            pr.inertial_error(L, e9);
+            pr.inertial_jacobians(L, J);
+            double J9[81];                                   /* 9 x 9: [J_P2 | J_V2] */
+            for (int r = 0; r < 9; r++) { for (int c = 0; c < 6; c++) J9[9 * r + c] = J[4][6 * r + c]; for (int c = 0; c < 3; c++) J9[9 * r + 6 + c] = J[5][3 * r + c]; }
+            for (int a = 0; a < 9; a++) {
+                for (int c = 0; c < 9; c++) {
+                    double s2 = 0;
+                    for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * J9[9 * q + c]; s2 += J9[9 * r + a] * t; }
+                    H[15 * a + c] += s2;
+                }
+                double s2 = 0;
+                for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * e9[q]; s2 += J9[9 * r + a] * t; }
+                b[a] -= s2;
+            }
+            for (int which = 0; which < 2; which++) {        /* random walks towards the key frame's biases */
+                const double* Om3 = which ? L.info_acc : L.info_gyro;
+                const int o = which ? 12 : 9;
+                double d[3], Od[3];
+                for (int q = 0; q < 3; q++) d[q] = which ? F.ba[q] - pr.kf[0].ba[q] : F.bg[q] - pr.kf[0].bg[q];
+                mat_vec(Om3, d, Od);
+                for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) H[15 * (o + a) + o + c] += Om3[3 * a + c]; b[o + a] -= Od[a]; }
+            }
+            /* dense Cholesky solve H x = b */
+            double Lm[225], x[15];
+            std::memcpy(Lm, H, sizeof(H));
+            bool ok = true;
+            for (int j = 0; j < 15 && ok; j++) {
+                double d = Lm[15 * j + j];
+                for (int q = 0; q < j; q++) d -= Lm[15 * j + q] * Lm[15 * j + q];
+                if (!(d > 0.0) || !std::isfinite(d)) { ok = false; break; }
+                const double ljj = std::sqrt(d);
+                Lm[15 * j + j] = ljj;
+                for (int i = j + 1; i < 15; i++) { double s2 = Lm[15 * i + j]; for (int q = 0; q < j; q++) s2 -= Lm[15 * i + q] * Lm[15 * j + q]; Lm[15 * i + j] = s2 / ljj; }
+            }
+            if (!ok) break;
+            for (int i = 0; i < 15; i++) { double s2 = b[i]; for (int q = 0; q < i; q++) s2 -= Lm[15 * i + q] * x[q]; x[i] = s2 / Lm[15 * i + i]; }
+            for (int i = 14; i >= 0; i--) { double s2 = x[i]; for (int q = i + 1; q < 15; q++) s2 -= Lm[15 * q + i] * x[q]; x[i] = s2 / Lm[15 * i + i]; }
+            pr.update_pose(F, x);
+            for (int q = 0; q < 3; q++) { F.v[q] += x[6 + q]; F.bg[q] += x[9 + q]; F.ba[q] += x[12 + q]; }
+        }
+        nBad = 0; nInliers = 0;
+        const float chi2close = 1.5 * chi2Mono[it];
+        for (int pass = 0; pass < 2; pass++)                 /* mono edges first, then stereo (:4716-4789); the order only matters for counters */
+            for (int i = 0; i < n; i++) {
+                if ((P->stereo[i] != 0) != (pass == 1)) continue;
+                if (outlier[i]) edge_error(i, &err[3 * (size_t)i]);
+                const float chi2 = (float)edge_chi2(i);
+                bool bad;
+                if (!P->stereo[i]) {
+                    double Xc[3];
+                    pr.project(F, P->Xw + 3 * (size_t)i, Xc);
+                    const bool bClose = P->close_point[i] != 0;
+                    bad = (chi2 > chi2Mono[it] && !bClose) || (bClose && chi2 > chi2close) || !(Xc[2] > 0.0);
+                } else
+                    bad = chi2 > chi2Stereo[it];
+                outlier[i] = bad; level[i] = bad;
+                if (bad) nBad++; else nInliers++;
+            }
+        if (it == 2) robust = false;
+        if (n + 3 < 10) break;                               /* optimizer.edges().size() < 10 (:4794) */
+    }
+    if (nInliers < 30 && !P->rec_init) {                     /* recover not too bad points (:4802-4828) */
+        nBad = 0;
+        for (int i = 0; i < n; i++) {
+            edge_error(i, &err[3 * (size_t)i]);
+            if ((float)edge_chi2(i) < (P->stereo[i] ? 24.f : 18.f)) outlier[i] = 0; else nBad++;
+        }
+    }
+    /* Hessian of the new prior (:4837-4870): inertial edge w.r.t. (pose, velocity), the random-walk informations, the inliers' 6 x 6 */
+    double Hout[225];
+    std::memset(Hout, 0, sizeof(Hout));
+    {
+        double J[6][54], J9[81];
+        pr.inertial_jacobians(L, J);
+        for (int r = 0; r < 9; r++) { for (int c = 0; c < 6; c++) J9[9 * r + c] = J[4][6 * r + c]; for (int c = 0; c < 3; c++) J9[9 * r + 6 + c] = J[5][3 * r + c]; }
+        for (int a = 0; a < 9; a++)
+            for (int c = 0; c < 9; c++) {
+                double s2 = 0;
+                for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * J9[9 * q + c]; s2 += J9[9 * r + a] * t; }
+                Hout[15 * a + c] += s2;
+            }
+        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) { Hout[15 * (9 + a) + 9 + c] += L.info_gyro[3 * a + c]; Hout[15 * (12 + a) + 12 + c] += L.info_acc[3 * a + c]; }
+        for (int i = 0; i < n; i++) {
+            if (outlier[i]) continue;
+            const int ne = P->stereo[i] ? 3 : 2;
+            double Jj[18];
+            edge_jac(i, Jj);
+            for (int a = 0; a < 6; a++)
+                for (int c = 0; c < 6; c++) { double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * Jj[6 * q + c]; Hout[15 * a + c] += P->inv_sigma2[i] * s2; }
+        }
+    }
+    std::memcpy(Rwb_out, F.Rwb, 72); std::memcpy(twb_out, F.twb, 24); std::memcpy(vel_out, F.v, 24); std::memcpy(bg_out, F.bg, 24); std::memcpy(ba_out, F.ba, 24);
+    if (H15_out) std::memcpy(H15_out, Hout, sizeof(Hout));
+    if (n_bad_out) *n_bad_out = nBad;
+    return n - nBad;
+}

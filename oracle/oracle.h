@@ -281,6 +281,25 @@ int    inertial_oracle_solve(const OracleInertialProblem* P, double* Rwb_out, do
                              double* ba_out, double* points_out, double* chi2_per_edge, uint8_t* depth_positive, OracleLbaStats* stats);
 double inertial_oracle_jacobian_check(const OracleInertialProblem* P, int link, double h);
 
+/* Optimizer::PoseInertialOptimizationLastKeyFrame (reference src/Optimizer.cc:4491-4873).  GROUNDWORK: oracle only. */
+typedef struct OraclePoseInertialProblem {
+    double Rwb[18], twb[6], vel[6], bg[6], ba[6];    /* [0] the last key frame (fixed), [1] the current frame */
+    double Rcb[9], tcb[3], tbc[3];
+    double fx, fy, cx, cy, bf;
+    int32_t n;                          /* features holding a map point, in feature order */
+    const double* Xw;                   /* n x 3 */
+    const double* obs;                  /* n x 3 */
+    const double* inv_sigma2;           /* mvInvLevelSigma2[octave] / uncertainty2 */
+    const uint8_t* stereo;
+    const uint8_t* close_point;         /* pMP->mTrackDepth < 10 */
+    OracleInertialLink link;            /* pFrame->mpImuPreintegrated: kf1 = 0, kf2 = 1 */
+    double huber_mono, huber_stereo;
+    int32_t rec_init;                   /* bRecInit */
+} OraclePoseInertialProblem;
+/* returns nInitialCorrespondences - nBad; H15 = the 15 x 15 Hessian of the new ConstraintPoseImu */
+int   pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P, double* Rwb_out, double* twb_out, double* vel_out,
+                                    double* bg_out, double* ba_out, uint8_t* outlier, double* H15_out, int* n_bad_out);
+
 #ifdef __cplusplus
 }
 #endif

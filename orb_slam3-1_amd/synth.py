@@ -421,3 +421,49 @@ def make_inertial_window(seed, n_opt=6, n_points=150, obs_per_point=4, dt=0.25, 
               huber_mono=float(np.float32(np.sqrt(5.991))), huber_stereo=float(np.float32(np.sqrt(7.815))), huber_inertial=float(np.sqrt(16.92)),
               lambda_init=1.0, max_iters=10)
     return pr, gt
+
+
+def make_pose_inertial_problem(seed, n=300, outlier_frac=0.1, stereo_frac=0.0, noise_px=0.5, dt=0.05, perturb=True):
+    """The per-frame inertial optimisation (Optimizer::PoseInertialOptimizationLastKeyFrame, reference src/Optimizer.cc:4491-4873):
+    the last key frame (fixed) and the current frame, linked by one pre-integrated measurement computed from the ground truth
+    (plus noise); n map points seen by the frame with some gross outliers.  Returns (problem dict, ground truth dict)."""
+    rs = np.random.RandomState(seed)
+    g = np.array([0.0, 0.0, -9.81])
+    R1 = _so3_exp(rs.normal(0, 0.2, 3)); p1 = rs.normal(0, 1.0, 3); v1 = np.array([0.8, 0.1, -0.05])
+    acc = rs.normal(0, 0.5, 3); omg = rs.normal(0, 0.3, 3)
+    R2 = R1 @ _so3_exp(omg * dt); p2 = p1 + v1 * dt + 0.5 * acc * dt * dt; v2 = v1 + acc * dt
+    bgk = rs.normal(0, 0.01, 3); bak = rs.normal(0, 0.05, 3)
+    Rcb = _so3_exp(np.array([0.01, -0.02, 0.015])) @ np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0.0]])
+    tcb = np.array([0.02, -0.01, 0.03]); tbc = -Rcb.T @ tcb
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    bf = 47.9 if stereo_frac > 0 else 0.0
+    sig_r, sig_v, sig_p = 1e-3, 5e-3, 2e-3
+    dR = R1.T @ R2 @ _so3_exp(rs.normal(0, sig_r * 0.3, 3))
+    dV = R1.T @ (v2 - v1 - g * dt) + rs.normal(0, sig_v * 0.3, 3)
+    dP = R1.T @ (p2 - p1 - v1 * dt - 0.5 * g * dt * dt) + rs.normal(0, sig_p * 0.3, 3)
+    link = dict(kf1=0, kf2=1, dR=dR.astype(np.float32), dV=dV.astype(np.float32), dP=dP.astype(np.float32),
+                JRg=(-dt * np.eye(3)).astype(np.float32), JVg=rs.normal(0, 0.01, (3, 3)).astype(np.float32), JVa=(-dt * dR).astype(np.float32),
+                JPg=rs.normal(0, 0.003, (3, 3)).astype(np.float32), JPa=(-0.5 * dt * dt * dR).astype(np.float32), dT=np.float32(dt),
+                bias0=np.concatenate([bak, bgk]).astype(np.float32),
+                info9=np.diag([1 / sig_r ** 2] * 3 + [1 / sig_v ** 2] * 3 + [1 / sig_p ** 2] * 3), info_gyro=np.eye(3) * 1e6 / dt,
+                info_acc=np.eye(3) * 1e4 / dt, robust=np.uint8(0))
+    Rcw = Rcb @ R2.T; tcw = Rcb @ (-R2.T @ p2) + tcb
+    Xc = np.stack([rs.uniform(-3, 3, n), rs.uniform(-2, 2, n), rs.uniform(2, 12, n)], 1)
+    Xw = (Rcw.T @ (Xc - tcw).T).T
+    octave = rs.randint(0, 5, n); sig = 1.2 ** octave
+    u = fx * Xc[:, 0] / Xc[:, 2] + cx + rs.normal(0, noise_px, n) * sig
+    v = fy * Xc[:, 1] / Xc[:, 2] + cy + rs.normal(0, noise_px, n) * sig
+    stereo = (rs.uniform(size=n) < stereo_frac).astype(np.uint8)
+    ur = np.where(stereo > 0, u - bf / Xc[:, 2] + rs.normal(0, noise_px, n) * sig, -1.0)
+    is_out = rs.uniform(size=n) < outlier_frac
+    u = u + is_out * rs.choice([-1, 1], n) * rs.uniform(15, 40, n)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    R2i, p2i, v2i = R2, p2, v2
+    if perturb:
+        R2i = R2 @ _so3_exp(rs.normal(0, 0.01, 3)); p2i = p2 + rs.normal(0, 0.02, 3); v2i = v2 + rs.normal(0, 0.05, 3)
+    pr = dict(Rwb=f32(np.stack([R1, R2i])), twb=f32(np.stack([p1, p2i])), vel=f32(np.stack([v1, v2i])), bg=f32(np.stack([bgk, bgk])), ba=f32(np.stack([bak, bak])),
+              Rcb=f32(Rcb), tcb=f32(tcb), tbc=f32(tbc), fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)),
+              bf=float(np.float32(bf)), Xw=f32(Xw), obs=np.stack([f32(u), f32(v), f32(ur)], 1), inv_sigma2=f32(1.0 / sig ** 2), stereo=stereo,
+              close_point=(Xc[:, 2] < 10).astype(np.uint8), link=link, huber_mono=float(np.float32(np.sqrt(5.991))), huber_stereo=float(np.float32(np.sqrt(7.815))),
+              rec_init=0)
+    return pr, dict(Rwb=R2, twb=p2, vel=v2, is_outlier=is_out)

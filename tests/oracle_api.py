@@ -516,3 +516,42 @@ def oracle_inertial_jacobian_check(orc, pr, link, h=1e-5):
     s = _inertial_struct(pr)
     orc.lib.inertial_oracle_jacobian_check.restype = C.c_double
     return orc.lib.inertial_oracle_jacobian_check(C.byref(s), int(link), C.c_double(h))
+
+
+class PoseInertialProblem(C.Structure):
+    _fields_ = [("Rwb", C.c_double * 18), ("twb", C.c_double * 6), ("vel", C.c_double * 6), ("bg", C.c_double * 6), ("ba", C.c_double * 6),
+                ("Rcb", C.c_double * 9), ("tcb", C.c_double * 3), ("tbc", C.c_double * 3),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p), ("close_point", C.c_void_p),
+                ("link", InertialLink), ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("rec_init", C.c_int32)]
+
+
+def fill_pose_inertial_struct(s, pr):
+    """shared by the oracle binding and the product binding (same field layout)"""
+    keep = {k: np.ascontiguousarray(pr[k], t) for k, t in (("Xw", np.float64), ("obs", np.float64), ("inv_sigma2", np.float64), ("stereo", np.uint8),
+                                                           ("close_point", np.uint8))}
+    for k, m in (("Rwb", 18), ("twb", 6), ("vel", 6), ("bg", 6), ("ba", 6), ("Rcb", 9), ("tcb", 3), ("tbc", 3)):
+        getattr(s, k)[:] = np.asarray(pr[k], np.float64).ravel().tolist()
+    s.fx, s.fy, s.cx, s.cy, s.bf = pr["fx"], pr["fy"], pr["cx"], pr["cy"], pr["bf"]
+    s.n = len(keep["Xw"])
+    for k in keep:
+        setattr(s, k, keep[k].ctypes.data)
+    d, L = pr["link"], s.link
+    L.kf1, L.kf2, L.dT, L.robust = int(d["kf1"]), int(d["kf2"]), float(d["dT"]), int(d["robust"])
+    for name in ("dR", "dV", "dP", "JRg", "JVg", "JVa", "JPg", "JPa", "bias0"):
+        getattr(L, name)[:] = np.asarray(d[name], np.float32).ravel().tolist()
+    for name in ("info9", "info_gyro", "info_acc"):
+        getattr(L, name)[:] = np.asarray(d[name], np.float64).ravel().tolist()
+    s.huber_mono, s.huber_stereo, s.rec_init = pr["huber_mono"], pr["huber_stereo"], int(pr["rec_init"])
+    s._keep = keep
+    return s
+
+
+def oracle_pose_inertial_optimize(orc, pr):
+    """Optimizer::PoseInertialOptimizationLastKeyFrame: dict(Rwb, twb, vel, bg, ba, outlier, H, n_bad, inliers)"""
+    s = fill_pose_inertial_struct(PoseInertialProblem(), pr)
+    n = s.n
+    Rwb = np.zeros((3, 3)); twb = np.zeros(3); vel = np.zeros(3); bg = np.zeros(3); ba = np.zeros(3)
+    out = np.zeros(max(n, 1), np.uint8); H = np.zeros((15, 15)); nb = C.c_int()
+    r = orc.lib.pose_inertial_oracle_optimize(C.byref(s), _p(Rwb), _p(twb), _p(vel), _p(bg), _p(ba), _p(out), _p(H), C.byref(nb))
+    return dict(Rwb=Rwb, twb=twb, vel=vel, bg=bg, ba=ba, outlier=out[:n], H=H, n_bad=nb.value, inliers=r)
