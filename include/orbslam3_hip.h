@@ -517,6 +517,29 @@ void liba_destroy(liba_solver* s);
 int  liba_solve(liba_solver* s, const LibaProblem* problem, double* Rwb_out, double* twb_out, double* vel_out, double* bg_out,
                 double* ba_out, double* points_out, double* chi2_per_edge, uint8_t* depth_positive, LbaStats* stats);
 
+/* int Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*, bool bRecInit) (src/Optimizer.cc:4491-4873): the per-frame optimisation
+ * of the inertial tracker, for a batch of frames (one per client stream) in one launch.  Index [0] of the state arrays is the last key
+ * frame (fixed), [1] the current frame.  Edges = the features holding a map point, in feature order; close_point = mTrackDepth < 10.
+ * Outputs per frame: the optimised body pose / velocity / biases, mvbOutlier (frame b's flags start at the sum of the earlier frames'
+ * n), the 15 x 15 Hessian of the new ConstraintPoseImu (:4837-4870), nInitialCorrespondences - nBad (the return value) and nBad.
+ * One camera / camera-body calibration per batch. */
+typedef struct LibaPoseProblem {
+    double Rwb[18], twb[6], vel[6], bg[6], ba[6];
+    double Rcb[9], tcb[3], tbc[3];
+    double fx, fy, cx, cy, bf;
+    int32_t n;
+    const double* Xw;               /* [n][3] pMP->GetWorldPos() */
+    const double* obs;              /* [n][3] */
+    const double* inv_sigma2;       /* mvInvLevelSigma2[octave] / uncertainty2(obs) */
+    const uint8_t* stereo;
+    const uint8_t* close_point;
+    LibaLink link;                  /* pFrame->mpImuPreintegrated, kf1 = 0, kf2 = 1; robust unused */
+    double huber_mono, huber_stereo;
+    int32_t rec_init;
+} LibaPoseProblem;
+int  liba_pose_optimize_batch(liba_solver* s, const LibaPoseProblem* problems, int batch, double* Rwb_out, double* twb_out, double* vel_out,
+                              double* bg_out, double* ba_out, uint8_t* outlier_out, double* H15_out, int32_t* inliers_out, int32_t* n_bad_out);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Edge-SLAM wire format (the fork's client <-> server packets).  Replaces the two constructors
  * of class SlamPktVI, reference include/Socket/slampkt_vi.h:

@@ -850,6 +850,84 @@ inline void LocalInertialBAHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& 
     pMap->IncreaseChangeIndex();
 }
 
+// int Optimizer::PoseInertialOptimizationLastKeyFrame(Frame* pFrame, bool bRecInit) (src/Optimizer.cc:4491-4873), conventional
+// cameras (Nleft == -1): one LibaPoseProblem edge per feature holding a map point, in feature order.
+inline int PoseInertialOptimizationLastKeyFrameHIP(Frame* pFrame, bool bRecInit = false)
+{
+    if (pFrame->Nleft != -1) return Optimizer::PoseInertialOptimizationLastKeyFrame(pFrame, bRecInit);     // stereo-fisheye rig: not on this path
+    const int N = pFrame->N;
+    std::vector<int> feat;
+    std::vector<double> Xw, obs, w;
+    std::vector<uint8_t> stereo, closePt;
+    {
+        std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);                   // :4545
+        for (int i = 0; i < N; i++) {
+            MapPoint* pMP = pFrame->mvpMapPoints[i];
+            if (!pMP) continue;
+            const cv::KeyPoint& kpUn = pFrame->mvKeysUn[i];
+            const float ur = pFrame->mvuRight[i];
+            Eigen::Matrix<double, 2, 1> o2; o2 << kpUn.pt.x, kpUn.pt.y;
+            const float unc2 = pFrame->mpCamera->uncertainty2(o2);
+            const float invSigma2 = pFrame->mvInvLevelSigma2[kpUn.octave] / unc2;
+            const Eigen::Vector3d X = pMP->GetWorldPos().cast<double>();
+            pFrame->mvbOutlier[i] = false;
+            feat.push_back(i);
+            Xw.push_back(X.x()); Xw.push_back(X.y()); Xw.push_back(X.z());
+            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(ur >= 0 ? (double)ur : -1.0);
+            w.push_back((double)invSigma2); stereo.push_back(ur >= 0); closePt.push_back(pMP->mTrackDepth < 10.f);
+        }
+    }
+    KeyFrame* pKF = pFrame->mpLastKeyFrame;
+    IMU::Preintegrated* pInt = pFrame->mpImuPreintegrated;
+    LibaPoseProblem pr;
+    std::memset(&pr, 0, sizeof(pr));
+    auto putState = [&](int i, const Eigen::Matrix3f& R, const Eigen::Vector3f& t, const Eigen::Vector3f& v, const IMU::Bias& b) {
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pr.Rwb[9 * i + 3 * r + c] = R(r, c); pr.twb[3 * i + r] = t(r); pr.vel[3 * i + r] = v(r); }
+        pr.bg[3 * i] = b.bwx; pr.bg[3 * i + 1] = b.bwy; pr.bg[3 * i + 2] = b.bwz; pr.ba[3 * i] = b.bax; pr.ba[3 * i + 1] = b.bay; pr.ba[3 * i + 2] = b.baz;
+    };
+    putState(0, pKF->GetImuRotation(), pKF->GetImuPosition(), pKF->GetVelocity(), pKF->GetImuBias());
+    putState(1, pFrame->GetImuRotation(), pFrame->GetImuPosition(), pFrame->GetVelocity(), pFrame->mImuBias);
+    const Eigen::Matrix3d Rcb = pFrame->mImuCalib.mTcb.rotationMatrix().cast<double>();
+    const Eigen::Vector3d tcb = pFrame->mImuCalib.mTcb.translation().cast<double>(), tbc = pFrame->mImuCalib.mTbc.translation().cast<double>();
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pr.Rcb[3 * r + c] = Rcb(r, c); pr.tcb[r] = tcb(r); pr.tbc[r] = tbc(r); }
+    pr.fx = pFrame->fx; pr.fy = pFrame->fy; pr.cx = pFrame->cx; pr.cy = pFrame->cy; pr.bf = pFrame->mbf;
+    pr.n = (int)feat.size(); pr.Xw = Xw.data(); pr.obs = obs.data(); pr.inv_sigma2 = w.data(); pr.stereo = stereo.data(); pr.close_point = closePt.data();
+    LibaLink& L = pr.link;
+    L.kf1 = 0; L.kf2 = 1;
+    auto put3x3 = [](float* dst, const Eigen::Matrix3f& M) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) dst[3 * r + c] = M(r, c); };
+    put3x3(L.dR, pInt->dR); put3x3(L.JRg, pInt->JRg); put3x3(L.JVg, pInt->JVg); put3x3(L.JVa, pInt->JVa); put3x3(L.JPg, pInt->JPg); put3x3(L.JPa, pInt->JPa);
+    for (int r = 0; r < 3; r++) { L.dV[r] = pInt->dV(r); L.dP[r] = pInt->dP(r); }
+    L.dT = pInt->dT;
+    const IMU::Bias b0 = pInt->GetOriginalBias();
+    L.bias0[0] = b0.bax; L.bias0[1] = b0.bay; L.bias0[2] = b0.baz; L.bias0[3] = b0.bwx; L.bias0[4] = b0.bwy; L.bias0[5] = b0.bwz;
+    Eigen::Matrix<double, 9, 9> Info = pInt->C.block<9, 9>(0, 0).cast<double>().inverse();       // EdgeInertial ctor, G2oTypes.cc:510-518
+    Info = (Info + Info.transpose()) / 2;
+    Eigen::SelfAdjointEigenSolver<Eigen::Matrix<double, 9, 9> > es(Info);
+    Eigen::Matrix<double, 9, 1> eigs = es.eigenvalues();
+    for (int k = 0; k < 9; k++) if (eigs[k] < 1e-12) eigs[k] = 0;
+    Info = es.eigenvectors() * eigs.asDiagonal() * es.eigenvectors().transpose();
+    const Eigen::Matrix3d InfoG = pInt->C.block<3, 3>(9, 9).cast<double>().inverse(), InfoA = pInt->C.block<3, 3>(12, 12).cast<double>().inverse();
+    for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) L.info9[9 * r + c] = Info(r, c);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { L.info_gyro[3 * r + c] = InfoG(r, c); L.info_acc[3 * r + c] = InfoA(r, c); }
+    const float thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815);
+    pr.huber_mono = thHuberMono; pr.huber_stereo = thHuberStereo; pr.rec_init = bRecInit;
+    static thread_local liba_solver* solver = nullptr;
+    if (!solver) orbslam3_hip::check(liba_create(0, &solver));
+    double R[9], t[3], v[3], bg[3], ba[3], H[225];
+    std::vector<uint8_t> outlier(feat.size() + 1);
+    int32_t inliers = 0, nBad = 0;
+    orbslam3_hip::check(liba_pose_optimize_batch(solver, &pr, 1, R, t, v, bg, ba, outlier.data(), H, &inliers, &nBad));
+    for (size_t k = 0; k < feat.size(); k++) pFrame->mvbOutlier[feat[k]] = outlier[k] != 0;
+    Eigen::Matrix3d Rwb; Eigen::Vector3d twb(t[0], t[1], t[2]), vwb(v[0], v[1], v[2]), vbg(bg[0], bg[1], bg[2]), vba(ba[0], ba[1], ba[2]);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rwb(r, c) = R[3 * r + c];
+    pFrame->SetImuPoseVelocity(Rwb.cast<float>(), twb.cast<float>(), vwb.cast<float>());         // :4831-4834
+    pFrame->mImuBias = IMU::Bias(ba[0], ba[1], ba[2], bg[0], bg[1], bg[2]);
+    Eigen::Matrix<double, 15, 15> Hm;
+    for (int r = 0; r < 15; r++) for (int c = 0; c < 15; c++) Hm(r, c) = H[15 * r + c];
+    pFrame->mpcpi = new ConstraintPoseImu(Rwb, twb, vwb, vbg, vba, Hm);                           // :4870
+    return inliers;
+}
+
 // void Frame::ComputeBoW() (src/Frame.cc:825-832): mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) on the device.
 // The tree is flattened once per vocabulary (TemplatedVocabulary::m_nodes is protected: reached through a derived type).
 class VocabularyHIP {

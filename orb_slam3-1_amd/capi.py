@@ -955,3 +955,52 @@ class InertialSolver:
         stats = dict(iterations=st.iterations, trials=st.trials, stop_reason=st.stop_reason, lambda_=st.lambda_, chi2_initial=st.chi2_initial,
                      chi2_final=st.chi2_final)
         return dict(Rwb=Rwb, twb=twb, vel=vel, bg=bg, ba=ba, points=pts[:m], chi2=chi2[:ne], depth_positive=dpos[:ne], stats=stats)
+
+
+class _LibaPoseProblem(C.Structure):
+    _fields_ = [("Rwb", C.c_double * 18), ("twb", C.c_double * 6), ("vel", C.c_double * 6), ("bg", C.c_double * 6), ("ba", C.c_double * 6),
+                ("Rcb", C.c_double * 9), ("tcb", C.c_double * 3), ("tbc", C.c_double * 3),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p), ("close_point", C.c_void_p),
+                ("link", _LibaLink), ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("rec_init", C.c_int32)]
+
+
+def _fill_liba_pose(s, pr, keep):
+    arrs = {k: np.ascontiguousarray(pr[k], t) for k, t in (("Xw", np.float64), ("obs", np.float64), ("inv_sigma2", np.float64), ("stereo", np.uint8),
+                                                           ("close_point", np.uint8))}
+    keep.append(arrs)
+    for k, m in (("Rwb", 18), ("twb", 6), ("vel", 6), ("bg", 6), ("ba", 6), ("Rcb", 9), ("tcb", 3), ("tbc", 3)):
+        getattr(s, k)[:] = np.asarray(pr[k], np.float64).ravel().tolist()
+    s.fx, s.fy, s.cx, s.cy, s.bf = pr["fx"], pr["fy"], pr["cx"], pr["cy"], pr["bf"]
+    s.n = len(arrs["Xw"])
+    for k in arrs:
+        setattr(s, k, arrs[k].ctypes.data)
+    d, L = pr["link"], s.link
+    L.kf1, L.kf2, L.dT, L.robust = int(d["kf1"]), int(d["kf2"]), float(d["dT"]), int(d["robust"])
+    for name in ("dR", "dV", "dP", "JRg", "JVg", "JVa", "JPg", "JPa", "bias0"):
+        getattr(L, name)[:] = np.asarray(d[name], np.float32).ravel().tolist()
+    for name in ("info9", "info_gyro", "info_acc"):
+        getattr(L, name)[:] = np.asarray(d[name], np.float64).ravel().tolist()
+    s.huber_mono, s.huber_stereo, s.rec_init = pr["huber_mono"], pr["huber_stereo"], int(pr["rec_init"])
+
+
+def _pose_inertial_batch(self, problems):
+    """Optimizer::PoseInertialOptimizationLastKeyFrame for a batch of frames: list of dict(Rwb, twb, vel, bg, ba, outlier, H, n_bad, inliers)"""
+    B = len(problems)
+    arr = (_LibaPoseProblem * B)()
+    keep = []
+    for s, pr in zip(arr, problems):
+        _fill_liba_pose(s, pr, keep)
+    tot = sum(int(s.n) for s in arr)
+    Rwb = np.zeros((B, 3, 3)); twb = np.zeros((B, 3)); vel = np.zeros((B, 3)); bg = np.zeros((B, 3)); ba = np.zeros((B, 3))
+    out = np.zeros(max(tot, 1), np.uint8); H = np.zeros((B, 15, 15)); inl = np.zeros(B, np.int32); nb = np.zeros(B, np.int32)
+    _check(lib.liba_pose_optimize_batch(self._h, arr, B, _p(Rwb), _p(twb), _p(vel), _p(bg), _p(ba), _p(out), _p(H), _p(inl), _p(nb)))
+    res, o = [], 0
+    for b in range(B):
+        n = int(arr[b].n)
+        res.append(dict(Rwb=Rwb[b], twb=twb[b], vel=vel[b], bg=bg[b], ba=ba[b], outlier=out[o:o + n].copy(), H=H[b], n_bad=int(nb[b]), inliers=int(inl[b])))
+        o += n
+    return res
+
+
+InertialSolver.pose_optimize_batch = _pose_inertial_batch

@@ -436,7 +436,7 @@ def make_pose_inertial_problem(seed, n=300, outlier_frac=0.1, stereo_frac=0.0, n
     Rcb = _so3_exp(np.array([0.01, -0.02, 0.015])) @ np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0.0]])
     tcb = np.array([0.02, -0.01, 0.03]); tbc = -Rcb.T @ tcb
     fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
-    bf = 47.9 if stereo_frac > 0 else 0.0
+    bf = 47.9                           # (only stereo observations use it; one camera per batch)
     sig_r, sig_v, sig_p = 1e-3, 5e-3, 2e-3
     dR = R1.T @ R2 @ _so3_exp(rs.normal(0, sig_r * 0.3, 3))
     dV = R1.T @ (v2 - v1 - g * dt) + rs.normal(0, sig_v * 0.3, 3)
