@@ -478,6 +478,24 @@ def main():
                                   "chi2_initial": ri["stats"]["chi2_initial"], "chi2_final": ri["stats"]["chi2_final"]}
             isol.close()
 
+        # ---- per-frame inertial optimisation leg: Optimizer::PoseInertialOptimizationLastKeyFrame for a batch of frames (one per stream) ----
+        if not args.no_lba:
+            pi_ws = [synth.make_pose_inertial_problem(100 + i, n=300, outlier_frac=0.1)[0] for i in range(16)] * (B // 16)
+            isol2 = pkg.InertialSolver(device=local_rank)
+            isol2.pose_optimize_batch(pi_ws)
+            t0 = time.perf_counter()
+            rpi = isol2.pose_optimize_batch(pi_ws)
+            dtpi = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            isol2.pose_optimize_batch(pi_ws[:1])
+            dtp1 = time.perf_counter() - t0
+            out["pose_inertial"] = {"metric": "PoseInertialOptimizationLastKeyFrame frames/s", "value": len(pi_ws) / dtpi, "unit": "frames/s", "dtype": "f64",
+                                    "ms_per_batch": 1e3 * dtpi, "single_frame_call_ms": 1e3 * dtp1,
+                                    "workload": "%d frames x 300 mono edges + inertial link, 10%% gross outliers, 4 rounds x 10 Gauss-Newton iterations; one C call = "
+                                                "upload + one launch (a workgroup per frame) + download (incl. the Python-side packing of the problems)" % len(pi_ws),
+                                    "inliers_per_frame": float(np.mean([r_["inliers"] for r_ in rpi]))}
+            isol2.close()
+
         # ---- CPU baseline leg (N=1 only, rank 0) ----
         if not args.no_cpu and world == 1:
             o, cb = cpu_baseline(synth, host_imgs, match_sets)
@@ -537,6 +555,15 @@ def main():
                 dtc = time.perf_counter() - t0
                 out["pose"]["cpu_baseline"] = {"value": 64 / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "64 frames"}
                 out["pose"]["speedup_vs_cpu_1core"] = out["pose"]["value"] / (64 / dtc)
+            if "pose_inertial" in out:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from oracle_api import oracle_pose_inertial_optimize
+                t0 = time.perf_counter()
+                for wp in pi_ws[:32]:
+                    oracle_pose_inertial_optimize(o, wp)
+                dtc = time.perf_counter() - t0
+                out["pose_inertial"]["cpu_baseline"] = {"value": 32 / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "32 frames (incl. the Python-side packing)"}
+                out["pose_inertial"]["speedup_vs_cpu_1core"] = out["pose_inertial"]["value"] / (32 / dtc)
             if "inertial_ba" in out:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 from oracle_api import oracle_inertial_solve
