@@ -16,6 +16,9 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_wri
 python tools/collect_pmc.py $OUT/pmc_fetch $OUT/pmc_write 256 > $OUT/pmc_traffic.log && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 cp $(ls $OUT/prof/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 timeout -k 10 200 python bench.py --streams 4 --no-cpu --no-lba > $OUT/bench_streams4.json 2> $OUT/bench_streams4.err || echo "streams-4 bench failed"
+# per-kernel times of the two BA solvers alone (profiles/<tag>_lba_kernel_stats.csv, <tag>_inertial_ba_kernel_stats.csv)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lbaprof -- python tools/lba_prof.py 5 > $OUT/lbaprof.log 2>&1 || echo "lba profile failed"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/libaprof -- python tools/liba_prof.py 5 > $OUT/libaprof.log 2>&1 || echo "inertial ba profile failed"
 python - <<PY
 import json
 d = json.load(open("$OUT/bench.json"))
