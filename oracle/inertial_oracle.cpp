@@ -627,11 +627,30 @@ extern "C" int pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P,
         for (int r = 0; r < 3; r++)
             for (int c = 0; c < 6; c++) Jj[6 * r + c] = prb[3 * r] * D[c] + prb[3 * r + 1] * D[6 + c] + prb[3 * r + 2] * D[12 + c];
     };
-    const float chi2Mono[4] = {12, 7.5, 5.991, 5.991}, chi2Stereo[4] = {15.6, 9.8, 7.815, 7.815};
+    const bool LF = P->last_frame != 0;                     /* PoseInertialOptimizationLastFrame (:4875-5285): the previous frame is free too */
+    const int N = LF ? 30 : 15, oc = LF ? 15 : 0;            /* unknowns; offset of the current frame's block */
+    KF& K0 = pr.kf[0];
+    const float chi2MonoKF[4] = {12, 7.5, 5.991, 5.991}, chi2MonoF[4] = {5.991, 5.991, 5.991, 5.991}, chi2Stereo[4] = {15.6, 9.8, 7.815, 7.815};
+    const float* chi2Mono = LF ? chi2MonoF : chi2MonoKF;
+    /* EdgePriorPoseImu (G2oTypes.cc:720-760): error (er, et, ev, ebg, eba) of the previous frame's states against the prior, 15 x 15 Jacobian */
+    auto prior_terms = [&](double* e15, double* J15) {
+        double Rt[9], Rr[9];
+        mat_tr(P->prior_Rwb, Rt);
+        mat_mul(Rt, K0.Rwb, Rr);
+        log_so3(Rr, e15);
+        double dt3[3] = {K0.twb[0] - P->prior_twb[0], K0.twb[1] - P->prior_twb[1], K0.twb[2] - P->prior_twb[2]};
+        mat_vec(Rt, dt3, e15 + 3);
+        for (int q = 0; q < 3; q++) { e15[6 + q] = K0.v[q] - P->prior_vel[q]; e15[9 + q] = K0.bg[q] - P->prior_bg[q]; e15[12 + q] = K0.ba[q] - P->prior_ba[q]; }
+        std::memset(J15, 0, 225 * sizeof(double));
+        double iJ[9];
+        inv_right_jac(e15, iJ);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { J15[15 * r + c] = iJ[3 * r + c]; J15[15 * (3 + r) + 3 + c] = Rr[3 * r + c]; }
+        for (int q = 6; q < 15; q++) J15[15 * q + q] = 1.0;
+    };
     int nBad = 0, nInliers = 0;
     for (int it = 0; it < 4; it++) {
         for (int k = 0; k < 10; k++) {                       /* optimize(its[it]): Gauss-Newton */
-            double H[225], b[15];
+            double H[900], b[30];
             std::memset(H, 0, sizeof(H)); std::memset(b, 0, sizeof(b));
             for (int i = 0; i < n; i++) {
                 if (level[i]) continue;
@@ -644,51 +663,90 @@ extern "C" int pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P,
                 edge_jac(i, Jj);
                 const double* r = &err[3 * (size_t)i];
                 for (int a = 0; a < 6; a++) {
-                    for (int c2 = 0; c2 < 6; c2++) { double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * Jj[6 * q + c2]; H[15 * a + c2] += w * s2; }
+                    for (int c2 = 0; c2 < 6; c2++) { double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * Jj[6 * q + c2]; H[N * (oc + a) + oc + c2] += w * s2; }
                     double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * r[q];
-                    b[a] -= w * s2;
+                    b[oc + a] -= w * s2;
                 }
             }
             double e9[9], J[6][54];
             pr.inertial_error(L, e9);
             pr.inertial_jacobians(L, J);
-            double J9[81];                                   /* 9 x 9: [J_P2 | J_V2] */
-            for (int r = 0; r < 9; r++) { for (int c = 0; c < 6; c++) J9[9 * r + c] = J[4][6 * r + c]; for (int c = 0; c < 3; c++) J9[9 * r + 6 + c] = J[5][3 * r + c]; }
-            for (int a = 0; a < 9; a++) {
-                for (int c = 0; c < 9; c++) {
-                    double s2 = 0;
-                    for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * J9[9 * q + c]; s2 += J9[9 * r + a] * t; }
-                    H[15 * a + c] += s2;
+            {   /* the link: all six vertices when the previous frame is free, (pose, velocity) of the current frame otherwise */
+                const int loc[6] = {0, 6, 9, 12, 15, 21}, dim[6] = {6, 3, 3, 3, 6, 3};
+                const int goff[6] = {LF ? 0 : -1, LF ? 6 : -1, LF ? 9 : -1, LF ? 12 : -1, oc, oc + 6};
+                (void)loc;
+                double Oe[9];
+                for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * e9[q]; Oe[r] = t; }
+                for (int va = 0; va < 6; va++) {
+                    if (goff[va] < 0) continue;
+                    for (int a = 0; a < dim[va]; a++) {
+                        double s2 = 0;
+                        for (int r = 0; r < 9; r++) s2 += J[va][r * dim[va] + a] * Oe[r];
+                        b[goff[va] + a] -= s2;
+                        for (int vb = 0; vb < 6; vb++) {
+                            if (goff[vb] < 0) continue;
+                            for (int c = 0; c < dim[vb]; c++) {
+                                double h = 0;
+                                for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * J[vb][q * dim[vb] + c]; h += J[va][r * dim[va] + a] * t; }
+                                H[N * (goff[va] + a) + goff[vb] + c] += h;
+                            }
+                        }
+                    }
                 }
-                double s2 = 0;
-                for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * e9[q]; s2 += J9[9 * r + a] * t; }
-                b[a] -= s2;
             }
-            for (int which = 0; which < 2; which++) {        /* random walks towards the key frame's biases */
+            for (int which = 0; which < 2; which++) {        /* random walks: e = b_cur - b_prev, J_prev = -I, J_cur = +I */
                 const double* Om3 = which ? L.info_acc : L.info_gyro;
-                const int o = which ? 12 : 9;
+                const int o2 = oc + (which ? 12 : 9), o1 = LF ? (which ? 12 : 9) : -1;
                 double d[3], Od[3];
-                for (int q = 0; q < 3; q++) d[q] = which ? F.ba[q] - pr.kf[0].ba[q] : F.bg[q] - pr.kf[0].bg[q];
+                for (int q = 0; q < 3; q++) d[q] = which ? F.ba[q] - K0.ba[q] : F.bg[q] - K0.bg[q];
                 mat_vec(Om3, d, Od);
-                for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) H[15 * (o + a) + o + c] += Om3[3 * a + c]; b[o + a] -= Od[a]; }
+                for (int a = 0; a < 3; a++) {
+                    for (int c = 0; c < 3; c++) {
+                        H[N * (o2 + a) + o2 + c] += Om3[3 * a + c];
+                        if (o1 >= 0) { H[N * (o1 + a) + o1 + c] += Om3[3 * a + c]; H[N * (o1 + a) + o2 + c] -= Om3[3 * a + c]; H[N * (o2 + a) + o1 + c] -= Om3[3 * a + c]; }
+                    }
+                    b[o2 + a] -= Od[a];
+                    if (o1 >= 0) b[o1 + a] += Od[a];
+                }
+            }
+            if (LF) {                                        /* the prior on the previous frame, Huber delta 5 (:5084-5090) */
+                double e15[15], J15[225], Oe[15];
+                prior_terms(e15, J15);
+                double c = 0;
+                for (int r = 0; r < 15; r++) { double t = 0; for (int q = 0; q < 15; q++) t += P->prior_H[15 * r + q] * e15[q]; Oe[r] = t; c += e15[r] * t; }
+                const double rho1 = c > 25.0 ? 5.0 / std::sqrt(c) : 1.0;
+                for (int a = 0; a < 15; a++) {
+                    double s2 = 0;
+                    for (int r = 0; r < 15; r++) s2 += J15[15 * r + a] * Oe[r];
+                    b[a] -= rho1 * s2;
+                    for (int c2 = 0; c2 < 15; c2++) {
+                        double h = 0;
+                        for (int r = 0; r < 15; r++) { double t = 0; for (int q = 0; q < 15; q++) t += P->prior_H[15 * r + q] * J15[15 * q + c2]; h += J15[15 * r + a] * t; }
+                        H[N * a + c2] += rho1 * h;
+                    }
+                }
             }
             /* dense Cholesky solve H x = b */
-            double Lm[225], x[15];
-            std::memcpy(Lm, H, sizeof(H));
+            double Lm[900], x[30];
+            std::memcpy(Lm, H, sizeof(double) * N * N);
             bool ok = true;
-            for (int j = 0; j < 15 && ok; j++) {
-                double d = Lm[15 * j + j];
-                for (int q = 0; q < j; q++) d -= Lm[15 * j + q] * Lm[15 * j + q];
+            for (int j = 0; j < N && ok; j++) {
+                double d = Lm[N * j + j];
+                for (int q = 0; q < j; q++) d -= Lm[N * j + q] * Lm[N * j + q];
                 if (!(d > 0.0) || !std::isfinite(d)) { ok = false; break; }
                 const double ljj = std::sqrt(d);
-                Lm[15 * j + j] = ljj;
-                for (int i = j + 1; i < 15; i++) { double s2 = Lm[15 * i + j]; for (int q = 0; q < j; q++) s2 -= Lm[15 * i + q] * Lm[15 * j + q]; Lm[15 * i + j] = s2 / ljj; }
+                Lm[N * j + j] = ljj;
+                for (int i = j + 1; i < N; i++) { double s2 = Lm[N * i + j]; for (int q = 0; q < j; q++) s2 -= Lm[N * i + q] * Lm[N * j + q]; Lm[N * i + j] = s2 / ljj; }
             }
             if (!ok) break;
-            for (int i = 0; i < 15; i++) { double s2 = b[i]; for (int q = 0; q < i; q++) s2 -= Lm[15 * i + q] * x[q]; x[i] = s2 / Lm[15 * i + i]; }
-            for (int i = 14; i >= 0; i--) { double s2 = x[i]; for (int q = i + 1; q < 15; q++) s2 -= Lm[15 * q + i] * x[q]; x[i] = s2 / Lm[15 * i + i]; }
-            pr.update_pose(F, x);
-            for (int q = 0; q < 3; q++) { F.v[q] += x[6 + q]; F.bg[q] += x[9 + q]; F.ba[q] += x[12 + q]; }
+            for (int i = 0; i < N; i++) { double s2 = b[i]; for (int q = 0; q < i; q++) s2 -= Lm[N * i + q] * x[q]; x[i] = s2 / Lm[N * i + i]; }
+            for (int i = N - 1; i >= 0; i--) { double s2 = x[i]; for (int q = i + 1; q < N; q++) s2 -= Lm[N * q + i] * x[q]; x[i] = s2 / Lm[N * i + i]; }
+            pr.update_pose(F, x + oc);
+            for (int q = 0; q < 3; q++) { F.v[q] += x[oc + 6 + q]; F.bg[q] += x[oc + 9 + q]; F.ba[q] += x[oc + 12 + q]; }
+            if (LF) {
+                pr.update_pose(K0, x);
+                for (int q = 0; q < 3; q++) { K0.v[q] += x[6 + q]; K0.bg[q] += x[9 + q]; K0.ba[q] += x[12 + q]; }
+            }
         }
         nBad = 0; nInliers = 0;
         const float chi2close = 1.5 * chi2Mono[it];
@@ -709,7 +767,7 @@ extern "C" int pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P,
                 if (bad) nBad++; else nInliers++;
             }
         if (it == 2) robust = false;
-        if (n + 3 < 10) break;                               /* optimizer.edges().size() < 10 (:4794) */
+        if (n + (LF ? 4 : 3) < 10) break;                    /* optimizer.edges().size() < 10 (:4794, :5200) */
     }
     if (nInliers < 30 && !P->rec_init) {                     /* recover not too bad points (:4802-4828) */
         nBad = 0;
@@ -719,30 +777,55 @@ extern "C" int pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P,
         }
     }
     /* Hessian of the new prior (:4837-4870): inertial edge w.r.t. (pose, velocity), the random-walk informations, the inliers' 6 x 6 */
-    double Hout[225];
+    double Hout[900];
     std::memset(Hout, 0, sizeof(Hout));
     {
-        double J[6][54], J9[81];
+        double J[6][54];
         pr.inertial_jacobians(L, J);
-        for (int r = 0; r < 9; r++) { for (int c = 0; c < 6; c++) J9[9 * r + c] = J[4][6 * r + c]; for (int c = 0; c < 3; c++) J9[9 * r + 6 + c] = J[5][3 * r + c]; }
-        for (int a = 0; a < 9; a++)
-            for (int c = 0; c < 9; c++) {
-                double s2 = 0;
-                for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * J9[9 * q + c]; s2 += J9[9 * r + a] * t; }
-                Hout[15 * a + c] += s2;
-            }
-        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) { Hout[15 * (9 + a) + 9 + c] += L.info_gyro[3 * a + c]; Hout[15 * (12 + a) + 12 + c] += L.info_acc[3 * a + c]; }
+        const int dim[6] = {6, 3, 3, 3, 6, 3};
+        const int goff[6] = {LF ? 0 : -1, LF ? 6 : -1, LF ? 9 : -1, LF ? 12 : -1, oc, oc + 6};      /* ei->GetHessian() / GetHessian2() */
+        for (int va = 0; va < 6; va++) {
+            if (goff[va] < 0) continue;
+            for (int a = 0; a < dim[va]; a++)
+                for (int vb = 0; vb < 6; vb++) {
+                    if (goff[vb] < 0) continue;
+                    for (int c = 0; c < dim[vb]; c++) {
+                        double h = 0;
+                        for (int r = 0; r < 9; r++) { double t = 0; for (int q = 0; q < 9; q++) t += L.info9[9 * r + q] * J[vb][q * dim[vb] + c]; h += J[va][r * dim[va] + a] * t; }
+                        Hout[N * (goff[va] + a) + goff[vb] + c] += h;
+                    }
+                }
+        }
+        for (int which = 0; which < 2; which++) {
+            const double* Om3 = which ? L.info_acc : L.info_gyro;
+            const int o2 = oc + (which ? 12 : 9), o1 = LF ? (which ? 12 : 9) : -1;
+            for (int a = 0; a < 3; a++)
+                for (int c = 0; c < 3; c++) {
+                    Hout[N * (o2 + a) + o2 + c] += Om3[3 * a + c];
+                    if (o1 >= 0) { Hout[N * (o1 + a) + o1 + c] += Om3[3 * a + c]; Hout[N * (o1 + a) + o2 + c] -= Om3[3 * a + c]; Hout[N * (o2 + a) + o1 + c] -= Om3[3 * a + c]; }
+                }
+        }
+        if (LF) {                                            /* ep->GetHessian(): J^T information J, no robust weight */
+            double e15[15], J15[225];
+            prior_terms(e15, J15);
+            for (int a = 0; a < 15; a++)
+                for (int c2 = 0; c2 < 15; c2++) {
+                    double h = 0;
+                    for (int r = 0; r < 15; r++) { double t = 0; for (int q = 0; q < 15; q++) t += P->prior_H[15 * r + q] * J15[15 * q + c2]; h += J15[15 * r + a] * t; }
+                    Hout[N * a + c2] += h;
+                }
+        }
         for (int i = 0; i < n; i++) {
             if (outlier[i]) continue;
             const int ne = P->stereo[i] ? 3 : 2;
             double Jj[18];
             edge_jac(i, Jj);
             for (int a = 0; a < 6; a++)
-                for (int c = 0; c < 6; c++) { double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * Jj[6 * q + c]; Hout[15 * a + c] += P->inv_sigma2[i] * s2; }
+                for (int c = 0; c < 6; c++) { double s2 = 0; for (int q = 0; q < ne; q++) s2 += Jj[6 * q + a] * Jj[6 * q + c]; Hout[N * (oc + a) + oc + c] += P->inv_sigma2[i] * s2; }
         }
     }
     std::memcpy(Rwb_out, F.Rwb, 72); std::memcpy(twb_out, F.twb, 24); std::memcpy(vel_out, F.v, 24); std::memcpy(bg_out, F.bg, 24); std::memcpy(ba_out, F.ba, 24);
-    if (H15_out) std::memcpy(H15_out, Hout, sizeof(Hout));
+    if (H15_out) std::memcpy(H15_out, Hout, sizeof(double) * N * N);     /* 15 x 15, or 30 x 30 (before Optimizer::Marginalize) for the last-frame variant */
     if (n_bad_out) *n_bad_out = nBad;
     return n - nBad;
 }

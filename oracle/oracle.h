@@ -295,6 +295,9 @@ typedef struct OraclePoseInertialProblem {
     OracleInertialLink link;            /* pFrame->mpImuPreintegrated: kf1 = 0, kf2 = 1 */
     double huber_mono, huber_stereo;
     int32_t rec_init;                   /* bRecInit */
+    /* PoseInertialOptimizationLastFrame (:4875-5285): [0] is the PREVIOUS FRAME and is optimised too, tied to pFp->mpcpi */
+    int32_t last_frame;
+    double prior_Rwb[9], prior_twb[3], prior_vel[3], prior_bg[3], prior_ba[3], prior_H[225];
 } OraclePoseInertialProblem;
 /* returns nInitialCorrespondences - nBad; H15 = the 15 x 15 Hessian of the new ConstraintPoseImu */
 int   pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P, double* Rwb_out, double* twb_out, double* vel_out,

@@ -423,7 +423,7 @@ def make_inertial_window(seed, n_opt=6, n_points=150, obs_per_point=4, dt=0.25, 
     return pr, gt
 
 
-def make_pose_inertial_problem(seed, n=300, outlier_frac=0.1, stereo_frac=0.0, noise_px=0.5, dt=0.05, perturb=True):
+def make_pose_inertial_problem(seed, n=300, outlier_frac=0.1, stereo_frac=0.0, noise_px=0.5, dt=0.05, perturb=True, last_frame=False):
     """The per-frame inertial optimisation (Optimizer::PoseInertialOptimizationLastKeyFrame, reference src/Optimizer.cc:4491-4873):
     the last key frame (fixed) and the current frame, linked by one pre-integrated measurement computed from the ground truth
     (plus noise); n map points seen by the frame with some gross outliers.  Returns (problem dict, ground truth dict)."""
@@ -466,4 +466,11 @@ def make_pose_inertial_problem(seed, n=300, outlier_frac=0.1, stereo_frac=0.0, n
               bf=float(np.float32(bf)), Xw=f32(Xw), obs=np.stack([f32(u), f32(v), f32(ur)], 1), inv_sigma2=f32(1.0 / sig ** 2), stereo=stereo,
               close_point=(Xc[:, 2] < 10).astype(np.uint8), link=link, huber_mono=float(np.float32(np.sqrt(5.991))), huber_stereo=float(np.float32(np.sqrt(7.815))),
               rec_init=0)
+    if last_frame:      # PoseInertialOptimizationLastFrame: [0] is the previous frame (free), tied to its prior pFp->mpcpi
+        A = rs.normal(0, 1, (15, 15))
+        Hp = np.diag([4e4] * 3 + [1e4] * 3 + [2e3] * 3 + [1e6] * 3 + [1e4] * 3) + 50.0 * (A @ A.T)
+        pr.update(last_frame=1, prior_Rwb=f32(R1 @ _so3_exp(rs.normal(0, 0.002, 3))), prior_twb=f32(p1 + rs.normal(0, 0.004, 3)),
+                  prior_vel=f32(v1 + rs.normal(0, 0.01, 3)), prior_bg=f32(bgk), prior_ba=f32(bak), prior_H=Hp)
+        if perturb:
+            pr["Rwb"][0] = f32(R1 @ _so3_exp(rs.normal(0, 0.004, 3))); pr["twb"][0] = f32(p1 + rs.normal(0, 0.01, 3)); pr["vel"][0] = f32(v1 + rs.normal(0, 0.02, 3))
     return pr, dict(Rwb=R2, twb=p2, vel=v2, is_outlier=is_out)

@@ -523,7 +523,9 @@ class PoseInertialProblem(C.Structure):
                 ("Rcb", C.c_double * 9), ("tcb", C.c_double * 3), ("tbc", C.c_double * 3),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
                 ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p), ("close_point", C.c_void_p),
-                ("link", InertialLink), ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("rec_init", C.c_int32)]
+                ("link", InertialLink), ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("rec_init", C.c_int32),
+                ("last_frame", C.c_int32), ("prior_Rwb", C.c_double * 9), ("prior_twb", C.c_double * 3), ("prior_vel", C.c_double * 3),
+                ("prior_bg", C.c_double * 3), ("prior_ba", C.c_double * 3), ("prior_H", C.c_double * 225)]
 
 
 def fill_pose_inertial_struct(s, pr):
@@ -543,6 +545,10 @@ def fill_pose_inertial_struct(s, pr):
     for name in ("info9", "info_gyro", "info_acc"):
         getattr(L, name)[:] = np.asarray(d[name], np.float64).ravel().tolist()
     s.huber_mono, s.huber_stereo, s.rec_init = pr["huber_mono"], pr["huber_stereo"], int(pr["rec_init"])
+    s.last_frame = int(pr.get("last_frame", 0))
+    if s.last_frame:
+        for k, m in (("prior_Rwb", 9), ("prior_twb", 3), ("prior_vel", 3), ("prior_bg", 3), ("prior_ba", 3), ("prior_H", 225)):
+            getattr(s, k)[:] = np.asarray(pr[k], np.float64).ravel().tolist()
     s._keep = keep
     return s
 
@@ -552,6 +558,7 @@ def oracle_pose_inertial_optimize(orc, pr):
     s = fill_pose_inertial_struct(PoseInertialProblem(), pr)
     n = s.n
     Rwb = np.zeros((3, 3)); twb = np.zeros(3); vel = np.zeros(3); bg = np.zeros(3); ba = np.zeros(3)
-    out = np.zeros(max(n, 1), np.uint8); H = np.zeros((15, 15)); nb = C.c_int()
+    N = 30 if s.last_frame else 15
+    out = np.zeros(max(n, 1), np.uint8); H = np.zeros((N, N)); nb = C.c_int()
     r = orc.lib.pose_inertial_oracle_optimize(C.byref(s), _p(Rwb), _p(twb), _p(vel), _p(bg), _p(ba), _p(out), _p(H), C.byref(nb))
     return dict(Rwb=Rwb, twb=twb, vel=vel, bg=bg, ba=ba, outlier=out[:n], H=H, n_bad=nb.value, inliers=r)

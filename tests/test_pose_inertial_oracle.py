@@ -32,3 +32,14 @@ def test_small_frames(oracle, synth):
     pr, _ = synth.make_pose_inertial_problem(4, n=0)
     r = oracle_pose_inertial_optimize(oracle, pr)       # pure inertial prediction
     assert r["inliers"] == 0 and np.isfinite(r["twb"]).all()
+
+
+def test_last_frame_variant(oracle, synth):
+    """PoseInertialOptimizationLastFrame: the previous frame is free and tied to its prior; 30 x 30 Hessian before Marginalize"""
+    for seed, kw in ((5, dict(n=300, outlier_frac=0.1)), (6, dict(n=80, outlier_frac=0.2, stereo_frac=0.5))):
+        pr, gt = synth.make_pose_inertial_problem(seed, last_frame=True, **kw)
+        r = oracle_pose_inertial_optimize(oracle, pr)
+        assert np.abs(r["twb"] - gt["twb"]).max() < 0.3 * np.abs(pr["twb"][1] - gt["twb"]).max() + 3e-3
+        assert r["outlier"][gt["is_outlier"]].all() and r["outlier"][~gt["is_outlier"]].mean() < 0.15
+        H = r["H"]
+        assert H.shape == (30, 30) and np.abs(H - H.T).max() < 1e-6 * np.abs(H).max() and np.linalg.eigvalsh((H + H.T) / 2).min() > 0
