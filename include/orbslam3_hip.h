@@ -521,7 +521,8 @@ int  liba_solve(liba_solver* s, const LibaProblem* problem, double* Rwb_out, dou
  * of the inertial tracker, for a batch of frames (one per client stream) in one launch.  Index [0] of the state arrays is the last key
  * frame (fixed), [1] the current frame.  Edges = the features holding a map point, in feature order; close_point = mTrackDepth < 10.
  * Outputs per frame: the optimised body pose / velocity / biases, mvbOutlier (frame b's flags start at the sum of the earlier frames'
- * n), the 15 x 15 Hessian of the new ConstraintPoseImu (:4837-4870), nInitialCorrespondences - nBad (the return value) and nBad.
+ * n), the Hessian of the new ConstraintPoseImu (:4837-4870; 15 x 15, or 30 x 30 per frame for the last-frame variant), nInitialCorrespondences -
+ * nBad (the return value) and nBad.
  * One camera / camera-body calibration per batch. */
 typedef struct LibaPoseProblem {
     double Rwb[18], twb[6], vel[6], bg[6], ba[6];
@@ -536,6 +537,11 @@ typedef struct LibaPoseProblem {
     LibaLink link;                  /* pFrame->mpImuPreintegrated, kf1 = 0, kf2 = 1; robust unused */
     double huber_mono, huber_stereo;
     int32_t rec_init;
+    /* last_frame != 0: Optimizer::PoseInertialOptimizationLastFrame (src/Optimizer.cc:4875-5285) -- index [0] is the PREVIOUS FRAME, optimised
+     * too and tied to its prior pFp->mpcpi (EdgePriorPoseImu, Huber 5); link = pFrame->mpImuPreintegratedFrame; the Hessian output is then
+     * 30 x 30 (previous frame 0-14, current frame 15-29), to be passed to Optimizer::Marginalize(H, 0, 14) by the caller (:5282). */
+    int32_t last_frame;
+    double prior_Rwb[9], prior_twb[3], prior_vel[3], prior_bg[3], prior_ba[3], prior_H[225];
 } LibaPoseProblem;
 int  liba_pose_optimize_batch(liba_solver* s, const LibaPoseProblem* problems, int batch, double* Rwb_out, double* twb_out, double* vel_out,
                               double* bg_out, double* ba_out, uint8_t* outlier_out, double* H15_out, int32_t* inliers_out, int32_t* n_bad_out);

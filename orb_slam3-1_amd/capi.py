@@ -962,7 +962,9 @@ class _LibaPoseProblem(C.Structure):
                 ("Rcb", C.c_double * 9), ("tcb", C.c_double * 3), ("tbc", C.c_double * 3),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
                 ("n", C.c_int32), ("Xw", C.c_void_p), ("obs", C.c_void_p), ("inv_sigma2", C.c_void_p), ("stereo", C.c_void_p), ("close_point", C.c_void_p),
-                ("link", _LibaLink), ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("rec_init", C.c_int32)]
+                ("link", _LibaLink), ("huber_mono", C.c_double), ("huber_stereo", C.c_double), ("rec_init", C.c_int32),
+                ("last_frame", C.c_int32), ("prior_Rwb", C.c_double * 9), ("prior_twb", C.c_double * 3), ("prior_vel", C.c_double * 3),
+                ("prior_bg", C.c_double * 3), ("prior_ba", C.c_double * 3), ("prior_H", C.c_double * 225)]
 
 
 def _fill_liba_pose(s, pr, keep):
@@ -982,6 +984,10 @@ def _fill_liba_pose(s, pr, keep):
     for name in ("info9", "info_gyro", "info_acc"):
         getattr(L, name)[:] = np.asarray(d[name], np.float64).ravel().tolist()
     s.huber_mono, s.huber_stereo, s.rec_init = pr["huber_mono"], pr["huber_stereo"], int(pr["rec_init"])
+    s.last_frame = int(pr.get("last_frame", 0))
+    if s.last_frame:
+        for k in ("prior_Rwb", "prior_twb", "prior_vel", "prior_bg", "prior_ba", "prior_H"):
+            getattr(s, k)[:] = np.asarray(pr[k], np.float64).ravel().tolist()
 
 
 def _pose_inertial_batch(self, problems):
@@ -993,7 +999,8 @@ def _pose_inertial_batch(self, problems):
         _fill_liba_pose(s, pr, keep)
     tot = sum(int(s.n) for s in arr)
     Rwb = np.zeros((B, 3, 3)); twb = np.zeros((B, 3)); vel = np.zeros((B, 3)); bg = np.zeros((B, 3)); ba = np.zeros((B, 3))
-    out = np.zeros(max(tot, 1), np.uint8); H = np.zeros((B, 15, 15)); inl = np.zeros(B, np.int32); nb = np.zeros(B, np.int32)
+    N = 30 if int(problems[0].get("last_frame", 0)) else 15         # last-frame variant: the 30 x 30 Hessian before Optimizer::Marginalize
+    out = np.zeros(max(tot, 1), np.uint8); H = np.zeros((B, N, N)); inl = np.zeros(B, np.int32); nb = np.zeros(B, np.int32)
     _check(lib.liba_pose_optimize_batch(self._h, arr, B, _p(Rwb), _p(twb), _p(vel), _p(bg), _p(ba), _p(out), _p(H), _p(inl), _p(nb)))
     res, o = [], 0
     for b in range(B):

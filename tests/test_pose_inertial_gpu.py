@@ -46,3 +46,21 @@ def test_pose_inertial_sweep(pkg, oracle, synth, seed):
             _check(oracle_pose_inertial_optimize(oracle, pr), r1, pr, seed)
     finally:
         s.close()
+
+
+def test_last_frame_variant_matches_oracle(pkg, oracle, synth):
+    """PoseInertialOptimizationLastFrame: free previous frame + EdgePriorPoseImu, 30 x 30 Hessian"""
+    cases = [dict(n=300, outlier_frac=0.1), dict(n=80, outlier_frac=0.2, stereo_frac=0.5), dict(n=4, outlier_frac=0.0), dict(n=0), dict(n=600, outlier_frac=0.05, stereo_frac=1.0),
+             dict(n=150, outlier_frac=0.3)]
+    probs = [synth.make_pose_inertial_problem(60 + i, last_frame=True, **kw)[0] for i, kw in enumerate(cases)]
+    s = pkg.InertialSolver()
+    try:
+        res = s.pose_optimize_batch(probs)
+        for i, (pr, r1) in enumerate(zip(probs, res)):
+            r0 = oracle_pose_inertial_optimize(oracle, pr)
+            assert r1["H"].shape == (30, 30)
+            _check(r0, r1, pr, ("last frame", cases[i]))
+        with pytest.raises(pkg.OrbxError):                   # one variant per batch
+            s.pose_optimize_batch([probs[0], synth.make_pose_inertial_problem(1, n=50)[0]])
+    finally:
+        s.close()
