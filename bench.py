@@ -494,6 +494,13 @@ def main():
                                     "workload": "%d frames x 300 mono edges + inertial link, 10%% gross outliers, 4 rounds x 10 Gauss-Newton iterations; one C call = "
                                                 "upload + one launch (a workgroup per frame) + download (incl. the Python-side packing of the problems)" % len(pi_ws),
                                     "inliers_per_frame": float(np.mean([r_["inliers"] for r_ in rpi]))}
+            # the last-frame variant (previous frame free, EdgePriorPoseImu, 30 unknowns): what the tracker calls on most frames
+            pl_ws = [synth.make_pose_inertial_problem(200 + i, n=300, outlier_frac=0.1, last_frame=True)[0] for i in range(16)] * (B // 16)
+            isol2.pose_optimize_batch(pl_ws)
+            t0 = time.perf_counter()
+            isol2.pose_optimize_batch(pl_ws)
+            dtpl = time.perf_counter() - t0
+            out["pose_inertial"]["last_frame_variant"] = {"value": len(pl_ws) / dtpl, "unit": "frames/s", "ms_per_batch": 1e3 * dtpl}
             isol2.close()
 
         # ---- CPU baseline leg (N=1 only, rank 0) ----

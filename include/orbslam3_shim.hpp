@@ -850,11 +850,14 @@ inline void LocalInertialBAHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& 
     pMap->IncreaseChangeIndex();
 }
 
-// int Optimizer::PoseInertialOptimizationLastKeyFrame(Frame* pFrame, bool bRecInit) (src/Optimizer.cc:4491-4873), conventional
-// cameras (Nleft == -1): one LibaPoseProblem edge per feature holding a map point, in feature order.
-inline int PoseInertialOptimizationLastKeyFrameHIP(Frame* pFrame, bool bRecInit = false)
+// int Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*, bool bRecInit) (src/Optimizer.cc:4491-4873) and
+// int Optimizer::PoseInertialOptimizationLastFrame(Frame*, bool bRecInit) (:4875-5285), conventional cameras (Nleft == -1): one
+// LibaPoseProblem edge per feature holding a map point, in feature order.  The last-frame variant optimises the previous frame too,
+// ties it to pFp->mpcpi and marginalises it afterwards with the reference's own Optimizer::Marginalize.
+inline int PoseInertialOptimizationHIP(Frame* pFrame, bool bRecInit, bool lastFrame)
 {
-    if (pFrame->Nleft != -1) return Optimizer::PoseInertialOptimizationLastKeyFrame(pFrame, bRecInit);     // stereo-fisheye rig: not on this path
+    if (pFrame->Nleft != -1)                                                        // stereo-fisheye rig: not on this path
+        return lastFrame ? Optimizer::PoseInertialOptimizationLastFrame(pFrame, bRecInit) : Optimizer::PoseInertialOptimizationLastKeyFrame(pFrame, bRecInit);
     const int N = pFrame->N;
     std::vector<int> feat;
     std::vector<double> Xw, obs, w;
@@ -878,14 +881,16 @@ inline int PoseInertialOptimizationLastKeyFrameHIP(Frame* pFrame, bool bRecInit 
         }
     }
     KeyFrame* pKF = pFrame->mpLastKeyFrame;
-    IMU::Preintegrated* pInt = pFrame->mpImuPreintegrated;
+    Frame* pFp = pFrame->mpPrevFrame;
+    IMU::Preintegrated* pInt = lastFrame ? pFrame->mpImuPreintegratedFrame : pFrame->mpImuPreintegrated;       // :5060 / :4673
     LibaPoseProblem pr;
     std::memset(&pr, 0, sizeof(pr));
     auto putState = [&](int i, const Eigen::Matrix3f& R, const Eigen::Vector3f& t, const Eigen::Vector3f& v, const IMU::Bias& b) {
         for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pr.Rwb[9 * i + 3 * r + c] = R(r, c); pr.twb[3 * i + r] = t(r); pr.vel[3 * i + r] = v(r); }
         pr.bg[3 * i] = b.bwx; pr.bg[3 * i + 1] = b.bwy; pr.bg[3 * i + 2] = b.bwz; pr.ba[3 * i] = b.bax; pr.ba[3 * i + 1] = b.bay; pr.ba[3 * i + 2] = b.baz;
     };
-    putState(0, pKF->GetImuRotation(), pKF->GetImuPosition(), pKF->GetVelocity(), pKF->GetImuBias());
+    if (lastFrame) putState(0, pFp->GetImuRotation(), pFp->GetImuPosition(), pFp->GetVelocity(), pFp->mImuBias);
+    else putState(0, pKF->GetImuRotation(), pKF->GetImuPosition(), pKF->GetVelocity(), pKF->GetImuBias());
     putState(1, pFrame->GetImuRotation(), pFrame->GetImuPosition(), pFrame->GetVelocity(), pFrame->mImuBias);
     const Eigen::Matrix3d Rcb = pFrame->mImuCalib.mTcb.rotationMatrix().cast<double>();
     const Eigen::Vector3d tcb = pFrame->mImuCalib.mTcb.translation().cast<double>(), tbc = pFrame->mImuCalib.mTbc.translation().cast<double>();
@@ -906,14 +911,25 @@ inline int PoseInertialOptimizationLastKeyFrameHIP(Frame* pFrame, bool bRecInit 
     Eigen::Matrix<double, 9, 1> eigs = es.eigenvalues();
     for (int k = 0; k < 9; k++) if (eigs[k] < 1e-12) eigs[k] = 0;
     Info = es.eigenvectors() * eigs.asDiagonal() * es.eigenvectors().transpose();
-    const Eigen::Matrix3d InfoG = pInt->C.block<3, 3>(9, 9).cast<double>().inverse(), InfoA = pInt->C.block<3, 3>(12, 12).cast<double>().inverse();
+    // both variants take the random-walk informations from pFrame->mpImuPreintegrated (:4686, :5069)
+    const Eigen::Matrix3d InfoG = pFrame->mpImuPreintegrated->C.block<3, 3>(9, 9).cast<double>().inverse();
+    const Eigen::Matrix3d InfoA = pFrame->mpImuPreintegrated->C.block<3, 3>(12, 12).cast<double>().inverse();
     for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) L.info9[9 * r + c] = Info(r, c);
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { L.info_gyro[3 * r + c] = InfoG(r, c); L.info_acc[3 * r + c] = InfoA(r, c); }
     const float thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815);
     pr.huber_mono = thHuberMono; pr.huber_stereo = thHuberStereo; pr.rec_init = bRecInit;
+    if (lastFrame) {                                                                // EdgePriorPoseImu(pFp->mpcpi) (:5079-5090)
+        const ConstraintPoseImu* c = pFp->mpcpi;
+        pr.last_frame = 1;
+        for (int r = 0; r < 3; r++) {
+            for (int q = 0; q < 3; q++) pr.prior_Rwb[3 * r + q] = c->Rwb(r, q);
+            pr.prior_twb[r] = c->twb(r); pr.prior_vel[r] = c->vwb(r); pr.prior_bg[r] = c->bg(r); pr.prior_ba[r] = c->ba(r);
+        }
+        for (int r = 0; r < 15; r++) for (int q = 0; q < 15; q++) pr.prior_H[15 * r + q] = c->H(r, q);
+    }
     static thread_local liba_solver* solver = nullptr;
     if (!solver) orbslam3_hip::check(liba_create(0, &solver));
-    double R[9], t[3], v[3], bg[3], ba[3], H[225];
+    double R[9], t[3], v[3], bg[3], ba[3], H[900];
     std::vector<uint8_t> outlier(feat.size() + 1);
     int32_t inliers = 0, nBad = 0;
     orbslam3_hip::check(liba_pose_optimize_batch(solver, &pr, 1, R, t, v, bg, ba, outlier.data(), H, &inliers, &nBad));
@@ -923,10 +939,19 @@ inline int PoseInertialOptimizationLastKeyFrameHIP(Frame* pFrame, bool bRecInit 
     pFrame->SetImuPoseVelocity(Rwb.cast<float>(), twb.cast<float>(), vwb.cast<float>());         // :4831-4834
     pFrame->mImuBias = IMU::Bias(ba[0], ba[1], ba[2], bg[0], bg[1], bg[2]);
     Eigen::Matrix<double, 15, 15> Hm;
-    for (int r = 0; r < 15; r++) for (int c = 0; c < 15; c++) Hm(r, c) = H[15 * r + c];
-    pFrame->mpcpi = new ConstraintPoseImu(Rwb, twb, vwb, vbg, vba, Hm);                           // :4870
+    if (lastFrame) {                                                                // :5282-5287
+        Eigen::MatrixXd H30(30, 30);
+        for (int r = 0; r < 30; r++) for (int c = 0; c < 30; c++) H30(r, c) = H[30 * r + c];
+        H30 = Optimizer::Marginalize(H30, 0, 14);
+        Hm = H30.block<15, 15>(15, 15);
+    } else
+        for (int r = 0; r < 15; r++) for (int c = 0; c < 15; c++) Hm(r, c) = H[15 * r + c];
+    pFrame->mpcpi = new ConstraintPoseImu(Rwb, twb, vwb, vbg, vba, Hm);                           // :4870 / :5284
+    if (lastFrame) { delete pFp->mpcpi; pFp->mpcpi = NULL; }
     return inliers;
 }
+inline int PoseInertialOptimizationLastKeyFrameHIP(Frame* pFrame, bool bRecInit = false) { return PoseInertialOptimizationHIP(pFrame, bRecInit, false); }
+inline int PoseInertialOptimizationLastFrameHIP(Frame* pFrame, bool bRecInit = false) { return PoseInertialOptimizationHIP(pFrame, bRecInit, true); }
 
 // void Frame::ComputeBoW() (src/Frame.cc:825-832): mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) on the device.
 // The tree is flattened once per vocabulary (TemplatedVocabulary::m_nodes is protected: reached through a derived type).
