@@ -214,7 +214,7 @@ def main():
                            "launch_ms": acc[dom], "algorithmic_bytes_per_launch": sb[dom] * B,
                            "stage_ms": acc, "stage_gbs": {k: sb[k] * B / (max(acc[k], 1e-6) * 1e-3) / 1e9 for k in acc}}
         # The HBM fraction above is what the contract asks for, but it is not what bounds this kernel: FAST is integer VALU work.
-        # SQ_INSTS_VALU of one launch (a separate rocprofv3 --pmc pass, profiles/r01_m_sq_counters.txt: 4.34e8 wave-instructions
+        # SQ_INSTS_VALU of one launch (a separate rocprofv3 --pmc pass, profiles/r01_n_sq_counters.txt: 4.34e8 wave-instructions
         # for 256 frames; the count is a property of the images, not of the run) against the chip's VALU issue rate
         # (256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz) with the launch time measured in THIS run.
         if dom == "fast_cells":
@@ -222,7 +222,7 @@ def main():
             peak_issue = 256 * 4 * 2.4e9 / 4.0
             out["roofline"]["valu_issue"] = {"achieved": valu_insts / (acc[dom] * 1e-3), "peak": peak_issue, "unit": "wave-instructions/s",
                                              "frac": valu_insts / (acc[dom] * 1e-3) / peak_issue,
-                                             "source": "SQ_INSTS_VALU per launch from profiles/r01_m_sq_counters.txt, launch time from this run"}
+                                             "source": "SQ_INSTS_VALU per launch from profiles/r01_n_sq_counters.txt, launch time from this run"}
 
         # ---- extra leg: the batch cut over S independent streams (one Extractor handle + BoW plan per stream, like the
         # reference's one ORBextractor per camera thread).  Stages with different bottlenecks (FAST: VALU, octree /
