@@ -52,3 +52,23 @@ for seed in range(N):
         print("lba seed %d: control flow differs" % seed, kw, r0["stats"], r1["stats"])
 s.close()
 print("local BA: %d windows, %d with a different control flow, worst relative update difference %.2e" % (N, bad, worst))
+from oracle_api import oracle_pose_inertial_optimize  # noqa: E402
+
+for lf in (False, True):
+    probs = []
+    for seed in range(N):
+        rs = np.random.RandomState(9000 + seed)
+        probs.append(synth.make_pose_inertial_problem(9500 + seed, n=int(rs.randint(0, 800)), outlier_frac=float(rs.choice([0.0, 0.1, 0.3])),
+                                                      stereo_frac=float(rs.choice([0.0, 0.5, 1.0])), noise_px=float(rs.choice([0.3, 1.0])), last_frame=lf)[0])
+    isol = pkg.InertialSolver()
+    res = isol.pose_optimize_batch(probs)
+    isol.close()
+    bad = 0; worst = 0.0
+    for pr, r1 in zip(probs, res):
+        r0 = oracle_pose_inertial_optimize(o, pr)
+        if not (np.array_equal(r0["outlier"], r1["outlier"]) and r0["n_bad"] == r1["n_bad"]):
+            bad += 1
+            continue
+        d0, d1 = r0["twb"] - pr["twb"][1], r1["twb"] - pr["twb"][1]
+        worst = max(worst, np.abs(d0 - d1).max() / max(np.abs(d0).max(), 1e-12))
+    print("pose-inertial (%s): %d frames, %d with different outlier flags, worst relative update difference %.2e" % ("last frame" if lf else "last key frame", N, bad, worst))
