@@ -587,6 +587,18 @@ int  orbe_unpack_batch_device(orbe_codec* c, const uint8_t* d_payload, int strid
                               OrbxKeyPoint* d_kps, uint8_t* d_desc, int32_t* d_n, int32_t* d_frame_id, int64_t* d_timestamp,
                               OrbeImuSample* d_imu, int32_t* d_n_imu, int32_t* d_status, void* stream);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:834-867) on the device, for key points that arrived in packets (the server-side Frame constructor,
+ * src/Frame.cc:384-470, runs it before AssignFeaturesToGrid): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) per key point, every
+ * other KeyPoint field copied.  k = (k1, k2, p1, p2, k3) as in mDistCoef; k[0] == 0 is the plain copy of :836-840.  Device pointers,
+ * [batch][cap] layout with d_n live rows per frame; only enqueues on `stream`.  d_kps_un may equal d_kps. */
+typedef struct OrbeCamera {
+    float fx, fy, cx, cy;           /* Pinhole::toK() */
+    float k[5];                     /* mDistCoef */
+    float fx_new, fy_new, cx_new, cy_new;   /* mK */
+} OrbeCamera;
+int  orbe_undistort_batch_device(orbe_codec* c, const OrbxKeyPoint* d_kps, const int32_t* d_n, int batch, int cap, const OrbeCamera* cam,
+                                 OrbxKeyPoint* d_kps_un, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

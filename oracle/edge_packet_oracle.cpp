@@ -88,3 +88,32 @@ int edge_oracle_unpack(const uint8_t* payload, int packet_size, int32_t* frame_i
 }
 
 }  // extern "C"
+
+/* Frame::UndistortKeyPoints (reference src/Frame.cc:834-867): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) restated from
+ * OpenCV 4.x cvUndistortPointsInternal [UPSTREAM, not in /root/reference; PARITY UNPINNED]: double arithmetic, five iterations
+ * (TermCriteria(MAX_ITER, 5, 0.01)), the icdist < 0 guard, no tilt, R = I, P = mK; results stored as float. */
+extern "C" void edge_oracle_undistort(const OracleKeyPoint* kin, int n, const float K[4], const float dist[5], const float Knew[4], OracleKeyPoint* kout)
+{
+    for (int i = 0; i < n; i++) {
+        OracleKeyPoint kp = kin[i];
+        if (dist[0] != 0.0f) {
+            const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], ifx = 1. / fx, ify = 1. / fy;
+            const double k[5] = {dist[0], dist[1], dist[2], dist[3], dist[4]};
+            const double u = kp.x, v = kp.y;
+            double x = (u - cx) * ifx, y = (v - cy) * ify;
+            const double x0 = x, y0 = y;
+            for (int j = 0; j < 5; j++) {
+                const double r2 = x * x + y * y;
+                const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+                if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+                const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+                const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+                x = (x0 - deltaX) * icdist;
+                y = (y0 - deltaY) * icdist;
+            }
+            kp.x = (float)((double)Knew[0] * x + (double)Knew[2]);
+            kp.y = (float)((double)Knew[1] * y + (double)Knew[3]);
+        }
+        kout[i] = kp;
+    }
+}

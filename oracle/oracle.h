@@ -303,6 +303,9 @@ typedef struct OraclePoseInertialProblem {
 int   pose_inertial_oracle_optimize(const OraclePoseInertialProblem* P, double* Rwb_out, double* twb_out, double* vel_out,
                                     double* bg_out, double* ba_out, uint8_t* outlier, double* H15_out, int* n_bad_out);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:834-867): K = fx fy cx cy, dist = k1 k2 p1 p2 k3, Knew = mK */
+void  edge_oracle_undistort(const OracleKeyPoint* kin, int n, const float K[4], const float dist[5], const float Knew[4], OracleKeyPoint* kout);
+
 #ifdef __cplusplus
 }
 #endif

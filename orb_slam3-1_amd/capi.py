@@ -870,6 +870,17 @@ class PacketCodec:
                                           C.c_void_p(d_payload), int(stride), C.c_void_p(d_len), C.c_void_p(d_head or 0), C.c_void_p(d_status),
                                           C.c_void_p(stream or 0)))
 
+    class _Camera(C.Structure):
+        _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("k", C.c_float * 5),
+                    ("fx_new", C.c_float), ("fy_new", C.c_float), ("cx_new", C.c_float), ("cy_new", C.c_float)]
+
+    def undistort_batch_device(self, d_kps, d_n, batch, cap, K, dist, Knew, d_kps_un, stream=None):
+        """Frame::UndistortKeyPoints on device arrays: K / Knew = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3)"""
+        cam = self._Camera(float(K[0]), float(K[1]), float(K[2]), float(K[3]), (C.c_float * 5)(*[float(v) for v in dist]),
+                           float(Knew[0]), float(Knew[1]), float(Knew[2]), float(Knew[3]))
+        _check(lib.orbe_undistort_batch_device(self._h, C.c_void_p(d_kps), C.c_void_p(d_n), int(batch), int(cap), C.byref(cam), C.c_void_p(d_kps_un),
+                                               C.c_void_p(stream or 0)))
+
     def unpack_batch_device(self, d_payload, stride, d_len, batch, cap, imu_cap, d_kps, d_desc, d_n, d_frame_id, d_timestamp, d_imu, d_n_imu,
                             d_status, stream=None):
         _check(lib.orbe_unpack_batch_device(self._h, C.c_void_p(d_payload), int(stride), C.c_void_p(d_len), int(batch), int(cap), int(imu_cap),

@@ -138,6 +138,40 @@ __global__ __launch_bounds__(kThreads) void k_unpack_packets(const uint8_t* __re
     }
 }
 
+// Frame::UndistortKeyPoints (reference src/Frame.cc:834-867) for the key points a server has just unpacked: cv::undistortPoints(mat, mat,
+// K, mDistCoef, cv::Mat(), mK) = five fixed-point iterations of the radial / tangential model in double (OpenCV 4.x
+// cvUndistortPointsInternal with TermCriteria(MAX_ITER, 5, 0.01), icdist < 0 guard), re-projected with the new camera matrix and
+// stored as float; every other KeyPoint field is copied (mvKeysUn[i] = mvKeys[i] with a new pt).  k[0] == 0 means "no distortion":
+// a plain copy, as at :836-840.  One thread per key point.
+__global__ __launch_bounds__(kThreads) void k_undistort(const OrbxKeyPoint* __restrict__ kin, const int32_t* __restrict__ n_pts, int cap, int total,
+                                                       OrbeCamera cam, OrbxKeyPoint* __restrict__ kout)
+{
+    const int g = blockIdx.x * kThreads + threadIdx.x;
+    if (g >= total) return;
+    const int b = g / cap, i = g - b * cap;
+    if (i >= min(max(n_pts[b], 0), cap)) return;
+    OrbxKeyPoint kp = kin[g];
+    if (cam.k[0] != 0.0f) {
+        const double fx = cam.fx, fy = cam.fy, cx = cam.cx, cy = cam.cy, ifx = 1. / fx, ify = 1. / fy;
+        const double k0 = cam.k[0], k1 = cam.k[1], p1 = cam.k[2], p2 = cam.k[3], k4 = cam.k[4];
+        const double u = kp.x, v = kp.y;
+        double x = (u - cx) * ifx, y = (v - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1. / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);      // k[5..7] = 0: the numerator of OpenCV's rational model is 1
+            if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+            const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+            const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        kp.x = (float)((double)cam.fx_new * x + (double)cam.cx_new);
+        kp.y = (float)((double)cam.fy_new * y + (double)cam.cy_new);
+    }
+    kout[g] = kp;
+}
+
 }  // namespace orbe
 
 struct orbe_codec {
@@ -304,6 +338,19 @@ int orbe_unpack_batch(orbe_codec* c, const uint8_t* payload, int stride, const i
     ORBE_HIP(hipMemcpyAsync(desc, d + o_desc, B * cap * 32, hipMemcpyDeviceToHost, s));
     if (imu_cap > 0) ORBE_HIP(hipMemcpyAsync(imu, d + o_imu, B * imu_cap * sizeof(OrbeImuSample), hipMemcpyDeviceToHost, s));
     ORBE_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+int orbe_undistort_batch_device(orbe_codec* c, const OrbxKeyPoint* d_kps, const int32_t* d_n, int batch, int cap, const OrbeCamera* cam,
+                                OrbxKeyPoint* d_kps_un, void* stream)
+{
+    if (!c || !d_kps || !d_n || !cam || !d_kps_un || batch < 1 || cap < 1) return fail(ORBX_ERR_ARG, "bad arguments");
+    if (!(cam->fx != 0.0f) || !(cam->fy != 0.0f)) return fail(ORBX_ERR_ARG, "bad camera matrix");
+    ORBE_HIP(hipSetDevice(c->device));
+    const int total = batch * cap;
+    hipLaunchKernelGGL(orbe::k_undistort, dim3((total + orbe::kThreads - 1) / orbe::kThreads), dim3(orbe::kThreads), 0, (hipStream_t)stream, d_kps, d_n, cap, total,
+                       *cam, d_kps_un);
+    ORBE_HIP(hipGetLastError());
     return ORBX_OK;
 }
 

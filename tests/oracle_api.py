@@ -562,3 +562,12 @@ def oracle_pose_inertial_optimize(orc, pr):
     out = np.zeros(max(n, 1), np.uint8); H = np.zeros((N, N)); nb = C.c_int()
     r = orc.lib.pose_inertial_oracle_optimize(C.byref(s), _p(Rwb), _p(twb), _p(vel), _p(bg), _p(ba), _p(out), _p(H), C.byref(nb))
     return dict(Rwb=Rwb, twb=twb, vel=vel, bg=bg, ba=ba, outlier=out[:n], H=H, n_bad=nb.value, inliers=r)
+
+
+def oracle_undistort(orc, kps, K, dist, Knew):
+    """Frame::UndistortKeyPoints: K / Knew = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3)"""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros_like(kps)
+    K = np.ascontiguousarray(K, np.float32); dist = np.ascontiguousarray(dist, np.float32); Knew = np.ascontiguousarray(Knew, np.float32)
+    orc.lib.edge_oracle_undistort(_p(kps), len(kps), _p(K), _p(dist), _p(Knew), _p(out))
+    return out

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle_api import IMU_DTYPE, oracle_pack_packet, oracle_unpack_packet
+from oracle_api import IMU_DTYPE, oracle_pack_packet, oracle_undistort, oracle_unpack_packet
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -135,3 +135,27 @@ def test_extractor_to_packet_device_chain(pkg, oracle, synth):
         assert np.array_equal(pay[b, :ln[b]], ref)
         assert np.array_equal(d2h[b, :n[b]], dh[b, :n[b]]) and np.array_equal(k2h["x"][b, :n[b]], np.trunc(kh["x"][b, :n[b]]))
     codec.close(); ex.close()
+
+
+def test_undistort_matches_oracle(pkg, oracle):
+    """Frame::UndistortKeyPoints on the device arrays a server has just unpacked -- floats bit-identical to the oracle"""
+    import torch
+    K = (458.654, 457.296, 367.215, 248.375); dist = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+    B, cap = 7, 1500
+    kps, _, n, _, _, _, _ = _batch(pkg, 11, B, cap, 0)
+    dev = torch.device("cuda:0")
+    d_k = torch.from_numpy(kps.view(np.uint8).reshape(-1)).to(dev); d_n = torch.from_numpy(n).to(dev); d_o = torch.zeros_like(d_k)
+    codec = pkg.PacketCodec()
+    s = torch.cuda.current_stream().cuda_stream
+    codec.undistort_batch_device(d_k.data_ptr(), d_n.data_ptr(), B, cap, K, dist, K, d_o.data_ptr(), s)
+    torch.cuda.synchronize()
+    out = d_o.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap)
+    for b in range(B):
+        ref = oracle_undistort(oracle, kps[b, :n[b]], K, dist, K)
+        assert out[b, :n[b]].tobytes() == ref.tobytes(), b
+        assert not out[b, n[b]:].view(np.uint8).any()           # rows past the count are not written
+    # in place, and the no-distortion copy
+    codec.undistort_batch_device(d_k.data_ptr(), d_n.data_ptr(), B, cap, K, (0, 0, 0, 0, 0), K, d_k.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert d_k.cpu().numpy().tobytes() == kps.tobytes()
+    codec.close()

@@ -6,7 +6,7 @@ import struct
 
 import numpy as np
 
-from oracle_api import IMU_DTYPE, KP_DTYPE, oracle_pack_packet, oracle_unpack_packet
+from oracle_api import IMU_DTYPE, KP_DTYPE, oracle_pack_packet, oracle_undistort, oracle_unpack_packet
 
 
 def _python_pack(frame_id, ts, kps, desc, imu):
@@ -80,3 +80,30 @@ def test_golden_packet(oracle):
     pay, head = oracle_pack_packet(oracle, int(g["frame_id"]), int(g["timestamp"]), kps, g["desc"], imu)
     assert np.array_equal(pay, g["payload"]) and np.array_equal(head, g["head"])
     assert np.array_equal(pay, _python_pack(int(g["frame_id"]), int(g["timestamp"]), kps, g["desc"], imu))
+
+
+EUROC_K = (458.654, 457.296, 367.215, 248.375)
+EUROC_DIST = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0)
+
+
+def test_undistort_inverts_the_distortion_model(oracle):
+    """the restated cv::undistortPoints against the forward radial / tangential model (Examples/Monocular/EuRoC.yaml:23-32)"""
+    rs = np.random.RandomState(0)
+    n = 500
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rs.uniform(0, 752, n).astype(np.float32); kps["y"] = rs.uniform(0, 480, n).astype(np.float32)
+    kps["size"] = 31; kps["octave"] = rs.randint(0, 8, n); kps["angle"] = rs.uniform(0, 360, n)
+    un = oracle_undistort(oracle, kps, EUROC_K, EUROC_DIST, EUROC_K)
+    fx, fy, cx, cy = EUROC_K; k1, k2, p1, p2, k3 = EUROC_DIST
+    x = (un["x"].astype(np.float64) - cx) / fx; y = (un["y"].astype(np.float64) - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x); yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    # five fixed iterations leave a few tenths of a pixel in the far corners of this strongly distorted camera, ~1e-5 px in the centre
+    assert np.abs(xd * fx + cx - kps["x"]).max() < 0.5 and np.abs(yd * fy + cy - kps["y"]).max() < 0.5
+    assert np.median(np.abs(xd * fx + cx - kps["x"])) < 2e-3
+    for f in ("size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(un[f], kps[f])
+    # no distortion: a plain copy (src/Frame.cc:836-840)
+    same = oracle_undistort(oracle, kps, EUROC_K, (0, 0.1, 0, 0, 0), EUROC_K)
+    assert same.tobytes() == kps.tobytes()
