@@ -194,39 +194,55 @@ typedef struct OrbmFrame {
     int32_t grid_cols, grid_rows;      /* FRAME_GRID_COLS, FRAME_GRID_ROWS (64, 48: include/Frame.h:44-45) */
     const float* scale_factors;        /* mvScaleFactors */
     int32_t n_levels;
+    const float* u_right;              /* mvuRight (rectified stereo / RGB-D: right-image column of feature i, < 0 when the
+                                        * feature has none); NULL for a monocular frame.  Only the two tracking searches
+                                        * read it (src/ORBmatcher.cc:92-98, :1751-1757); frames are F.Nleft == -1. */
 } OrbmFrame;
 
 /* int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, float th, bool bFarPoints,
- *                                    float thFarPoints) (src/ORBmatcher.cc:43-213), mono branch.
- * Per map point i: in_view = mbTrackInView, proj_u/v = mTrackProjX/Y, pred_level = mnTrackScaleLevel,
+ *                                    float thFarPoints) (src/ORBmatcher.cc:43-213), F.Nleft == -1 (monocular and
+ * rectified stereo / RGB-D; the stereo-fisheye branch :140-209 is out of scope).
+ * Per map point i: in_view = mbTrackInView, proj_u/v = mTrackProjX/Y, proj_ur = mTrackProjXR (= u - mbf*invz,
+ * src/Frame.cc:652; read only against features with f->u_right[idx] > 0, the gate of :92-98; may be NULL when
+ * f->u_right is NULL), pred_level = mnTrackScaleLevel,
  * view_cos = mTrackViewCos, track_depth = mTrackDepth, bad = isBad(), has_obs = Observations()>0, desc = GetDescriptor().
  * occupied[n] (in/out): F.mvpMapPoints[i] != NULL && Observations()>0.  assign[n] (in/out): map point index now held by
  * feature i (unchanged where the call made no assignment).  Returns nmatches. */
 int orbm_search_by_projection(orbm_matcher* m, const OrbmFrame* f,
-                              int n_mp, const uint8_t* in_view, const float* proj_u, const float* proj_v,
+                              int n_mp, const uint8_t* in_view, const float* proj_u, const float* proj_v, const float* proj_ur,
                               const int32_t* pred_level, const float* view_cos, const float* track_depth,
                               const uint8_t* desc_mp, const uint8_t* mp_has_obs, const uint8_t* mp_bad,
                               float th, int far_points, float th_far, float nnratio,
                               int32_t* assign, uint8_t* occupied);
 
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th, bool bMono)
- * (src/ORBmatcher.cc:1676-1887), mono branch.  The caller projects the last frame's map points (Tcw*x3Dw,
- * Pinhole::project) with the reference's own float expressions and clears last_valid where invzc<0, the point is
- * NULL or an outlier.  last_octave/last_angle = LastFrame.mvKeys[i].octave / mvKeysUn[i].angle. */
+ * (src/ORBmatcher.cc:1676-1887), both frames Nleft == -1 (monocular and rectified stereo / RGB-D).  The caller projects
+ * the last frame's map points (Tcw*x3Dw, Pinhole::project) with the reference's own float expressions and clears
+ * last_valid where invzc<0, the point is NULL or an outlier.  proj_ur[i] = uv(0) - CurrentFrame.mbf*invzc (:1753, float;
+ * read only against features with cur->u_right[i2] > 0; may be NULL when cur->u_right is NULL).
+ * last_octave/last_angle = LastFrame.mvKeys[i].octave / mvKeysUn[i].angle.
+ * level_window: ORBM_LEVELS_AROUND (neither bForward nor bBackward, always so for bMono: levels octave-1 .. octave+1, :1733),
+ * ORBM_LEVELS_FORWARD (bForward = tlc(2) > mb && !bMono, :1692: levels >= octave, :1729) or ORBM_LEVELS_BACKWARD
+ * (bBackward = -tlc(2) > mb && !bMono, :1693: levels 0 .. octave, :1731). */
+#define ORBM_LEVELS_AROUND   0
+#define ORBM_LEVELS_FORWARD  1
+#define ORBM_LEVELS_BACKWARD 2
 int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
-                                   int n_last, const uint8_t* last_valid, const float* proj_u, const float* proj_v,
+                                   int n_last, const uint8_t* last_valid, const float* proj_u, const float* proj_v, const float* proj_ur,
                                    const int32_t* last_octave, const float* last_angle,
                                    const uint8_t* desc_mp, const uint8_t* mp_has_obs,
-                                   float th, int check_orientation,
+                                   float th, int level_window, int check_orientation,
                                    int32_t* assign, uint8_t* occupied);
 
 /* Batched forms of the two tracking searches: n_frames independent (frame, projected points) problems -- e.g. one frame
  * of every client stream of a tracking server -- in ONE launch, a wave per frame.  Field meaning as in the single-frame
- * calls above (level = pred_level / last_octave, angle = last_angle); n_matches is written per query. */
+ * calls above (level = pred_level / last_octave, angle = last_angle; level_window is per query because bForward /
+ * bBackward depend on each stream's own motion); n_matches is written per query. */
 typedef struct OrbmProjQuery {
     const OrbmFrame* frame;
     int32_t n_pts;
-    const uint8_t* valid; const float* proj_u; const float* proj_v; const int32_t* level;
+    const uint8_t* valid; const float* proj_u; const float* proj_v; const float* proj_ur; const int32_t* level;
+    int32_t level_window;                                                          /* last-frame search only: ORBM_LEVELS_* */
     const float* view_cos; const float* track_depth; const uint8_t* mp_bad;      /* Frame x map points only */
     const float* angle;                                                            /* last-frame search only */
     const uint8_t* desc_mp; const uint8_t* mp_has_obs;

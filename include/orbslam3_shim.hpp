@@ -260,34 +260,47 @@ public:
         return n;
     }
 
+    // SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:43-213): monocular and
+    // rectified-stereo / RGB-D frames (F.Nleft == -1; the mvuRight gate :92-98 runs on the device); stereo-fisheye frames keep
+    // the reference.
     int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const bool bFarPoints, const float thFarPoints)
     {
+        if (F.Nleft != -1) return ORBmatcher(mfNNratio, mbCheckOrientation).SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints);
         const int nMP = (int)vpMapPoints.size(), nF = F.N;
         std::vector<uint8_t> inView(nMP), hasObs(nMP), bad(nMP), desc((size_t)nMP * 32), occ(nF);
-        std::vector<float> u(nMP), v(nMP), vc(nMP), depth(nMP);
+        std::vector<float> u(nMP), v(nMP), ur(nMP), vc(nMP), depth(nMP);
         std::vector<int32_t> lvl(nMP), assign(nF, -2);
         for (int i = 0; i < nMP; i++) {
             MapPoint* p = vpMapPoints[i];
-            inView[i] = p->mbTrackInView; u[i] = p->mTrackProjX; v[i] = p->mTrackProjY; lvl[i] = p->mnTrackScaleLevel;
+            inView[i] = p->mbTrackInView; u[i] = p->mTrackProjX; v[i] = p->mTrackProjY; ur[i] = p->mTrackProjXR; lvl[i] = p->mnTrackScaleLevel;
             vc[i] = p->mTrackViewCos; depth[i] = p->mTrackDepth; bad[i] = p->isBad(); hasObs[i] = p->Observations() > 0;
             const cv::Mat d = p->GetDescriptor();
             std::memcpy(&desc[(size_t)i * 32], d.data, 32);
         }
         OrbmFrame f = frameView(F, occ);
-        const int n = orbslam3_hip::check(orbm_search_by_projection(m_, &f, nMP, inView.data(), u.data(), v.data(), lvl.data(), vc.data(),
+        const int n = orbslam3_hip::check(orbm_search_by_projection(m_, &f, nMP, inView.data(), u.data(), v.data(), ur.data(), lvl.data(), vc.data(),
                                                                      depth.data(), desc.data(), hasObs.data(), bad.data(),
                                                                      th, bFarPoints, thFarPoints, mfNNratio, assign.data(), occ.data()));
         for (int i = 0; i < nF; i++) if (assign[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assign[i]];
         return n;
     }
 
+    // SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1676-1887): bMono is
+    // honoured -- a stereo / RGB-D caller gets the forward / backward level windows (:1692-1693, :1728-1733) and the ur gate
+    // (:1751-1757); stereo-fisheye frames (Nleft != -1) keep the reference.
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono)
     {
-        (void)bMono;    // the stereo forward/backward branches are not on the accelerated path; callers keep the reference for them
+        if (CurrentFrame.Nleft != -1 || LastFrame.Nleft != -1) return ORBmatcher(mfNNratio, mbCheckOrientation).SearchByProjection(CurrentFrame, LastFrame, th, bMono);
         const int nL = LastFrame.N, nF = CurrentFrame.N;
         const Sophus::SE3f Tcw = CurrentFrame.GetPose();
+        const Eigen::Vector3f twc = Tcw.inverse().translation();                   // :1686-1693
+        const Sophus::SE3f Tlw = LastFrame.GetPose();
+        const Eigen::Vector3f tlc = Tlw * twc;
+        const bool bForward = tlc(2) > CurrentFrame.mb && !bMono;
+        const bool bBackward = -tlc(2) > CurrentFrame.mb && !bMono;
+        const int levelWindow = bForward ? ORBM_LEVELS_FORWARD : bBackward ? ORBM_LEVELS_BACKWARD : ORBM_LEVELS_AROUND;
         std::vector<uint8_t> valid(nL, 0), hasObs(nL, 0), desc((size_t)nL * 32, 0), occ(nF);
-        std::vector<float> u(nL, 0.f), v(nL, 0.f), ang(nL, 0.f);
+        std::vector<float> u(nL, 0.f), v(nL, 0.f), ur(nL, 0.f), ang(nL, 0.f);
         std::vector<int32_t> oct(nL, 0), assign(nF, -2);      // -2 = untouched, -1 = nulled by the rotation check (:1878)
         for (int i = 0; i < nL; i++) {
             MapPoint* p = LastFrame.mvpMapPoints[i];
@@ -296,14 +309,14 @@ public:
             const float invzc = 1.0 / x3Dc(2);
             if (invzc < 0) continue;
             const Eigen::Vector2f uv = CurrentFrame.mpCamera->project(x3Dc);
-            valid[i] = 1; u[i] = uv(0); v[i] = uv(1);
+            valid[i] = 1; u[i] = uv(0); v[i] = uv(1); ur[i] = uv(0) - CurrentFrame.mbf * invzc;      // :1753
             oct[i] = LastFrame.mvKeys[i].octave; ang[i] = LastFrame.mvKeysUn[i].angle; hasObs[i] = p->Observations() > 0;
             const cv::Mat d = p->GetDescriptor();
             std::memcpy(&desc[(size_t)i * 32], d.data, 32);
         }
         OrbmFrame f = frameView(CurrentFrame, occ);
-        const int n = orbslam3_hip::check(orbm_search_by_projection_last(m_, &f, nL, valid.data(), u.data(), v.data(), oct.data(), ang.data(),
-                                                                          desc.data(), hasObs.data(), th, mbCheckOrientation,
+        const int n = orbslam3_hip::check(orbm_search_by_projection_last(m_, &f, nL, valid.data(), u.data(), v.data(), ur.data(), oct.data(), ang.data(),
+                                                                          desc.data(), hasObs.data(), th, levelWindow, mbCheckOrientation,
                                                                           assign.data(), occ.data()));
         for (int i = 0; i < nF; i++) {
             if (assign[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[assign[i]];
@@ -381,7 +394,7 @@ public:
         f.n = nK; f.x = x_.data(); f.y = y_.data(); f.octave = o_.data(); f.angle = NULL; f.desc = pKF->mDescriptors.data;
         f.min_x = pKF->mnMinX; f.min_y = pKF->mnMinY; f.max_x = pKF->mnMaxX; f.max_y = pKF->mnMaxY;
         f.grid_cols = pKF->mnGridCols; f.grid_rows = pKF->mnGridRows;
-        f.scale_factors = pKF->mvScaleFactors.data(); f.n_levels = (int)pKF->mvScaleFactors.size();
+        f.scale_factors = pKF->mvScaleFactors.data(); f.n_levels = (int)pKF->mvScaleFactors.size(); f.u_right = NULL;
         orbslam3_hip::check(orbm_fuse_search(m_, &f, pKF->mvuRight.data(), pKF->mvInvLevelSigma2.data(), nMPs, valid.data(), u.data(), v.data(),
                                              ur.data(), lvl.data(), desc.data(), th, 1, bestIdx.data(), bestDist.data()));
         int nFused = 0;
@@ -505,7 +518,7 @@ public:
             f.n = nK; f.x = x_.data(); f.y = y_.data(); f.octave = o_.data(); f.angle = NULL; f.desc = to->mDescriptors.data;
             f.min_x = to->mnMinX; f.min_y = to->mnMinY; f.max_x = to->mnMaxX; f.max_y = to->mnMaxY;
             f.grid_cols = to->mnGridCols; f.grid_rows = to->mnGridRows;
-            f.scale_factors = to->mvScaleFactors.data(); f.n_levels = (int)to->mvScaleFactors.size();
+            f.scale_factors = to->mvScaleFactors.data(); f.n_levels = (int)to->mvScaleFactors.size(); f.u_right = NULL;
             orbslam3_hip::check(orbm_fuse_search(m_, &f, NULL, NULL, n, valid.data(), u.data(), v.data(), NULL, lvl.data(), desc.data(), th, 0,
                                                  bestIdx.data(), bestDist.data()));
             vnMatch.assign(n, -1);
@@ -536,6 +549,7 @@ private:
         f.min_x = F.mnMinX; f.min_y = F.mnMinY; f.max_x = F.mnMaxX; f.max_y = F.mnMaxY;
         f.grid_cols = FRAME_GRID_COLS; f.grid_rows = FRAME_GRID_ROWS;
         f.scale_factors = F.mvScaleFactors.data(); f.n_levels = (int)F.mvScaleFactors.size();
+        f.u_right = (int)F.mvuRight.size() == n && n > 0 ? F.mvuRight.data() : NULL;       // all -1 for a monocular frame (src/Frame.cc:320)
         return f;
     }
     float mfNNratio;

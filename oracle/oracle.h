@@ -94,28 +94,31 @@ typedef struct OracleFrameGrid {
     const int32_t* octave;
     float min_x, min_y, max_x, max_y;   /* mnMinX .. mnMaxY */
     int32_t cols, rows;                 /* FRAME_GRID_COLS / ROWS (64, 48) */
+    const float* u_right;               /* mvuRight (rectified stereo / RGB-D), NULL for a monocular frame; read by the two
+                                         * tracking searches only */
 } OracleFrameGrid;
 
-/* SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFar, thFar) mono branch (:43-213).
- * Per point: in_view, proj u/v, predicted level, view cos, track depth, 32B descriptor, has_obs (Observations()>0).
+/* SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFar, thFar), F.Nleft == -1 (:43-138).
+ * Per point: in_view, proj u/v, proj_ur = mTrackProjXR (gate :92-98 against g->u_right), predicted level, view cos, track depth, 32B descriptor, has_obs (Observations()>0).
  * occupied[nF]: in/out, 1 if F.mvpMapPoints[i] holds a MapPoint with Observations()>0.
  * assign[nF]: in/out, index of map point held by feature i (-1 none). */
 int   orbm_oracle_search_by_projection(const OracleFrameGrid* g, const uint8_t* dF, const float* scale_factors, int nlevels,
-                                       int nMP, const uint8_t* in_view, const float* proj_u, const float* proj_v,
+                                       int nMP, const uint8_t* in_view, const float* proj_u, const float* proj_v, const float* proj_ur,
                                        const int32_t* pred_level, const float* view_cos, const float* track_depth,
                                        const uint8_t* dMP, const uint8_t* mp_has_obs, const uint8_t* mp_bad,
                                        float th, int bFar, float thFar, float nnratio,
                                        int32_t* assign, uint8_t* occupied);
 
-/* SearchByProjection(Frame& cur, const Frame& last, th, bMono) mono branch (:1676-1887).
- * The caller projects (Tcw * x3Dw, Pinhole::project) and clears last_valid for invzc<0. */
+/* SearchByProjection(Frame& cur, const Frame& last, th, bMono), Nleft == -1 (:1676-1887).
+ * The caller projects (Tcw * x3Dw, Pinhole::project), clears last_valid for invzc<0, computes proj_ur = uv(0) - mbf*invzc
+ * (:1753) and level_window (0: octave-1..octave+1; 1: bForward, >= octave; 2: bBackward, 0..octave; :1692-1693,:1728-1733). */
 int   orbm_oracle_search_by_projection_last(const OracleFrameGrid* g, const uint8_t* dF, const float* angF,
                                             const float* scale_factors, int nlevels,
                                             int nLast, const uint8_t* last_valid /* has MP && !outlier && invzc>=0 */,
-                                            const float* proj_u, const float* proj_v,
+                                            const float* proj_u, const float* proj_v, const float* proj_ur,
                                             const int32_t* last_octave, const float* last_angle,
                                             const uint8_t* dMP, const uint8_t* mp_has_obs,
-                                            float th, int checkOri,
+                                            float th, int level_window, int checkOri,
                                             int32_t* assign, uint8_t* occupied);
 
 /* SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1889-2010), relocalisation. */

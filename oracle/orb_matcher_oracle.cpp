@@ -10,7 +10,9 @@
  *   /root/reference/src/ORBmatcher.cc:1676-1887 SearchByProjection(Frame&, const Frame&, th, bMono)
  *   /root/reference/src/ORBmatcher.cc:2012-2074 ComputeThreeMaxima, DescriptorDistance
  *   /root/reference/src/Frame.cc:472-503,744-822 AssignFeaturesToGrid, GetFeaturesInArea, PosInGrid
- * Mono branches only (F.Nleft == -1, mvuRight < 0).  PARITY UNPINNED (no reference tests).
+ * Conventional cameras (F.Nleft == -1): monocular and rectified stereo / RGB-D (mvuRight gates :92-98, :1751-1757;
+ * bForward / bBackward level windows :1692-1693, :1728-1733).  The stereo-fisheye branches (Nleft != -1) are out of scope.
+ * PARITY UNPINNED (no reference tests).
  */
 #include "oracle.h"
 
@@ -238,7 +240,7 @@ int orbm_oracle_search_by_bow_kfkf(const uint8_t* d1, int n1, const uint8_t* val
 }
 
 int orbm_oracle_search_by_projection(const OracleFrameGrid* g, const uint8_t* dF, const float* scale_factors, int nlevels,
-                                     int nMP, const uint8_t* in_view, const float* proj_u, const float* proj_v,
+                                     int nMP, const uint8_t* in_view, const float* proj_u, const float* proj_v, const float* proj_ur,
                                      const int32_t* pred_level, const float* view_cos, const float* track_depth,
                                      const uint8_t* dMP, const uint8_t* mp_has_obs, const uint8_t* mp_bad,
                                      float th, int bFar, float thFar, float nnratio,
@@ -250,7 +252,7 @@ int orbm_oracle_search_by_projection(const OracleFrameGrid* g, const uint8_t* dF
     const bool bFactor = th != 1.0;
     std::vector<int> idxs;
     for (int iMP = 0; iMP < nMP; iMP++) {
-        if (!in_view[iMP]) continue;                                // mbTrackInView (mono: no right view)
+        if (!in_view[iMP]) continue;                                // mbTrackInView (Nleft == -1: mbTrackInViewR is never set)
         if (bFar && track_depth[iMP] > thFar) continue;
         if (mp_bad[iMP]) continue;
         const int lvl = pred_level[iMP];
@@ -263,6 +265,10 @@ int orbm_oracle_search_by_projection(const OracleFrameGrid* g, const uint8_t* dF
         for (size_t c = 0; c < idxs.size(); c++) {
             const int idx = idxs[c];
             if (occupied[idx]) continue;                            // F.mvpMapPoints[idx] && Observations()>0
+            if (g->u_right && g->u_right[idx] > 0) {                // F.Nleft == -1 && F.mvuRight[idx]>0 (:92-98)
+                const float er = std::fabs(proj_ur[iMP] - g->u_right[idx]);
+                if (er > r * scale_factors[lvl]) continue;
+            }
             const int dist = hamming256(dmp, dF + (size_t)idx * 32);
             if (dist < bestDist) {
                 bestDist2 = bestDist; bestDist = dist;
@@ -285,12 +291,13 @@ int orbm_oracle_search_by_projection(const OracleFrameGrid* g, const uint8_t* dF
 
 int orbm_oracle_search_by_projection_last(const OracleFrameGrid* g, const uint8_t* dF, const float* angF,
                                           const float* scale_factors, int nlevels,
-                                          int nLast, const uint8_t* last_valid, const float* proj_u, const float* proj_v,
+                                          int nLast, const uint8_t* last_valid, const float* proj_u, const float* proj_v, const float* proj_ur,
                                           const int32_t* last_octave, const float* last_angle,
                                           const uint8_t* dMP, const uint8_t* mp_has_obs,
-                                          float th, int checkOri,
+                                          float th, int level_window, int checkOri,
                                           int32_t* assign, uint8_t* occupied)
 {
+    const bool bForward = level_window == 1, bBackward = level_window == 2;      // :1692-1693, evaluated by the caller
     (void)nlevels;
     Grid grid(g);
     int nmatches = 0;
@@ -305,13 +312,20 @@ int orbm_oracle_search_by_projection_last(const OracleFrameGrid* g, const uint8_
         if (v < g->min_y || v > g->max_y) continue;
         const int oct = last_octave[i];
         const float radius = th * scale_factors[oct];
-        grid.in_area(u, v, radius, oct - 1, oct + 1, idxs);    // mono: neither forward nor backward
+        if (bForward) grid.in_area(u, v, radius, oct, -1, idxs);                 // :1728-1733
+        else if (bBackward) grid.in_area(u, v, radius, 0, oct, idxs);
+        else grid.in_area(u, v, radius, oct - 1, oct + 1, idxs);
         if (idxs.empty()) continue;
         const uint8_t* dmp = dMP + (size_t)i * 32;
         int bestDist = 256, bestIdx2 = -1;
         for (size_t c = 0; c < idxs.size(); c++) {
             const int i2 = idxs[c];
             if (occupied[i2]) continue;
+            if (g->u_right && g->u_right[i2] > 0) {            // CurrentFrame.Nleft == -1 && mvuRight[i2]>0 (:1751-1757)
+                const float ur = proj_ur[i];                    // uv(0) - CurrentFrame.mbf*invzc, a float expression of the caller
+                const float er = std::fabs(ur - g->u_right[i2]);
+                if (er > radius) continue;
+            }
             const int dist = hamming256(dmp, dF + (size_t)i2 * 32);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }

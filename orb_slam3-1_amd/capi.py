@@ -34,7 +34,8 @@ class BowPair(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("n", C.c_int32), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p),
                 ("desc", C.c_void_p), ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
-                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("scale_factors", C.c_void_p), ("n_levels", C.c_int32)]
+                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("scale_factors", C.c_void_p), ("n_levels", C.c_int32),
+                ("u_right", C.c_void_p)]
 
 
 class LbaProblem(C.Structure):
@@ -274,10 +275,10 @@ class Matcher:
         lib.orbm_search_by_bow_kfkf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
                                                 C.c_float, C.c_int, C.c_void_p]
-        lib.orbm_search_by_projection.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int] + [C.c_void_p] * 9 + \
+        lib.orbm_search_by_projection.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int] + [C.c_void_p] * 10 + \
             [C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
-        lib.orbm_search_by_projection_last.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int] + [C.c_void_p] * 7 + \
-            [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        lib.orbm_search_by_projection_last.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int] + [C.c_void_p] * 8 + \
+            [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         h = C.c_void_p()
         _check(lib.orbm_create(device, C.byref(h)))
         self._h = h
@@ -340,23 +341,26 @@ class Matcher:
         f = Frame(len(g["x"]), g["x"].ctypes.data, g["y"].ctypes.data, g["octave"].ctypes.data,
                   angle.ctypes.data if angle is not None else None, desc.ctypes.data,
                   g["min_x"], g["min_y"], g["max_x"], g["max_y"], g.get("cols", 64), g.get("rows", 48),
-                  scale_factors.ctypes.data, len(scale_factors))
+                  scale_factors.ctypes.data, len(scale_factors),
+                  g["u_right"].ctypes.data if g.get("u_right") is not None else None)      # mvuRight: rectified stereo / RGB-D frames
         return f
 
     def SearchByProjection(self, g, dF, scale_factors, mp, th, assign, occupied, far_points=False, th_far=0.0):
         """SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)."""
         f = self._frame(g, dF, scale_factors)
         return _check(lib.orbm_search_by_projection(
-            self._h, C.byref(f), len(mp["u"]), _p(mp["in_view"]), _p(mp["u"]), _p(mp["v"]), _p(mp["level"]),
+            self._h, C.byref(f), len(mp["u"]), _p(mp["in_view"]), _p(mp["u"]), _p(mp["v"]), _p(mp.get("ur")), _p(mp["level"]),
             _p(mp["view_cos"]), _p(mp["depth"]), _p(mp["desc"]), _p(mp["has_obs"]), _p(mp["bad"]),
             th, int(far_points), th_far, self.nnratio, _p(assign), _p(occupied)))
 
     def SearchByProjection_last(self, g, dF, angF, scale_factors, last, th, assign, occupied):
-        """SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono=true)."""
+        """SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono): last["level_window"] carries
+        bForward (1) / bBackward (2), last["ur"] the predicted right-image columns of a rectified-stereo frame."""
         f = self._frame(g, dF, scale_factors, angF)
         return _check(lib.orbm_search_by_projection_last(
-            self._h, C.byref(f), len(last["u"]), _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last["octave"]),
-            _p(last["angle"]), _p(last["desc"]), _p(last["has_obs"]), th, int(self.check_ori), _p(assign), _p(occupied)))
+            self._h, C.byref(f), len(last["u"]), _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last.get("ur")), _p(last["octave"]),
+            _p(last["angle"]), _p(last["desc"]), _p(last["has_obs"]), th, int(last.get("level_window", 0)), int(self.check_ori),
+            _p(assign), _p(occupied)))
 
     def SearchByProjection_kf(self, g, dF, angF, scale_factors, pts, th, orb_dist, assign, occupied):
         """SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (relocalisation)."""
@@ -401,7 +405,7 @@ class Matcher:
 
     class _ProjQuery(C.Structure):
         _fields_ = [("frame", C.c_void_p), ("n_pts", C.c_int32), ("valid", C.c_void_p), ("proj_u", C.c_void_p), ("proj_v", C.c_void_p),
-                    ("level", C.c_void_p), ("view_cos", C.c_void_p), ("track_depth", C.c_void_p), ("mp_bad", C.c_void_p), ("angle", C.c_void_p),
+                    ("proj_ur", C.c_void_p), ("level", C.c_void_p), ("level_window", C.c_int32), ("view_cos", C.c_void_p), ("track_depth", C.c_void_p), ("mp_bad", C.c_void_p), ("angle", C.c_void_p),
                     ("desc_mp", C.c_void_p), ("mp_has_obs", C.c_void_p), ("assign", C.c_void_p), ("occupied", C.c_void_p), ("n_matches", C.c_int32)]
 
     def prepare_last_batch(self, cases):
@@ -415,6 +419,8 @@ class Matcher:
             q = qs[i]
             q.frame = C.addressof(f); q.n_pts = len(last["u"])
             q.valid, q.proj_u, q.proj_v, q.level = (last[k].ctypes.data for k in ("valid", "u", "v", "octave"))
+            q.proj_ur = last["ur"].ctypes.data if last.get("ur") is not None else None
+            q.level_window = int(last.get("level_window", 0))
             q.angle = last["angle"].ctypes.data; q.desc_mp = last["desc"].ctypes.data; q.mp_has_obs = last["has_obs"].ctypes.data
             q.assign = assign.ctypes.data; q.occupied = occ.ctypes.data
         return dict(qs=qs, frames=frames, cases=cases, n=n)

@@ -229,6 +229,7 @@ struct ProjFrameDev {
     float min_x, min_y, max_x, max_y, winv, hinv;
     int32_t n, cols, rows;
     int32_t n_levels = 0;       // > 0: k_proj keeps the scale factors in LDS
+    const float* u_right = nullptr;     // mvuRight (rectified stereo / RGB-D), nullptr for a monocular frame
 };
 
 constexpr unsigned long long kNoKey = ~0ull;
@@ -282,8 +283,10 @@ __device__ unsigned long long d_proj_prof[8];
 
 // Frame::GetFeaturesInArea (src/Frame.cc:744-810) + the candidate loop of SearchByProjection: returns the two
 // smallest candidates in (distance, visiting order) lexicographic order == the reference's best / second best.
+// pt_ur: the point's predicted right-image column (mTrackProjXR, :94 / uv(0) - mbf*invzc, :1753); a candidate that has a
+// right coordinate of its own (mvuRight > 0) is skipped when the two differ by more than the window radius.
 __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float x, float y, float r, int minLevel, int maxLevel,
-                              const unsigned long long* dq, int lane, int* s_col, unsigned long long& best, unsigned long long& second)
+                              float pt_ur, const unsigned long long* dq, int lane, int* s_col, unsigned long long& best, unsigned long long& second)
 {
     best = second = kNoKey;
     const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.winv));
@@ -333,6 +336,10 @@ __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8
             const float distx = F.x[idx] - x, disty = F.y[idx] - y;
             if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
             if (s_occ[idx]) continue;                                        // mvpMapPoints[idx] && Observations()>0
+            if (F.u_right) {                                                 // :92-98, :1751-1757
+                const float ur = F.u_right[idx];
+                if (ur > 0.f && fabsf(pt_ur - ur) > r) continue;
+            }
             const unsigned long long* db = (const unsigned long long*)(F.desc + (size_t)idx * 32);
             const int dist = __popcll(dq[0] ^ db[0]) + __popcll(dq[1] ^ db[1]) + __popcll(dq[2] ^ db[2]) + __popcll(dq[3] ^ db[3]);
             if (dist >= 256) continue;
@@ -356,6 +363,10 @@ __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8
             const float distx = F.x[idx] - x, disty = F.y[idx] - y;
             if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
             if (s_occ[idx]) continue;                                        // mvpMapPoints[idx] && Observations()>0
+            if (F.u_right) {
+                const float ur = F.u_right[idx];
+                if (ur > 0.f && fabsf(pt_ur - ur) > r) continue;
+            }
             const unsigned long long* db = (const unsigned long long*)(F.desc + (size_t)idx * 32);
             const int dist = __popcll(dq[0] ^ db[0]) + __popcll(dq[1] ^ db[1]) + __popcll(dq[2] ^ db[2]) + __popcll(dq[3] ^ db[3]);
             if (dist >= 256) continue;                                       // never beats the initial bestDist = 256
@@ -384,6 +395,7 @@ struct ProjArgs {
     int32_t n_pts;
     const uint8_t* valid;       // in_view (M4) / last_valid (M5)
     const float* u; const float* v;
+    const float* ur;            // mTrackProjXR (M4) / uv(0) - mbf*invzc (M5); read only when F.u_right != nullptr
     const int32_t* level;       // predicted level (M4) / last octave (M5)
     const float* view_cos; const float* depth; const uint8_t* bad;      // M4 only
     const float* angle;         // M5: last frame keypoint angle
@@ -392,6 +404,7 @@ struct ProjArgs {
     int32_t far_points, check_ori;
     int32_t last_frame_mode;    // 0: Frame x map points (:43); 1: window around a projected feature, levels l-1..l+1, image-bounds
                                 // check, rotation histogram (:1676 last frame, :1889 key frame); 2: Sim3 key-frame search (:427, :534)
+    int32_t level_window;       // mode 1: ORBM_LEVELS_AROUND / _FORWARD (bForward, :1729) / _BACKWARD (bBackward, :1731)
     int32_t* assign; uint8_t* occupied;
     int32_t* log_feat; int32_t* log_bin;     // M5 rotation log, capacity n_pts
     int32_t* n_matches;
@@ -454,9 +467,11 @@ __global__ __launch_bounds__(64) void k_proj(const ProjArgs* __restrict__ jobs)
         float* s_y = (float*)(s_dyn + off); off += (size_t)n * 4;
         int32_t* s_oct = (int32_t*)(s_dyn + off); off += (size_t)n * 4;
         int32_t* s_cfeat = (int32_t*)(s_dyn + off); off += (size_t)n * 4;
+        float* s_ur = (float*)(s_dyn + off); off += F.u_right ? (size_t)n * 4 : 0;
         int32_t* s_coff = (int32_t*)(s_dyn + off);
         for (int i = lane; i < n * 8; i += 64) ((uint32_t*)s_desc)[i] = ((const uint32_t*)F.desc)[i];
         for (int i = lane; i < n; i += 64) { s_x[i] = F.x[i]; s_y[i] = F.y[i]; s_oct[i] = F.octave[i]; }
+        if (F.u_right) { for (int i = lane; i < n; i += 64) s_ur[i] = F.u_right[i]; F.u_right = s_ur; }
         const int nfeat_cells = F.cell_off[ncell];
         for (int i = lane; i < nfeat_cells; i += 64) s_cfeat[i] = F.cell_feat[i];
         for (int i = lane; i <= ncell; i += 64) s_coff[i] = F.cell_off[i];
@@ -474,10 +489,11 @@ __global__ __launch_bounds__(64) void k_proj(const ProjArgs* __restrict__ jobs)
     int nmatches = 0, nlog = 0;
     const bool bFactor = A.th != 1.0f;
     // point data is fetched one point ahead: the loads of point i+1 are in flight while point i walks its window
-    struct Pt { int valid, level, bad; float u, v, depth, vcos; unsigned long long d[4]; };
+    struct Pt { int valid, level, bad; float u, v, ur, depth, vcos; unsigned long long d[4]; };
     auto load_pt = [&](int i) {
         Pt p;
         p.valid = A.valid[i]; p.level = A.level[i]; p.u = A.u[i]; p.v = A.v[i];
+        p.ur = A.F.u_right ? A.ur[i] : 0.f;
         p.bad = 0; p.depth = 0.f; p.vcos = 0.f;
         if (!A.last_frame_mode) { p.bad = A.bad[i]; p.depth = A.depth[i]; p.vcos = A.view_cos[i]; }
         const unsigned long long* dp = (const unsigned long long*)(A.desc + (size_t)i * 32);
@@ -509,14 +525,16 @@ __global__ __launch_bounds__(64) void k_proj(const ProjArgs* __restrict__ jobs)
             if (y < F.min_y || y > F.max_y) continue;
             const int oct = cur.level;
             r = A.th * F.scale_factors[oct];
-            minLevel = oct - 1; maxLevel = oct + 1;
+            if (A.level_window == ORBM_LEVELS_FORWARD) { minLevel = oct; maxLevel = -1; }          // :1729
+            else if (A.level_window == ORBM_LEVELS_BACKWARD) { minLevel = 0; maxLevel = oct; }     // :1731
+            else { minLevel = oct - 1; maxLevel = oct + 1; }                                        // :1733, :1938
         } else {
             const int lvl = cur.level;
             r = A.th * F.scale_factors[lvl];                          // :489
             minLevel = lvl - 1; maxLevel = lvl;                        // :509 (KeyFrame::GetFeaturesInArea itself does not filter)
         }
         unsigned long long kb, ks;
-        search_window(F, s_occ, x, y, r, minLevel, maxLevel, cur.d, lane, s_col, kb, ks);
+        search_window(F, s_occ, x, y, r, minLevel, maxLevel, cur.ur, cur.d, lane, s_col, kb, ks);
         if (kb == kNoKey) continue;
         const int bestDist = key_dist(kb), bestIdx = key_idx(kb);
         if ((float)bestDist > A.dist_th) continue;                    // TH_HIGH (:122, :1844), ORBdist (:1967), TH_LOW*ratioHamming (:522)
@@ -1063,6 +1081,9 @@ struct ProjJob {
     const OrbmFrame* f;
     int n_pts;
     const uint8_t* valid; const float* u; const float* v; const int32_t* level;
+    const float* ur = nullptr;      // M4 / M5 with a rectified-stereo frame (f->u_right != NULL); other searches never gate on it
+    int level_window = 0;           // M5: ORBM_LEVELS_*
+    bool stereo_gate = false;       // the entry point is one of the two tracking searches (:92-98, :1751-1757)
     const float* view_cos; const float* depth; const uint8_t* bad;     // mode 0
     const float* angle;                                                  // mode 1
     const uint8_t* desc; const uint8_t* has_obs;
@@ -1079,7 +1100,7 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
     ORBM_HIP(hipSetDevice(m->device));
     Blob blob(m->h_blob);
     const size_t oargs = blob.reserve(sizeof(orbm::ProjArgs) * (size_t)n_jobs);
-    struct Off { size_t x, y, oct, ang, desc, coff, cfeat, sf, valid, u, v, level, vc, dep, bad, angl, dmp, obs, assign, occ, logf, logb, nm; float winv, hinv; };
+    struct Off { size_t x, y, oct, ang, desc, coff, cfeat, sf, uright, ur, valid, u, v, level, vc, dep, bad, angl, dmp, obs, assign, occ, logf, logb, nm; float winv, hinv; };
     std::vector<Off> offs(n_jobs);
     std::vector<int32_t> cell_off, cell_feat;
     size_t max_n = 0;
@@ -1104,6 +1125,9 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
             cell_feat.assign(std::max(f->n, 1), 0);
         } else if ((r = build_grid(f, cell_off, cell_feat, o.winv, o.hinv))) return r;
         if (last_mode == 1 && check_ori && n_pts > 0 && (!q.angle || !f->angle)) return fail(ORBX_ERR_ARG, "job %d: NULL angle arrays", j);
+        const bool gate = q.stereo_gate && f->u_right != nullptr && f->n > 0;
+        if (gate && n_pts > 0 && !q.ur) return fail(ORBX_ERR_ARG, "job %d: the frame has u_right but the points have no proj_ur", j);
+        if (q.level_window < ORBM_LEVELS_AROUND || q.level_window > ORBM_LEVELS_BACKWARD) return fail(ORBX_ERR_ARG, "job %d: bad level_window %d", j, q.level_window);
         for (int i = 0; i < n_pts; i++)
             if (q.valid[i] && (q.level[i] < 0 || q.level[i] >= f->n_levels)) return fail(ORBX_ERR_ARG, "job %d point %d: level %d out of range", j, i, q.level[i]);
         if ((size_t)f->n + 256 > 150 * 1024) return fail(ORBX_ERR_ARG, "frame with %d features exceeds the LDS occupancy table", f->n);
@@ -1116,6 +1140,8 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
         o.coff = blob.put(cell_off.data(), sizeof(int32_t) * cell_off.size());
         o.cfeat = blob.put(cell_feat.data(), sizeof(int32_t) * cell_feat.size());
         o.sf = blob.put(f->scale_factors, sizeof(float) * f->n_levels);
+        o.uright = blob.put(gate ? f->u_right : nullptr, gate ? sizeof(float) * n : 0);
+        o.ur = blob.put(gate ? q.ur : nullptr, gate ? sizeof(float) * n_pts : 0);
         o.valid = blob.put(q.valid, n_pts); o.u = blob.put(q.u, sizeof(float) * n_pts); o.v = blob.put(q.v, sizeof(float) * n_pts);
         o.level = blob.put(q.level, sizeof(int32_t) * n_pts);
         o.vc = blob.put(q.view_cos, q.view_cos ? sizeof(float) * n_pts : 0); o.dep = blob.put(q.depth, q.depth ? sizeof(float) * n_pts : 0);
@@ -1147,6 +1173,9 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
         A.F.scale_factors = (const float*)(base + o.sf);
         A.F.min_x = f->min_x; A.F.min_y = f->min_y; A.F.max_x = f->max_x; A.F.max_y = f->max_y; A.F.winv = o.winv; A.F.hinv = o.hinv;
         A.F.n = f->n; A.F.cols = f->grid_cols; A.F.rows = f->grid_rows; A.F.n_levels = f->n_levels;
+        const bool gate = q.stereo_gate && f->u_right != nullptr && f->n > 0;
+        A.F.u_right = gate ? (const float*)(base + o.uright) : nullptr;
+        A.ur = (const float*)(base + o.ur); A.level_window = q.level_window;
         A.n_pts = q.n_pts; A.valid = base + o.valid; A.u = (const float*)(base + o.u); A.v = (const float*)(base + o.v);
         A.level = (const int32_t*)(base + o.level); A.view_cos = (const float*)(base + o.vc); A.depth = (const float*)(base + o.dep);
         A.bad = base + o.bad; A.angle = (const float*)(base + o.angl); A.desc = base + o.dmp; A.has_obs = q.has_obs ? base + o.obs : nullptr;
@@ -1159,7 +1188,7 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
     size_t max_cells = 0;
     for (int j = 0; j < n_jobs; j++) max_cells = std::max(max_cells, (size_t)jobs[j].f->grid_cols * jobs[j].f->grid_rows);
     const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64);
-    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 48 + (max_cells + 1) * 4 + 64;
+    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (max_cells + 1) * 4 + 64;     // 52: with u_right staged
     const bool stage = lds_full <= 150 * 1024;
     const size_t lds = stage ? lds_full : lds_occ;
     for (int j = 0; j < n_jobs; j++) args[j].lds_frame = stage ? 1 : 0;
@@ -1196,9 +1225,11 @@ static int run_projection(orbm_matcher* m, const OrbmFrame* f, int last_mode, in
                           const float* u, const float* v, const int32_t* level, const float* view_cos, const float* depth,
                           const uint8_t* bad, const float* angle, const uint8_t* desc, const uint8_t* has_obs,
                           float th, int far_points, float th_far, float nnratio, int check_ori,
-                          int32_t* assign, uint8_t* occupied, float dist_th = (float)orbm::TH_HIGH)
+                          int32_t* assign, uint8_t* occupied, float dist_th = (float)orbm::TH_HIGH,
+                          const float* ur = nullptr, int level_window = 0, bool stereo_gate = false)
 {
     ProjJob q;
+    q.ur = ur; q.level_window = level_window; q.stereo_gate = stereo_gate;
     q.f = f; q.n_pts = n_pts; q.valid = valid; q.u = u; q.v = v; q.level = level; q.view_cos = view_cos; q.depth = depth; q.bad = bad;
     q.angle = angle; q.desc = desc; q.has_obs = has_obs; q.assign = assign; q.occupied = occupied; q.n_matches = 0;
     const int r = run_projection_jobs(m, &q, 1, last_mode, th, far_points, th_far, nnratio, check_ori, dist_th);
@@ -1420,26 +1451,28 @@ int orbm_search_by_bow_kfkf(orbm_matcher* m,
 }
 
 int orbm_search_by_projection(orbm_matcher* m, const OrbmFrame* f,
-                              int n_mp, const uint8_t* in_view, const float* proj_u, const float* proj_v,
+                              int n_mp, const uint8_t* in_view, const float* proj_u, const float* proj_v, const float* proj_ur,
                               const int32_t* pred_level, const float* view_cos, const float* track_depth,
                               const uint8_t* desc_mp, const uint8_t* mp_has_obs, const uint8_t* mp_bad,
                               float th, int far_points, float th_far, float nnratio,
                               int32_t* assign, uint8_t* occupied)
 {
     return run_projection(m, f, 0, n_mp, in_view, proj_u, proj_v, pred_level, view_cos, track_depth, mp_bad, nullptr,
-                          desc_mp, mp_has_obs, th, far_points, th_far, nnratio, 0, assign, occupied);
+                          desc_mp, mp_has_obs, th, far_points, th_far, nnratio, 0, assign, occupied, (float)orbm::TH_HIGH,
+                          proj_ur, 0, true);
 }
 
 int orbm_search_by_projection_last(orbm_matcher* m, const OrbmFrame* cur,
-                                   int n_last, const uint8_t* last_valid, const float* proj_u, const float* proj_v,
+                                   int n_last, const uint8_t* last_valid, const float* proj_u, const float* proj_v, const float* proj_ur,
                                    const int32_t* last_octave, const float* last_angle,
                                    const uint8_t* desc_mp, const uint8_t* mp_has_obs,
-                                   float th, int check_orientation,
+                                   float th, int level_window, int check_orientation,
                                    int32_t* assign, uint8_t* occupied)
 {
     if (n_last > 0 && !mp_has_obs) return fail(ORBX_ERR_ARG, "NULL mp_has_obs");
     return run_projection(m, cur, 1, n_last, last_valid, proj_u, proj_v, last_octave, nullptr, nullptr, nullptr, last_angle,
-                          desc_mp, mp_has_obs, th, 0, 0.f, 0.f, check_orientation, assign, occupied);
+                          desc_mp, mp_has_obs, th, 0, 0.f, 0.f, check_orientation, assign, occupied, (float)orbm::TH_HIGH,
+                          proj_ur, level_window, true);
 }
 
 // Batched forms: n_frames independent (frame, points) problems in ONE launch, a wave per frame.
@@ -1451,6 +1484,7 @@ static int run_projection_batch(orbm_matcher* m, OrbmProjQuery* q, int n_frames,
     for (int j = 0; j < n_frames; j++) {
         ProjJob& p = jobs[j];
         p.f = q[j].frame; p.n_pts = q[j].n_pts; p.valid = q[j].valid; p.u = q[j].proj_u; p.v = q[j].proj_v; p.level = q[j].level;
+        p.ur = q[j].proj_ur; p.level_window = mode == 1 ? q[j].level_window : 0; p.stereo_gate = true;
         p.view_cos = q[j].view_cos; p.depth = q[j].track_depth; p.bad = q[j].mp_bad; p.angle = q[j].angle; p.desc = q[j].desc_mp;
         p.has_obs = q[j].mp_has_obs; p.assign = q[j].assign; p.occupied = q[j].occupied; p.n_matches = 0;
         if (!p.f) return fail(ORBX_ERR_ARG, "query %d: NULL frame", j);

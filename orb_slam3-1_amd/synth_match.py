@@ -29,8 +29,22 @@ def make_frame_features(seed, n=1000, w=752, h=480, nlevels=8, cluster=True):
     return g, desc, ang, scale
 
 
-def make_projection_case(seed, n=1000, n_mp=900, nlevels=8):
-    """Inputs of SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (reference src/ORBmatcher.cc:43-213)."""
+def _add_stereo(seed, g, tgt, u, pts, stereo_frac):
+    """Rectified-stereo side of a tracking search (reference src/ORBmatcher.cc:92-98, :1751-1757): a share of the frame's
+    features gets a right-image column (mvuRight > 0, the rest -1) and every point a predicted one (mTrackProjXR /
+    uv(0) - mbf*invzc) that lands on both sides of the window radius.  Drawn from its own stream: the monocular arrays of
+    the case stay what they are without it."""
+    rs = np.random.RandomState(86420 + seed)
+    n = len(g["x"])
+    g["u_right"] = np.where(rs.uniform(size=n) < stereo_frac, np.maximum(g["x"] - rs.uniform(2, 40, n), 0.5), -1.0).astype(np.float32)
+    err = rs.normal(0, 1.0, len(tgt)) * np.where(rs.uniform(size=len(tgt)) < 0.6, 2.0, 15.0)
+    ur = np.where(g["u_right"][tgt] > 0, g["u_right"][tgt] + err, u - rs.uniform(2, 40, len(tgt)))
+    pts["ur"] = ur.astype(np.float32)
+
+
+def make_projection_case(seed, n=1000, n_mp=900, nlevels=8, stereo_frac=None):
+    """Inputs of SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (reference src/ORBmatcher.cc:43-213);
+    stereo_frac: share of the frame's features with a right-image coordinate (None = monocular frame, no mvuRight)."""
     rs = np.random.RandomState(777 + seed)
     g, dF, angF, scale = make_frame_features(seed, n, nlevels=nlevels)
     tgt = rs.randint(0, n, n_mp)
@@ -51,11 +65,14 @@ def make_projection_case(seed, n=1000, n_mp=900, nlevels=8):
               has_obs=(rs.uniform(size=n_mp) < 0.9).astype(np.uint8), bad=(rs.uniform(size=n_mp) < 0.03).astype(np.uint8))
     occupied = (rs.uniform(size=n) < 0.1).astype(np.uint8)
     assign = np.where(occupied > 0, 100000 + np.arange(n), -1).astype(np.int32)
+    if stereo_frac is not None:
+        _add_stereo(seed, g, tgt, u, mp, stereo_frac)
     return g, dF, angF, scale, mp, assign, occupied
 
 
-def make_last_frame_case(seed, n=1000, n_last=900, nlevels=8):
-    """Inputs of SearchByProjection(Frame& cur, const Frame& last, th, bMono) (reference src/ORBmatcher.cc:1676-1887)."""
+def make_last_frame_case(seed, n=1000, n_last=900, nlevels=8, stereo_frac=None, level_window=0):
+    """Inputs of SearchByProjection(Frame& cur, const Frame& last, th, bMono) (reference src/ORBmatcher.cc:1676-1887);
+    stereo_frac as above, level_window 1 = bForward / 2 = bBackward (:1692-1693; only a stereo caller, !bMono, sets them)."""
     rs = np.random.RandomState(999 + seed)
     g, dF, angF, scale = make_frame_features(seed + 50, n, nlevels=nlevels)
     tgt = rs.randint(0, n, n_last)
@@ -72,6 +89,10 @@ def make_last_frame_case(seed, n=1000, n_last=900, nlevels=8):
                 has_obs=(rs.uniform(size=n_last) < 0.8).astype(np.uint8))
     occupied = np.zeros(n, np.uint8)
     assign = np.full(n, -1, np.int32)
+    if stereo_frac is not None:
+        _add_stereo(seed + 1000, g, tgt, u, last, stereo_frac)
+    if level_window:
+        last["level_window"] = int(level_window)
     return g, dF, angF, scale, last, assign, occupied
 
 

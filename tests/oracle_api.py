@@ -29,7 +29,7 @@ class FeatVec(C.Structure):
 class FrameGrid(C.Structure):
     _fields_ = [("n", C.c_int32), ("x", C.c_void_p), ("y", C.c_void_p), ("octave", C.c_void_p),
                 ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
-                ("cols", C.c_int32), ("rows", C.c_int32)]
+                ("cols", C.c_int32), ("rows", C.c_int32), ("u_right", C.c_void_p)]
 
 
 class LbaProblem(C.Structure):
@@ -48,7 +48,7 @@ class LbaStats(C.Structure):
 
 
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 class Oracle:
@@ -87,12 +87,12 @@ class Oracle:
                                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(FeatVec),
                                                      C.c_float, C.c_int, C.c_void_p]
         L.orbm_oracle_search_by_projection.argtypes = [C.POINTER(FrameGrid), C.c_void_p, C.c_void_p, C.c_int,
-                                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orbm_oracle_search_by_projection_last.argtypes = [C.POINTER(FrameGrid), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                            C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+                                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                            C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.lba_oracle_solve.argtypes = [C.POINTER(LbaProblem), C.c_void_p, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LbaStats)]
 
@@ -131,22 +131,22 @@ class Oracle:
     @staticmethod
     def _grid(g):
         s = FrameGrid(len(g["x"]), _p(g["x"]), _p(g["y"]), _p(g["octave"]),
-                      g["min_x"], g["min_y"], g["max_x"], g["max_y"], g.get("cols", 64), g.get("rows", 48))
+                      g["min_x"], g["min_y"], g["max_x"], g["max_y"], g.get("cols", 64), g.get("rows", 48), _p(g.get("u_right")))
         return s
 
     def search_by_projection(self, g, dF, scale_factors, mp, th, nnratio, assign, occupied, b_far=False, th_far=0.0):
         s = self._grid(g)
         return self.lib.orbm_oracle_search_by_projection(
             C.byref(s), _p(dF), _p(scale_factors), len(scale_factors), len(mp["u"]),
-            _p(mp["in_view"]), _p(mp["u"]), _p(mp["v"]), _p(mp["level"]), _p(mp["view_cos"]), _p(mp["depth"]),
+            _p(mp["in_view"]), _p(mp["u"]), _p(mp["v"]), _p(mp.get("ur")), _p(mp["level"]), _p(mp["view_cos"]), _p(mp["depth"]),
             _p(mp["desc"]), _p(mp["has_obs"]), _p(mp["bad"]), th, int(b_far), th_far, nnratio, _p(assign), _p(occupied))
 
     def search_by_projection_last(self, g, dF, angF, scale_factors, last, th, check_ori, assign, occupied):
         s = self._grid(g)
         return self.lib.orbm_oracle_search_by_projection_last(
             C.byref(s), _p(dF), _p(angF), _p(scale_factors), len(scale_factors), len(last["u"]),
-            _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last["octave"]), _p(last["angle"]),
-            _p(last["desc"]), _p(last["has_obs"]), th, int(check_ori), _p(assign), _p(occupied))
+            _p(last["valid"]), _p(last["u"]), _p(last["v"]), _p(last.get("ur")), _p(last["octave"]), _p(last["angle"]),
+            _p(last["desc"]), _p(last["has_obs"]), th, int(last.get("level_window", 0)), int(check_ori), _p(assign), _p(occupied))
 
     def search_by_projection_kf(self, g, dF, angF, scale_factors, pts, th, orb_dist, check_ori, assign, occupied):
         s = self._grid(g)

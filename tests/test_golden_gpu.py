@@ -44,6 +44,19 @@ def test_matcher_and_lba_golden(pkg, synth):
         m2.close()
         assert n2 == int(g2["n"])
         np.testing.assert_array_equal(assign, g2["assign"]); np.testing.assert_array_equal(occ, g2["occupied"])
+        g3 = np.load(os.path.join(GOLDEN, "proj_stereo_300.npz"))       # rectified-stereo gate, src/ORBmatcher.cc:92-98
+        gr, dF, angF, scale, mp, assign, occ = sm.make_projection_case(46, n=300, n_mp=250, stereo_frac=0.5)
+        m2 = pkg.Matcher(0.8, True)
+        n3 = m2.SearchByProjection(gr, dF, scale, mp, 3.0, assign, occ)
+        assert n3 == int(g3["n"])
+        np.testing.assert_array_equal(assign, g3["assign"]); np.testing.assert_array_equal(occ, g3["occupied"])
+        for lw, name in ((1, "forward"), (2, "backward")):                 # !bMono level windows + ur gate, :1692-1757
+            g4 = np.load(os.path.join(GOLDEN, "proj_last_stereo_%s_300.npz" % name))
+            gr, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(47, n=300, n_last=250, stereo_frac=0.5, level_window=lw)
+            n4 = m2.SearchByProjection_last(gr, dF, angF, scale, last, 15.0, assign, occ)
+            assert n4 == int(g4["n"])
+            np.testing.assert_array_equal(assign, g4["assign"]); np.testing.assert_array_equal(occ, g4["occupied"])
+        m2.close()
     finally:
         m.close()
     g = np.load(os.path.join(GOLDEN, "lba_5kf_60mp.npz"))

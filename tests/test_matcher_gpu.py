@@ -98,6 +98,65 @@ def test_search_by_projection(pkg, oracle, sm, seed, th, far):
     np.testing.assert_array_equal(o1, o0)
 
 
+@pytest.mark.parametrize("seed,th,far,frac", [(4, 1.0, False, 0.0), (5, 3.0, False, 0.5), (6, 3.0, True, 1.0), (7, 15.0, False, 0.5),
+                                              (8, 1.0, False, 1.0)])
+def test_search_by_projection_rectified_stereo(pkg, oracle, sm, seed, th, far, frac):
+    """the mvuRight gate of src/ORBmatcher.cc:92-98 (F.Nleft == -1 && F.mvuRight[idx] > 0) at stereo shares 0 / 0.5 / 1"""
+    g, dF, angF, scale, mp, assign, occ = sm.make_projection_case(seed, stereo_frac=frac)
+    a0, o0 = assign.copy(), occ.copy()
+    n0 = oracle.search_by_projection(g, dF, scale, mp, th, 0.8, a0, o0, b_far=far, th_far=20.0)
+    gm = {k: v for k, v in g.items() if k != "u_right"}
+    am, om = assign.copy(), occ.copy()
+    nm = oracle.search_by_projection(gm, dF, scale, mp, th, 0.8, am, om, b_far=far, th_far=20.0)
+    m = pkg.Matcher(0.8, True)
+    try:
+        a1, o1 = assign.copy(), occ.copy()
+        n1 = m.SearchByProjection(g, dF, scale, mp, th, a1, o1, far_points=far, th_far=20.0)
+        a2, o2 = assign.copy(), occ.copy()
+        n2 = m.SearchByProjection(gm, dF, scale, mp, th, a2, o2, far_points=far, th_far=20.0)     # mono results unchanged
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 100
+    np.testing.assert_array_equal(a1, a0); np.testing.assert_array_equal(o1, o0)
+    assert n2 == nm
+    np.testing.assert_array_equal(a2, am)
+    assert (frac == 0.0) == np.array_equal(a0, am)      # the gate bites whenever some feature has a right coordinate
+
+
+@pytest.mark.parametrize("seed,th,ori,frac,lw", [(3, 15.0, True, 0.0, 0), (4, 15.0, True, 0.5, 0), (5, 7.0, True, 1.0, 0),
+                                                 (6, 15.0, True, 0.5, 1), (7, 15.0, True, 0.5, 2), (8, 7.0, False, 1.0, 1),
+                                                 (9, 15.0, True, 1.0, 2), (10, 15.0, True, None, 1), (11, 15.0, True, None, 2)])
+def test_search_by_projection_last_frame_stereo(pkg, oracle, sm, seed, th, ori, frac, lw):
+    """!bMono: the ur gate (:1751-1757) and the forward / backward level windows (:1692-1693, :1728-1733)"""
+    g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(seed, stereo_frac=frac, level_window=lw)
+    a0, o0 = assign.copy(), occ.copy()
+    n0 = oracle.search_by_projection_last(g, dF, angF, scale, last, th, ori, a0, o0)
+    m = pkg.Matcher(0.9, ori)
+    try:
+        a1, o1 = assign.copy(), occ.copy()
+        n1 = m.SearchByProjection_last(g, dF, angF, scale, last, th, a1, o1)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 60
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(o1, o0)
+
+
+def test_projection_stereo_argument_errors(pkg, sm):
+    """a stereo frame without the points' right columns is refused, never searched as if it were monocular"""
+    g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(2, n=200, n_last=100, stereo_frac=0.5)
+    bad = {k: v for k, v in last.items() if k != "ur"}
+    m = pkg.Matcher(0.9, True)
+    try:
+        with pytest.raises(pkg.OrbxError):
+            m.SearchByProjection_last(g, dF, angF, scale, bad, 15.0, assign.copy(), occ.copy())
+        bad = dict(last); bad["level_window"] = 3
+        with pytest.raises(pkg.OrbxError):
+            m.SearchByProjection_last(g, dF, angF, scale, bad, 15.0, assign.copy(), occ.copy())
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("seed,th,ori", [(0, 7.0, True), (1, 15.0, True), (2, 15.0, False)])
 def test_search_by_projection_last_frame(pkg, oracle, sm, seed, th, ori):
     g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(seed)
@@ -202,8 +261,9 @@ def test_search_for_initialization(pkg, oracle, sm, seed, win, ratio, ori):
 def test_search_by_projection_last_batch(pkg, oracle, sm):
     """a wave per frame: the batched launch equals the per-frame oracle runs (ragged sizes, an empty query)"""
     cases, refs = [], []
-    for i, (n, nl) in enumerate(((1000, 900), (400, 700), (1000, 0), (1500, 1200), (64, 50))):
-        g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(30 + i, n=n, n_last=max(nl, 1))
+    # ragged sizes, an empty query, and per-query stereo shares / level windows (every stream has its own motion)
+    for i, (n, nl, frac, lw) in enumerate(((1000, 900, None, 0), (400, 700, 0.5, 1), (1000, 0, None, 0), (1500, 1200, 1.0, 2), (64, 50, 0.5, 0))):
+        g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(30 + i, n=n, n_last=max(nl, 1), stereo_frac=frac, level_window=lw)
         if nl == 0:
             last = {k: v[:0].copy() for k, v in last.items()}
         a0, o0 = assign.copy(), occ.copy()

@@ -16,7 +16,7 @@ from oracle_api import (IMU_DTYPE, KP_DTYPE, Oracle, build_oracle, oracle_inerti
 
 synth = importlib.import_module("orb_slam3-1_amd.synth")
 sm = importlib.import_module("orb_slam3-1_amd.synth_match")
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("ORB_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))    # set it to regenerate into a scratch directory
 
 
 def main():
@@ -70,6 +70,14 @@ def main():
     ir = oracle_inertial_solve(o, iw)
     np.savez_compressed(os.path.join(OUT, "inertial_5kf_120mp.npz"), iterations=ir["stats"]["iterations"], trials=ir["stats"]["trials"],
                         chi2_final=ir["stats"]["chi2_final"], Rwb=ir["Rwb"], twb=ir["twb"], vel=ir["vel"], bg=ir["bg"], ba=ir["ba"], points=ir["points"])
+    # the rectified-stereo branches of the two tracking searches (src/ORBmatcher.cc:92-98, :1692-1693, :1728-1733, :1751-1757)
+    gr, dF, angF, scale, mp, assign, occ = sm.make_projection_case(46, n=300, n_mp=250, stereo_frac=0.5)
+    n = o.search_by_projection(gr, dF, scale, mp, 3.0, 0.8, assign, occ)
+    np.savez_compressed(os.path.join(OUT, "proj_stereo_300.npz"), n=n, assign=assign, occupied=occ)
+    for lw, name in ((1, "forward"), (2, "backward")):
+        gr, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(47, n=300, n_last=250, stereo_frac=0.5, level_window=lw)
+        n = o.search_by_projection_last(gr, dF, angF, scale, last, 15.0, True, assign, occ)
+        np.savez_compressed(os.path.join(OUT, "proj_last_stereo_%s_300.npz" % name), n=n, assign=assign, occupied=occ)
     print("golden fixtures written to", OUT)
 
 
