@@ -154,6 +154,8 @@ private:
 #ifdef ORBSLAM3_HIP_WITH_REFERENCE
 
 #include <algorithm>
+#include <cassert>
+#include <cmath>
 #include <list>
 #include <map>
 #include <mutex>
@@ -164,6 +166,8 @@ private:
 #include "KeyFrame.h"
 #include "Map.h"
 #include "MapPoint.h"
+#include "ORBmatcher.h"     // the reference entry points the adapters fall back to for rigs outside the accelerated path
+#include "Optimizer.h"
 
 namespace ORB_SLAM3 {
 
@@ -561,73 +565,94 @@ private:
 
 // Drop-in for Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&, int&, int&, int&) (src/Optimizer.cc:1116-1498).
 // The pointer-graph walk and the map write-back are the reference's own logic; only the g2o part is replaced.
-inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges)
-{
-    (void)num_MPs;      // never assigned by the reference overload either (SURVEY.md B14)
-    std::list<KeyFrame*> lLocalKeyFrames;
-    lLocalKeyFrames.push_back(pKF);
-    pKF->mnBALocalForKF = pKF->mnId;
-    Map* pCurrentMap = pKF->GetMap();
-    const std::vector<KeyFrame*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
-    for (KeyFrame* pKFi : vNeighKFs) {
-        pKFi->mnBALocalForKF = pKF->mnId;
-        if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lLocalKeyFrames.push_back(pKFi);
-    }
-    num_fixedKF = 0;
+//
+// LbaGraph = what the walk produces: the reference's three lists plus the flattened problem in g2o's vertex / edge order
+// (B1 of SURVEY.md 8(a)).  Kept separate from the solve so that the walk can be exercised without a device
+// (tests/test_shim_reference_typed.py runs it on a toy map built from stand-in types).
+struct LbaGraph {
+    std::list<KeyFrame*> lLocalKeyFrames, lFixedCameras;
     std::list<MapPoint*> lLocalMapPoints;
-    for (KeyFrame* pKFi : lLocalKeyFrames) {
-        if (pKFi->mnId == pMap->GetInitKFid()) num_fixedKF = 1;
-        for (MapPoint* pMP : pKFi->GetMapPointMatches())
-            if (pMP && !pMP->isBad() && pMP->GetMap() == pCurrentMap && pMP->mnBALocalForKF != pKF->mnId) {
-                lLocalMapPoints.push_back(pMP);
-                pMP->mnBALocalForKF = pKF->mnId;
-            }
-    }
-    std::list<KeyFrame*> lFixedCameras;
-    for (MapPoint* pMP : lLocalMapPoints)
-        for (auto& obs : pMP->GetObservations()) {
-            KeyFrame* pKFi = obs.first;
-            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
-                pKFi->mnBAFixedForKF = pKF->mnId;
-                if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) lFixedCameras.push_back(pKFi);
-            }
-        }
-    num_fixedKF = (int)lFixedCameras.size() + num_fixedKF;
-    if (num_fixedKF == 0) return;                                                   // :1182-1186
-
-    // vertices in ascending id (g2o sorts active vertices by id, sparse_optimizer.cpp:482-487)
-    std::vector<KeyFrame*> kfs(lLocalKeyFrames.begin(), lLocalKeyFrames.end());
-    kfs.insert(kfs.end(), lFixedCameras.begin(), lFixedCameras.end());
-    std::sort(kfs.begin(), kfs.end(), [](KeyFrame* a, KeyFrame* b) { return a->mnId < b->mnId; });
-    std::vector<MapPoint*> mps(lLocalMapPoints.begin(), lLocalMapPoints.end());
-    std::sort(mps.begin(), mps.end(), [](MapPoint* a, MapPoint* b) { return a->mnId < b->mnId; });
+    std::vector<KeyFrame*> kfs;                 // all pose vertices, ascending mnId (g2o sorts active vertices by id, sparse_optimizer.cpp:482-487)
+    std::vector<MapPoint*> mps;                 // all point vertices, ascending mnId (vertex id = mnId + maxKFid + 1, :1287)
     std::map<KeyFrame*, int> kfIndex;
     std::map<MapPoint*, int> mpIndex;
-    std::vector<double> q(kfs.size() * 4), t(kfs.size() * 3), X(mps.size() * 3);
-    std::vector<uint8_t> fixed(kfs.size());
-    for (size_t i = 0; i < kfs.size(); i++) {
-        kfIndex[kfs[i]] = (int)i;
-        const Sophus::SE3<float> Tcw = kfs[i]->GetPose();
-        const Eigen::Quaterniond qd = Tcw.unit_quaternion().cast<double>();
-        const Eigen::Vector3d td = Tcw.translation().cast<double>();
-        q[4 * i] = qd.x(); q[4 * i + 1] = qd.y(); q[4 * i + 2] = qd.z(); q[4 * i + 3] = qd.w();
-        t[3 * i] = td.x(); t[3 * i + 1] = td.y(); t[3 * i + 2] = td.z();
-        fixed[i] = kfs[i]->mnBALocalForKF != pKF->mnId || kfs[i]->mnId == pMap->GetInitKFid();     // :1220, :1237
-    }
-    num_OptKF = (int)lLocalKeyFrames.size();
-    for (size_t i = 0; i < mps.size(); i++) {
-        mpIndex[mps[i]] = (int)i;
-        const Eigen::Vector3d Xd = mps[i]->GetWorldPos().cast<double>();
-        X[3 * i] = Xd.x(); X[3 * i + 1] = Xd.y(); X[3 * i + 2] = Xd.z();
-    }
-    // edges in addEdge order: map points in list order, observations in map order (:1278-1401)
-    std::vector<int32_t> ePoint, ePose;
+    std::vector<double> q, t, X;                // poses [n][4] qx qy qz qw, [n][3]; points [n][3]
+    std::vector<uint8_t> fixed;
+    std::vector<int32_t> ePoint, ePose;         // edges in addEdge order: map points in list order, observations in map order (:1278-1401)
     std::vector<double> eObs, eW;
     std::vector<uint8_t> eStereo;
     std::vector<KeyFrame*> eKF;
     std::vector<MapPoint*> eMP;
     double fx = 0, fy = 0, cx = 0, cy = 0, bf = 0;
-    for (MapPoint* pMP : lLocalMapPoints)
+    int num_fixedKF = 0, num_OptKF = 0, num_edges = 0;
+};
+
+// true when every camera of the window is a plain pinhole without a second (fisheye-rig) camera: the only edges the device
+// builds are EdgeSE3ProjectXYZ with Pinhole::project and EdgeStereoSE3ProjectXYZ (src/Optimizer.cc:1305-1364); windows with
+// EdgeSE3ProjectXYZToBody (:1366-1396) or KannalaBrandt8 cameras stay with the reference.
+inline bool LbaWindowIsPinhole(KeyFrame* pKF)
+{
+    if (pKF->mpCamera2 || !pKF->mpCamera || pKF->mpCamera->GetType() != GeometricCamera::CAM_PINHOLE) return false;
+    for (KeyFrame* pKFi : pKF->GetVectorCovisibleKeyFrames())
+        if (pKFi->mpCamera2 || !pKFi->mpCamera || pKFi->mpCamera->GetType() != GeometricCamera::CAM_PINHOLE) return false;
+    return true;
+}
+
+// src/Optimizer.cc:1118-1404.  Returns false on the reference's silent early return (no fixed key frame, :1182-1186); the
+// counters are then what the reference leaves in its out-parameters at that point.
+inline bool LocalBundleAdjustmentGraph(KeyFrame* pKF, Map* pMap, LbaGraph& g)
+{
+    g.lLocalKeyFrames.push_back(pKF);
+    pKF->mnBALocalForKF = pKF->mnId;
+    Map* pCurrentMap = pKF->GetMap();
+    const std::vector<KeyFrame*> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+    for (KeyFrame* pKFi : vNeighKFs) {
+        pKFi->mnBALocalForKF = pKF->mnId;
+        if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) g.lLocalKeyFrames.push_back(pKFi);
+    }
+    g.num_fixedKF = 0;
+    for (KeyFrame* pKFi : g.lLocalKeyFrames) {
+        if (pKFi->mnId == pMap->GetInitKFid()) g.num_fixedKF = 1;
+        for (MapPoint* pMP : pKFi->GetMapPointMatches())
+            if (pMP && !pMP->isBad() && pMP->GetMap() == pCurrentMap && pMP->mnBALocalForKF != pKF->mnId) {
+                g.lLocalMapPoints.push_back(pMP);
+                pMP->mnBALocalForKF = pKF->mnId;
+            }
+    }
+    for (MapPoint* pMP : g.lLocalMapPoints)
+        for (auto& obs : pMP->GetObservations()) {
+            KeyFrame* pKFi = obs.first;
+            if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) {
+                pKFi->mnBAFixedForKF = pKF->mnId;
+                if (!pKFi->isBad() && pKFi->GetMap() == pCurrentMap) g.lFixedCameras.push_back(pKFi);
+            }
+        }
+    g.num_fixedKF = (int)g.lFixedCameras.size() + g.num_fixedKF;
+    if (g.num_fixedKF == 0) return false;                                           // :1182-1186
+
+    g.kfs.assign(g.lLocalKeyFrames.begin(), g.lLocalKeyFrames.end());
+    g.kfs.insert(g.kfs.end(), g.lFixedCameras.begin(), g.lFixedCameras.end());
+    std::sort(g.kfs.begin(), g.kfs.end(), [](KeyFrame* a, KeyFrame* b) { return a->mnId < b->mnId; });
+    g.mps.assign(g.lLocalMapPoints.begin(), g.lLocalMapPoints.end());
+    std::sort(g.mps.begin(), g.mps.end(), [](MapPoint* a, MapPoint* b) { return a->mnId < b->mnId; });
+    g.q.resize(g.kfs.size() * 4); g.t.resize(g.kfs.size() * 3); g.X.resize(g.mps.size() * 3);
+    g.fixed.resize(g.kfs.size());
+    for (size_t i = 0; i < g.kfs.size(); i++) {
+        g.kfIndex[g.kfs[i]] = (int)i;
+        const Sophus::SE3<float> Tcw = g.kfs[i]->GetPose();
+        const Eigen::Quaterniond qd = Tcw.unit_quaternion().cast<double>();
+        const Eigen::Vector3d td = Tcw.translation().cast<double>();
+        g.q[4 * i] = qd.x(); g.q[4 * i + 1] = qd.y(); g.q[4 * i + 2] = qd.z(); g.q[4 * i + 3] = qd.w();
+        g.t[3 * i] = td.x(); g.t[3 * i + 1] = td.y(); g.t[3 * i + 2] = td.z();
+        g.fixed[i] = g.kfs[i]->mnBALocalForKF != pKF->mnId || g.kfs[i]->mnId == pMap->GetInitKFid();     // :1220, :1237
+    }
+    g.num_OptKF = (int)g.lLocalKeyFrames.size();                                    // :1227
+    for (size_t i = 0; i < g.mps.size(); i++) {
+        g.mpIndex[g.mps[i]] = (int)i;
+        const Eigen::Vector3d Xd = g.mps[i]->GetWorldPos().cast<double>();
+        g.X[3 * i] = Xd.x(); g.X[3 * i + 1] = Xd.y(); g.X[3 * i + 2] = Xd.z();
+    }
+    for (MapPoint* pMP : g.lLocalMapPoints)
         for (auto& obs : pMP->GetObservations()) {
             KeyFrame* pKFi = obs.first;
             if (pKFi->isBad() || pKFi->GetMap() != pCurrentMap) continue;
@@ -635,27 +660,39 @@ inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap,
             if (leftIndex == -1) continue;
             const cv::KeyPoint& kpUn = pKFi->mvKeysUn[leftIndex];
             const float ur = pKFi->mvuRight[leftIndex];
-            ePoint.push_back(mpIndex[pMP]); ePose.push_back(kfIndex[pKFi]);
-            eObs.push_back(kpUn.pt.x); eObs.push_back(kpUn.pt.y); eObs.push_back(ur >= 0 ? (double)ur : -1.0);
-            eW.push_back((double)pKFi->mvInvLevelSigma2[kpUn.octave]);
-            eStereo.push_back(ur >= 0);
-            eKF.push_back(pKFi); eMP.push_back(pMP);
-            fx = pKFi->fx; fy = pKFi->fy; cx = pKFi->cx; cy = pKFi->cy; bf = pKFi->mbf;
+            g.ePoint.push_back(g.mpIndex.at(pMP)); g.ePose.push_back(g.kfIndex.at(pKFi));      // .at(): an observer outside the window is a bug, not vertex 0
+            g.eObs.push_back(kpUn.pt.x); g.eObs.push_back(kpUn.pt.y); g.eObs.push_back(ur >= 0 ? (double)ur : -1.0);
+            g.eW.push_back((double)pKFi->mvInvLevelSigma2[kpUn.octave]);
+            g.eStereo.push_back(ur >= 0);
+            g.eKF.push_back(pKFi); g.eMP.push_back(pMP);
+            g.fx = pKFi->fx; g.fy = pKFi->fy; g.cx = pKFi->cx; g.cy = pKFi->cy; g.bf = pKFi->mbf;
         }
-    num_edges = (int)ePoint.size();
+    g.num_edges = (int)g.ePoint.size();                                             // :1404
+    return true;
+}
+
+inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges)
+{
+    if (!LbaWindowIsPinhole(pKF)) { Optimizer::LocalBundleAdjustment(pKF, pbStopFlag, pMap, num_fixedKF, num_OptKF, num_MPs, num_edges); return; }
+    (void)num_MPs;      // never assigned by the reference overload either (SURVEY.md B14)
+    LbaGraph g;
+    const bool ok = LocalBundleAdjustmentGraph(pKF, pMap, g);
+    num_fixedKF = g.num_fixedKF;
+    if (!ok) return;                                                                // :1182-1186: the other counters keep the caller's values
+    num_OptKF = g.num_OptKF; num_edges = g.num_edges;
     if (pbStopFlag && *pbStopFlag) return;                                          // :1406-1408
 
     LbaProblem pr;
-    pr.n_poses = (int)kfs.size(); pr.pose_q = q.data(); pr.pose_t = t.data(); pr.pose_fixed = fixed.data();
-    pr.n_points = (int)mps.size(); pr.points = X.data();
-    pr.n_edges = num_edges; pr.edge_point = ePoint.data(); pr.edge_pose = ePose.data(); pr.edge_obs = eObs.data();
-    pr.edge_inv_sigma2 = eW.data(); pr.edge_stereo = eStereo.data();
-    pr.fx = fx; pr.fy = fy; pr.cx = cx; pr.cy = cy; pr.bf = bf;
+    pr.n_poses = (int)g.kfs.size(); pr.pose_q = g.q.data(); pr.pose_t = g.t.data(); pr.pose_fixed = g.fixed.data();
+    pr.n_points = (int)g.mps.size(); pr.points = g.X.data();
+    pr.n_edges = num_edges; pr.edge_point = g.ePoint.data(); pr.edge_pose = g.ePose.data(); pr.edge_obs = g.eObs.data();
+    pr.edge_inv_sigma2 = g.eW.data(); pr.edge_stereo = g.eStereo.data();
+    pr.fx = g.fx; pr.fy = g.fy; pr.cx = g.cx; pr.cy = g.cy; pr.bf = g.bf;
     const float thHuberMono = sqrt(5.991), thHuberStereo = sqrt(7.815);             // :1275-1276 (through float)
     pr.huber_mono = thHuberMono; pr.huber_stereo = thHuberStereo;
     static thread_local lba_solver* solver = nullptr;
     if (!solver) orbslam3_hip::check(lba_create(0, &solver));
-    std::vector<double> qo(q.size()), to(t.size()), Xo(X.size()), chi2(num_edges);
+    std::vector<double> qo(g.q.size()), to(g.t.size()), Xo(g.X.size()), chi2(num_edges);
     std::vector<uint8_t> depthPos(num_edges);
     LbaStats st;
     orbslam3_hip::check(lba_solve(solver, &pr, (const volatile uint8_t*)pbStopFlag, 10, pMap->IsInertial() ? 100.0 : 0.0,
@@ -663,18 +700,18 @@ inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap,
 
     std::vector<std::pair<KeyFrame*, MapPoint*> > vToErase;                         // :1413-1460
     for (int e = 0; e < num_edges; e++) {
-        if (eMP[e]->isBad()) continue;
-        if (chi2[e] > (eStereo[e] ? 7.815 : 5.991) || !depthPos[e]) vToErase.push_back(std::make_pair(eKF[e], eMP[e]));
+        if (g.eMP[e]->isBad()) continue;
+        if (chi2[e] > (g.eStereo[e] ? 7.815 : 5.991) || !depthPos[e]) vToErase.push_back(std::make_pair(g.eKF[e], g.eMP[e]));
     }
     std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);                       // :1464
     for (auto& er : vToErase) { er.first->EraseMapPointMatch(er.second); er.second->EraseObservation(er.first); }
-    for (KeyFrame* pKFi : lLocalKeyFrames) {
-        const int i = kfIndex[pKFi];
+    for (KeyFrame* pKFi : g.lLocalKeyFrames) {
+        const int i = g.kfIndex.at(pKFi);
         const Eigen::Quaterniond qd(qo[4 * i + 3], qo[4 * i], qo[4 * i + 1], qo[4 * i + 2]);
         pKFi->SetPose(Sophus::SE3f(qd.cast<float>(), Eigen::Vector3d(to[3 * i], to[3 * i + 1], to[3 * i + 2]).cast<float>()));
     }
-    for (MapPoint* pMP : lLocalMapPoints) {
-        const int i = mpIndex[pMP];
+    for (MapPoint* pMP : g.lLocalMapPoints) {
+        const int i = g.mpIndex.at(pMP);
         pMP->SetWorldPos(Eigen::Vector3d(Xo[3 * i], Xo[3 * i + 1], Xo[3 * i + 2]).cast<float>());
         pMP->UpdateNormalAndDepth();
     }
@@ -757,7 +794,7 @@ inline void LocalInertialBAHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& 
         pInt->SetNewBias(pKFi->mPrevKF->GetImuBias());
         LibaLink L;
         std::memset(&L, 0, sizeof(L));
-        L.kf1 = kfIndex[pKFi->mPrevKF]; L.kf2 = kfIndex[pKFi];
+        L.kf1 = kfIndex.at(pKFi->mPrevKF); L.kf2 = kfIndex.at(pKFi);
         auto put3x3 = [](float* dst, const Eigen::Matrix3f& M) { for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) dst[3 * r + c] = M(r, c); };
         put3x3(L.dR, pInt->dR); put3x3(L.JRg, pInt->JRg); put3x3(L.JVg, pInt->JVg); put3x3(L.JVa, pInt->JVa); put3x3(L.JPg, pInt->JPg); put3x3(L.JPa, pInt->JPa);
         for (int r = 0; r < 3; r++) { L.dV[r] = pInt->dV(r); L.dP[r] = pInt->dP(r); }
@@ -802,7 +839,7 @@ inline void LocalInertialBAHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& 
             Eigen::Matrix<double, 2, 1> o2; o2 << kpUn.pt.x, kpUn.pt.y;
             const float unc2 = pKFi->mpCamera->uncertainty2(o2);
             const float invSigma2 = pKFi->mvInvLevelSigma2[kpUn.octave] / unc2;
-            eKFi.push_back(kfIndex[pKFi]); ePt.push_back(mpIndex[pMP]);
+            eKFi.push_back(kfIndex.at(pKFi)); ePt.push_back(mpIndex.at(pMP));
             eObs.push_back(kpUn.pt.x); eObs.push_back(kpUn.pt.y); eObs.push_back(ur >= 0 ? (double)ur : -1.0);
             eW.push_back((double)invSigma2); eStereo.push_back(ur >= 0);
             eKF.push_back(pKFi); eMP.push_back(pMP);
@@ -1108,7 +1145,6 @@ public:
     int getNumIMUs() { return (int)imus_.size(); }
     int getFrameId() { return frame_id_; }
     long getTimeStamp() { return time_stamp_; }
-    std::vector<IMUData> imus_;                                                     // public in the reference (src/Socket/client.cc:138)
 
 private:
     static orbslam3_hip::EdgePacketCodec& codec() { static thread_local orbslam3_hip::EdgePacketCodec c; return c; }
@@ -1116,6 +1152,11 @@ private:
     long time_stamp_ = 0;
     std::vector<cv::KeyPoint> kps_;
     cv::Mat descriptors_;
+
+public:
+    std::vector<IMUData> imus_;                                                     // public in the reference (src/Socket/client.cc:138)
+
+private:
     std::vector<unsigned char> payload_;
     unsigned char head_[2] = {0, 0};
 };

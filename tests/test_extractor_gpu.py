@@ -111,3 +111,22 @@ def test_pyramid_border(pkg, oracle, synth, gpu_ex):
     lvl = gpu_ex.pyramid_level(2, border=19)
     inner = gpu_ex.pyramid_level(2)
     np.testing.assert_array_equal(lvl, np.pad(inner, 19, mode="reflect"))     # numpy 'reflect' == BORDER_REFLECT_101
+
+
+@pytest.mark.parametrize("args", [(1000, 1.2, 8, 20, 7), (5000, 1.2, 8, 20, 7), (150, 1.5, 3, 20, 7), (2000, 1.1, 12, 15, 5), (500, 2.0, 4, 20, 7)])
+def test_constructor_tables_match_oracle(pkg, oracle, args):
+    """E0: the tables Frame / KeyFrame read through the getters (include/ORBextractor.h:61-81, src/ORBextractor.cc:409-445) --
+    mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2 and mnFeaturesPerLevel -- are the oracle's, bit for bit."""
+    ex = pkg.Extractor(*args)
+    try:
+        t = oracle.extractor(*args).tables()
+        assert ex.GetLevels() == args[2]
+        assert np.float32(ex.GetScaleFactor()) == np.float32(args[1])
+        for name, got in (("scale", ex.GetScaleFactors()), ("inv_scale", ex.GetInverseScaleFactors()),
+                          ("sigma2", ex.GetScaleSigmaSquares()), ("inv_sigma2", ex.GetInverseScaleSigmaSquares())):
+            assert got.dtype == np.float32
+            np.testing.assert_array_equal(got.view(np.uint32), t[name].view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(ex.features_per_level(), t["nfeat"])
+        assert ex.features_per_level().sum() == args[0]
+    finally:
+        ex.close()
