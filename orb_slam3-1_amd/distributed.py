@@ -61,14 +61,28 @@ class TorchDist:
         self.dist = dist
         self.device = device
         self.world = dist.get_world_size()
+        self._events = []           # (start, end) event pairs around the reduce-buffer all-reduces (device tensors only)
 
     def sum_(self, t):
+        cuda = getattr(t, "is_cuda", False)
+        if cuda:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(self.torch.cuda.current_stream(t.device))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         # RCCL enqueues the all-reduce on torch's current stream and returns; the shard kernels that consume the buffer
         # run on the shard's own stream, so the host waits here (the LM loop needs the scalars of this trial anyway)
-        if getattr(t, "is_cuda", False):
+        if cuda:
+            e1.record(self.torch.cuda.current_stream(t.device))
+            self._events.append((e0, e1))
             self.torch.cuda.current_stream(t.device).synchronize()
         return t
+
+    @property
+    def allreduce_seconds(self):
+        """device time spent in the reduce-buffer all-reduces so far (HIP events on the collective's stream); None on CPU backends"""
+        if not self._events:
+            return None
+        return 1e-3 * sum(a.elapsed_time(b) for a, b in self._events)
 
     def sum_scalars(self, vals):
         t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.device)
