@@ -44,10 +44,6 @@ struct TileDesc {
 // items (locality: shared image rows / 128-B lines stay in one L2), while successive groups and a per-frame rotation
 // spread cheap and expensive items (pyramid levels differ) evenly over the XCDs.
 constexpr int kXcdRun = 16;
-#ifndef ORBX_FAST_THREADS
-#define ORBX_FAST_THREADS 256
-#endif
-constexpr int kFastThreads = ORBX_FAST_THREADS;     // threads per FAST cell workgroup (64 = one wave per cell, no workgroup barriers)
 __host__ __device__ inline int xcd_remap(int block, int frame)
 {
     const int group = block / (8 * kXcdRun), within = block - group * (8 * kXcdRun);

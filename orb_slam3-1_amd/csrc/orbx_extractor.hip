@@ -104,7 +104,8 @@ struct orbx_extractor {
     std::vector<TileDesc> tiles;
     size_t pyr_frame_bytes = 0;
     int cand_frame_entries = 0, sel_frame_entries = 0;
-    int tile_pitch = 0, tile_rows = 0, m_pitch = 0, m_rows = 0, surv_off = 0, bits_off = 0;
+    std::vector<StripDesc> strips;       // FAST work items: runs of adjacent cells of one cell row
+    FastLds fast_layout;
     size_t fast_lds = 0, oct_lds = 0;
     int oct_pool = 0, oct_lds_keys = 0, oct_small_keys = 0;
     size_t oct_small_lds = 0;
@@ -113,6 +114,7 @@ struct orbx_extractor {
     DevBuf<LevelDesc> d_levels;
     DevBuf<CellDesc> d_cells;
     DevBuf<TileDesc> d_tiles;
+    DevBuf<StripDesc> d_strips;
     std::vector<DevBuf<int> > d_xofs, d_yofs;
     std::vector<DevBuf<short> > d_ialpha, d_ibeta;
 
@@ -181,6 +183,7 @@ int orbx_extractor::setup_geometry(int w, int h)
     levels.assign(nlevels, LevelDesc());
     cells.clear();
     tiles.clear();
+    strips.clear();
     size_t off = 0;
     int cand_off = 0, sel_off = 0, max_tw = 0, max_th = 0, max_nfeat = 0;
     d_xofs.resize(nlevels); d_yofs.resize(nlevels); d_ialpha.resize(nlevels); d_ibeta.resize(nlevels);
@@ -234,6 +237,24 @@ int orbx_extractor::setup_geometry(int w, int h)
         }
         L.cell_count = (int)cells.size() - L.cell_begin;
         L.cand_cap = cand_off - L.cand_off;
+        // strips: the cells of a cell row are adjacent (interiors tile the row); cut every row into runs of at most
+        // kStripMaxCells cells and about kStripWidth columns, evenly
+        for (int c0 = L.cell_begin; c0 < (int)cells.size();) {
+            int c1 = c0 + 1;
+            while (c1 < (int)cells.size() && cells[c1].y0 == cells[c0].y0) c1++;
+            const int n_row = c1 - c0;
+            const int w_cell = std::max(cells[c0].x1 - cells[c0].x0 - 6, 1);
+            const int per = std::max(1, std::min(kStripMaxCells, (kStripWidth - 6) / w_cell));
+            const int n_strips_row = (n_row + per - 1) / per;
+            for (int k = 0; k < n_strips_row; k++) {
+                const int a = c0 + (int)((long long)n_row * k / n_strips_row), b = c0 + (int)((long long)n_row * (k + 1) / n_strips_row);
+                StripDesc sd;
+                sd.level = (int16_t)l; sd.cell0 = (int16_t)a; sd.ncell = (int16_t)(b - a);
+                sd.x0 = cells[a].x0; sd.x1 = cells[b - 1].x1; sd.y0 = cells[a].y0; sd.y1 = cells[a].y1; sd.pad = 0;
+                strips.push_back(sd);
+            }
+            c0 = c1;
+        }
         // blur tiles
         for (int y0 = 0; y0 < L.h; y0 += kBlurTH)
             for (int x0 = 0; x0 < L.w; x0 += kBlurTW) {
@@ -273,20 +294,43 @@ int orbx_extractor::setup_geometry(int w, int h)
     pyr_frame_bytes = off;
     cand_frame_entries = std::max(cand_off, 1);
     sel_frame_entries = sel_off;
-    // FAST kernel LDS
-    tile_pitch = round_up(max_tw + 8, 4);       // re-aligned tile + room for the 12-byte windows of the quick test
-    tile_rows = std::max(max_th, 1);
-    m_pitch = round_up(std::max(max_tw - 6, 1) + 2, 4);
-    m_rows = std::max(max_th - 6, 1) + 2;
-    fast_lds = (size_t)tile_rows * tile_pitch + (size_t)m_rows * m_pitch + 64;
-    fast_lds = (fast_lds + 15) & ~(size_t)15;
-    surv_off = (int)fast_lds;
-    fast_lds += 2 * (size_t)std::max(max_tw - 6, 1) * std::max(max_th - 6, 1) + 16;
-    fast_lds = (fast_lds + 15) & ~(size_t)15;
-    bits_off = (int)fast_lds;
-    fast_lds += 3 * 256 * sizeof(uint32_t);
-    if ((max_tw - 6) * (max_th - 6) > 8192) return fail(ORBX_ERR_ARG, "FAST cell interior of %dx%d px exceeds the 8192-px bitmask", max_tw - 6, max_th - 6);
-    if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST cell of %dx%d px does not fit LDS", max_tw, max_th);
+    // FAST kernel LDS: sized for the largest strip (orbx_fast_strips.inc)
+    {
+        if (cells.size() > 32767) return fail(ORBX_ERR_ARG, "%zu FAST cells exceed the strip table's 16-bit cell index", cells.size());
+        int max_ngx = 1, max_sth = 7, max_items = 1, max_ncell = 1, max_int = 1, max_kp = 1;
+        for (const StripDesc& sd : strips) {
+            const int g0 = (sd.x0 + 3) >> 2, g1 = (sd.x1 - 4) >> 2, ngx = g1 - g0 + 1, sth = sd.y1 - sd.y0, ih = sth - 6;
+            if (ngx > 64 || ih > 127) return fail(ORBX_ERR_ARG, "FAST strip of %dx%d px exceeds the 64-quad x 127-row work item index", sd.x1 - sd.x0, sth);
+            int kp = 0;
+            for (int j = 0; j < sd.ncell; j++) {
+                const CellDesc& c = cells[sd.cell0 + j];
+                max_int = std::max(max_int, (c.x1 - c.x0 - 6) * ih);
+                kp += c.slot_cap;
+            }
+            max_ngx = std::max(max_ngx, ngx); max_sth = std::max(max_sth, sth); max_items = std::max(max_items, ngx * ih);
+            max_ncell = std::max(max_ncell, (int)sd.ncell); max_kp = std::max(max_kp, kp);
+        }
+        if (max_int > 8191) return fail(ORBX_ERR_ARG, "FAST cell interior of %d px exceeds the 8191-px bitmask", max_int);
+        FastLds& Z = fast_layout;
+        auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        size_t o = 0;
+        Z.tile_pitch = 4 * (max_ngx + 2);
+        o = al16((size_t)max_sth * Z.tile_pitch);
+        Z.map_off = (int)o; Z.map_pitch = 4 * max_ngx + 8;
+        o = al16(o + (size_t)(max_sth - 6 + 2) * Z.map_pitch);
+        Z.colcell_off = (int)o; o = al16(o + Z.map_pitch);
+        Z.ent_off = (int)o; o = al16(o + 4 * (size_t)max_items);
+        Z.wpc = (max_int + 31) / 32;
+        Z.pre_off = (int)o; o = al16(o + 4 * (size_t)max_ncell * Z.wpc);
+        Z.bits_off = (int)o; o = al16(o + 4 * (size_t)max_ncell * Z.wpc);
+        Z.px_cap = 2048;
+        Z.px_off = (int)o; o = al16(o + 2 * (size_t)Z.px_cap);
+        Z.kp_cap = max_kp;
+        Z.kp_off = (int)o; o = al16(o + 4 * (size_t)max_kp);
+        Z.total = (int)o;
+        fast_lds = o;
+        if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST strip of %d quads x %d rows does not fit LDS", max_ngx, max_sth);
+    }
     // octree kernel LDS
     oct_pool = max_nfeat + 16;
     if (oct_pool > 16000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree", max_nfeat);
@@ -308,9 +352,9 @@ int orbx_extractor::setup_geometry(int w, int h)
     if (oct_lds_keys > 0 && oct_lds_keys < max_cand_cap) oct_lds_keys = 0;              // the LDS instantiation needs room for a whole level
     ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)node_bytes + 64));
     ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(oct_lds, oct_small_lds)));
-    ORBX_HIP(hipFuncSetAttribute((const void*)k_fast_cells, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_fast_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
     int r;
-    if ((r = d_levels.upload(levels)) || (r = d_cells.upload(cells)) || (r = d_tiles.upload(tiles))) return r;
+    if ((r = d_levels.upload(levels)) || (r = d_cells.upload(cells)) || (r = d_tiles.upload(tiles)) || (r = d_strips.upload(strips))) return r;
     geo_w = w; geo_h = h;
     batch_cap = 0;      // scratch must be re-sized for the new geometry
     return ORBX_OK;
@@ -378,9 +422,9 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     mark();
     const int n_cells = (int)cells.size();
     if (n_cells > 0)
-        hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(n_cells), B), dim3(kFastThreads), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
-                           ini_th, min_th, tile_pitch, tile_rows, m_pitch, surv_off, bits_off, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p, n_cells);
-    ORBX_LAUNCHED("k_fast_cells");
+        hipLaunchKernelGGL(k_fast_strips, dim3(xcd_grid((int)strips.size()), B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
+                           d_strips.p, (int)strips.size(), n_cells, ini_th, min_th, fast_layout, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p);
+    ORBX_LAUNCHED("k_fast_strips");
     mark();
     // The octree is latency-bound (one wave per frame and level) and leaves most of the chip idle, while the blur only
     // needs the pyramid: run the blur on a side stream next to octree + index and join before the descriptors.
@@ -494,7 +538,7 @@ void orbx_destroy(orbx_extractor* e)
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    e->d_levels.release(); e->d_cells.release(); e->d_tiles.release();
+    e->d_levels.release(); e->d_cells.release(); e->d_tiles.release(); e->d_strips.release();
     for (auto& b : e->d_xofs) b.release();
     for (auto& b : e->d_yofs) b.release();
     for (auto& b : e->d_ialpha) b.release();
@@ -769,15 +813,5 @@ int orbx_debug_oct_prof(unsigned long long* out8)
 }
 #endif
 
-#ifdef ORBX_FAST_TIMING
-// reads and clears the cycle sums of k_fast_cells (timing builds only; not part of include/orbslam3_hip.h)
-int orbx_debug_fast_prof(unsigned long long* out8)
-{
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(d_fast_prof), sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(d_fast_prof), z, sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
-    return ORBX_OK;
-}
-#endif
 
 }  // extern "C"

@@ -2,7 +2,7 @@
 //
 // Pipeline per batch of B frames (all launches cover the whole batch; blockIdx.y / .z = frame):
 //   k_resize        level l-1 -> l, fixed-point bilinear            (E1, ComputePyramid :1170-1195)
-//   k_fast_cells    FAST-9/16 score + per-cell NMS / threshold fallback / ordered compaction
+//   k_fast_strips   FAST-9/16 score + per-cell NMS / threshold fallback / ordered compaction, a workgroup per strip of cells
 //                                                                    (E2, ComputeKeyPointsOctTree :787-872)
 //   k_octree        quadtree keypoint selection, one wave per (frame, level)
 //                                                                    (E3, DistributeOctTree :555-779)
@@ -103,237 +103,13 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_
 }
 
 // ------------------------------------------------------------------------------------------------
-// E2: FAST-9/16.  M(p) = max over the 16 arcs of 9 contiguous ring pixels of min(+-(v - ring)).
-// OpenCV's corner test at threshold t is  M > t  and its score (response) is  M - 1  (SURVEY App. A.1).
+// E2: FAST-9/16 on strips of cells -- orbx_fast_strips.inc
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_m(const uint8_t* __restrict__ t, int pitch)
-{
-    // t points at the pixel inside the LDS tile
-    const int v = t[0];
-    int d[16];
-    d[0] = v - t[3 * pitch];       d[1] = v - t[3 * pitch + 1];   d[2] = v - t[2 * pitch + 2];   d[3] = v - t[pitch + 3];
-    d[4] = v - t[3];               d[5] = v - t[-pitch + 3];      d[6] = v - t[-2 * pitch + 2];  d[7] = v - t[-3 * pitch + 1];
-    d[8] = v - t[-3 * pitch];      d[9] = v - t[-3 * pitch - 1];  d[10] = v - t[-2 * pitch - 2]; d[11] = v - t[-pitch - 3];
-    d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int best_dark = -256, best_bright = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   // min of d[k..k+8]
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);   // max of d[k..k+8]
-        best_dark = max(best_dark, lo9);
-        best_bright = min(best_bright, hi9);
-    }
-    const int m = max(best_dark, -best_bright);
-    return max(m, 0);
-}
-
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
 
-// One 256-thread workgroup per FAST cell.  LDS: image tile (cell + 3 px ring halo, re-aligned so that tile column 0 sits
-// on a dword), M tile with a 1-px zero halo (NMS must treat everything outside the cell's own interior as 0), survivor
-// list, two keypoint bitmasks (iniTh / minTh) and their word-prefix sums.
-//
-// pass 1  exact necessary condition for "corner at minThFAST": in each of the 8 opposite ring pairs (k, k+8) at least one
-//         pixel is beyond the threshold with the same polarity (a 9-arc covers one pixel of every pair).  One work item =
-//         4 horizontally adjacent pixels fed by 19 aligned dword LDS reads (instead of 68 byte reads); survivors are
-//         compacted into an LDS list.  Rejected pixels keep M = 0, which is what NMS / thresholds see for M <= minTh anyway.
-// pass 2  full arc min/max tree, densely, on the survivors only.
-// pass 3  3x3 NMS at both thresholds on the survivors -> bitmasks over the cell's pixels (row-major bit order).
-// pass 4  per-cell fallback to minThFAST only when iniThFAST found nothing (:843); word popcount prefix sums.
-// pass 5  ordered (row-major) compaction: rank = prefix[word] + popcount(lower bits).
-#define ORBX_B(w, j) (((w)[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
-#ifdef ORBX_FAST_TIMING      // section-wise cycle sums over all workgroups (tools/fast_timing.py); never defined in the product build
-__device__ unsigned long long d_fast_prof[8];
-#define ORBX_FTICK(k) if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {      /* 1 workgroup in 64: the atomics must not perturb the run */ const long long t_now = clock64(); atomicAdd(&d_fast_prof[k], (unsigned long long)(t_now - t_prev)); t_prev = t_now; }
-#else
-#define ORBX_FTICK(k)
-#endif
-__global__ __launch_bounds__(kFastThreads) void k_fast_cells(const uint8_t* __restrict__ pyr, size_t frame_stride,
-                                                    const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
-                                                    int ini_th, int min_th, int tile_pitch, int tile_rows, int m_pitch, int surv_off, int bits_off,
-                                                    uint32_t* __restrict__ cand, size_t cand_frame_stride,
-                                                    int* __restrict__ cell_count, int n_cells)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    uint8_t* tile = smem;                                   // tile_rows x tile_pitch
-    uint8_t* mt = smem + (size_t)tile_rows * tile_pitch;    // (ih+2) x m_pitch
-    uint16_t* surv = (uint16_t*)(smem + surv_off);          // survivors of the quick test (pixel index inside the cell)
-    uint32_t* bits_ini = (uint32_t*)(smem + bits_off);      // [256] keypoints at iniThFAST
-    uint32_t* bits_min = bits_ini + 256;                    // [256] keypoints at minThFAST
-    uint32_t* wbase = bits_min + 256;                       // [256] exclusive popcount prefix of the selected mask
-    __shared__ int s_wave_tot[4];
-    __shared__ int s_nsurv;
-
-    // XCD-aware mapping (orbx_device.h): neighbouring cells share image rows and 128-B lines, keep them in one L2.
-    const int cell_idx = xcd_remap(blockIdx.x, blockIdx.y);
-    if (cell_idx >= n_cells) return;
-    const CellDesc c = cells[cell_idx];
-    const LevelDesc L = levels[c.level];
-    const int frame = blockIdx.y;
-    const uint8_t* img = pyr + (size_t)frame * frame_stride + L.off;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tw = c.x1 - c.x0, th = c.y1 - c.y0;       // tile (cell sub-image) size
-    const int iw = tw - 6, ih = th - 6;                 // interior (detection area)
-    const int n_int = iw * ih;
-    const int xa = c.x0 & ~3;                           // dword-aligned address of the tile's first column
-    const int shift = c.x0 - xa;
-    const int row_dw = (tw + 8) >> 2;                   // LDS dwords per tile row (covers the 12-byte windows of pass 1)
-
-#ifdef ORBX_FAST_TIMING
-    long long t_prev = clock64();
-#endif
-    if (tid == 0) s_nsurv = 0;
-    // tile load: coalesced dword loads (rows are 64-B aligned in HBM), byte-realigned so that LDS column k = image column x0 + k
-    for (int i = tid; i < th * row_dw; i += kFastThreads) {
-        const int r = i / row_dw, q = i - r * row_dw;
-        const uint32_t* g = (const uint32_t*)(img + (size_t)(c.y0 + r) * L.stride + xa) + q;
-        const uint32_t lo = g[0];
-        uint32_t v = lo;
-        if (shift) v = __builtin_amdgcn_alignbyte(g[1], lo, (uint32_t)shift);
-        *(uint32_t*)(tile + r * tile_pitch + 4 * q) = v;
-    }
-    for (int i = tid; i < (ih + 2) * m_pitch / 4; i += kFastThreads) ((uint32_t*)mt)[i] = 0;
-    for (int i = tid; i < 512; i += kFastThreads) bits_ini[i] = 0;       // both masks
-    __syncthreads();
-    ORBX_FTICK(0)
-
-    // ---- pass 1 ----
-    const int ngx = (iw + 3) >> 2;
-    for (int gi = tid; gi < ngx * ih; gi += kFastThreads) {
-        const int y = gi / ngx, gx = gi - y * ngx;
-        const uint32_t* base = (const uint32_t*)(tile + y * tile_pitch) + gx;      // window: rows y..y+6, bytes 4gx..4gx+11
-        const int pd = tile_pitch >> 2;
-        uint32_t w0[3], w1[3], w2[3], w3[3], w4[3], w5[3], w6[3];
-        w0[0] = base[0]; w0[1] = base[1]; w0[2] = 0;
-        w1[0] = base[pd]; w1[1] = base[pd + 1]; w1[2] = base[pd + 2];
-        w2[0] = base[2 * pd]; w2[1] = base[2 * pd + 1]; w2[2] = base[2 * pd + 2];
-        w3[0] = base[3 * pd]; w3[1] = base[3 * pd + 1]; w3[2] = base[3 * pd + 2];
-        w4[0] = base[4 * pd]; w4[1] = base[4 * pd + 1]; w4[2] = base[4 * pd + 2];
-        w5[0] = base[5 * pd]; w5[1] = base[5 * pd + 1]; w5[2] = base[5 * pd + 2];
-        w6[0] = base[6 * pd]; w6[1] = base[6 * pd + 1]; w6[2] = 0;
-        // The four pixels travel in two registers of 2 x u16: pixels (0, 2) and pixels (1, 3).  v_perm_b32 pulls the two
-        // bytes of a ring position out of the row window and zero-extends them in ONE instruction; per ring pair the test
-        // "one of the two is darker than v - t" for ALL pairs is  max over pairs of min(a, b) < v - t  (packed min / max),
-        // likewise  min over pairs of max(a, b) > v + t  for the bright polarity: 12 packed ops per pair for 4 pixels.
-#define ORBX_SEL_E(r) ((uint32_t)(r) | 0x0C000C00u | ((uint32_t)((r) + 2) << 16))
-#define ORBX_SEL_O(r) ((uint32_t)((r) + 1) | 0x0C000C00u | ((uint32_t)((r) + 3) << 16))
-#define ORBX_PE(W, s) as_us2(__builtin_amdgcn_perm((W)[((s) >> 2) + 1], (W)[(s) >> 2], ORBX_SEL_E((s) & 3)))
-#define ORBX_PO(W, s) as_us2(__builtin_amdgcn_perm((W)[((s) >> 2) + 1], (W)[(s) >> 2], ORBX_SEL_O((s) & 3)))
-        const us2 T2 = as_us2((uint32_t)min_th | ((uint32_t)min_th << 16));
-        const us2 ce = ORBX_PE(w3, 3), co = ORBX_PO(w3, 3);
-        const us2 lo_e = __builtin_elementwise_sub_sat(ce, T2), lo_o = __builtin_elementwise_sub_sat(co, T2);   // max(v - t, 0)
-        const us2 hi_e = ce + T2, hi_o = co + T2;
-        us2 dk_e = as_us2(0u), dk_o = as_us2(0u), br_e = as_us2(0xFFFFFFFFu), br_o = as_us2(0xFFFFFFFFu);
-#define ORBX_PAIR(WA, SA, WB, SB) { \
-            const us2 ae = ORBX_PE(WA, SA), ao = ORBX_PO(WA, SA), be = ORBX_PE(WB, SB), bo = ORBX_PO(WB, SB); \
-            dk_e = __builtin_elementwise_max(dk_e, __builtin_elementwise_min(ae, be)); \
-            dk_o = __builtin_elementwise_max(dk_o, __builtin_elementwise_min(ao, bo)); \
-            br_e = __builtin_elementwise_min(br_e, __builtin_elementwise_max(ae, be)); \
-            br_o = __builtin_elementwise_min(br_o, __builtin_elementwise_max(ao, bo)); }
-        ORBX_PAIR(w6, 3, w0, 3)        // ring 0 / 8
-        ORBX_PAIR(w3, 6, w3, 0)        // 4 / 12
-        ORBX_PAIR(w5, 5, w1, 1)        // 2 / 10
-        ORBX_PAIR(w1, 5, w5, 1)        // 6 / 14
-        ORBX_PAIR(w6, 4, w0, 2)        // 1 / 9
-        ORBX_PAIR(w4, 6, w2, 0)        // 3 / 11
-        ORBX_PAIR(w2, 6, w4, 0)        // 5 / 13
-        ORBX_PAIR(w0, 4, w6, 2)        // 7 / 15
-#undef ORBX_PAIR
-        // non-zero 16-bit lane = candidate: sat(lo - dk) != 0  <=>  dk < v - t;   sat(br - hi) != 0  <=>  br > v + t
-        const uint32_t c_e = as_u32(__builtin_elementwise_sub_sat(lo_e, dk_e)) | as_u32(__builtin_elementwise_sub_sat(br_e, hi_e));
-        const uint32_t c_o = as_u32(__builtin_elementwise_sub_sat(lo_o, dk_o)) | as_u32(__builtin_elementwise_sub_sat(br_o, hi_o));
-        const int x4 = 4 * gx;
-        if ((c_e & 0xFFFFu) && x4 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4);
-        if ((c_o & 0xFFFFu) && x4 + 1 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4 + 1);
-        if ((c_e >> 16) && x4 + 2 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4 + 2);
-        if ((c_o >> 16) && x4 + 3 < iw) surv[atomicAdd(&s_nsurv, 1)] = (uint16_t)(y * iw + x4 + 3);
-#undef ORBX_PE
-#undef ORBX_PO
-#undef ORBX_SEL_E
-#undef ORBX_SEL_O
-    }
-    __syncthreads();
-    ORBX_FTICK(1)
-    const int nsurv = s_nsurv;
-    // ---- pass 2 ----
-    for (int i = tid; i < nsurv; i += kFastThreads) {
-        const int q = surv[i];
-        const int y = q / iw, x = q - y * iw;
-        const int m = fast_m(tile + (y + 3) * tile_pitch + x + 3, tile_pitch);
-        mt[(y + 1) * m_pitch + x + 1] = (uint8_t)m;
-    }
-    __syncthreads();
-    ORBX_FTICK(2)
-    // ---- pass 3 ----
-    for (int i = tid; i < nsurv; i += kFastThreads) {
-        const int q = surv[i];
-        const int y = q / iw, x = q - y * iw;
-        const uint8_t* p = mt + (y + 1) * m_pitch + x + 1;
-        const int m = p[0];
-        if (m > min_th) {
-            const int n0 = p[-m_pitch - 1], n1 = p[-m_pitch], n2 = p[-m_pitch + 1], n3 = p[-1], n4 = p[1],
-                      n5 = p[m_pitch - 1], n6 = p[m_pitch], n7 = p[m_pitch + 1];
-            const int s = m - 1;
-#define ORBX_NB(n, t) (((n) > (t)) ? (n)-1 : 0)
-#define ORBX_PASS(t) (s > ORBX_NB(n0, t) && s > ORBX_NB(n1, t) && s > ORBX_NB(n2, t) && s > ORBX_NB(n3, t) && \
-                      s > ORBX_NB(n4, t) && s > ORBX_NB(n5, t) && s > ORBX_NB(n6, t) && s > ORBX_NB(n7, t))
-            if (m > ini_th && ORBX_PASS(ini_th)) atomicOr(&bits_ini[q >> 5], 1u << (q & 31));
-            if (ORBX_PASS(min_th)) atomicOr(&bits_min[q >> 5], 1u << (q & 31));
-#undef ORBX_PASS
-#undef ORBX_NB
-        }
-    }
-    __syncthreads();
-    ORBX_FTICK(3)
-    // ---- pass 4: which threshold, then exclusive prefix of the word popcounts (n_int <= 8192 -> <= 256 words) ----
-    const int nwords = (n_int + 31) >> 5;
-    bool any_l = false;
-    for (int i = tid; i < nwords; i += kFastThreads) any_l |= bits_ini[i] != 0;
-    const int ini_any = __syncthreads_or(any_l);
-    const uint32_t* bits = ini_any ? bits_ini : bits_min;
-    int total = 0;
-    for (int w0 = 0; w0 < nwords; w0 += kFastThreads) {          // one round for 256 threads, up to four for a single wave
-        const int i = w0 + tid;
-        const int my = (i < nwords) ? __popc(bits[i]) : 0;
-        int incl = my;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        if (lane == 63) s_wave_tot[wave] = incl;
-        __syncthreads();
-        int wave_base = total, round_total = 0;
-        for (int w = 0; w < kFastThreads / 64; w++) { if (w < wave) wave_base += s_wave_tot[w]; round_total += s_wave_tot[w]; }
-        if (i < nwords) wbase[i] = (uint32_t)(wave_base + incl - my);
-        total += round_total;
-        __syncthreads();
-    }
-    ORBX_FTICK(4)
-    // ---- pass 5 ----
-    uint32_t* out = cand + (size_t)frame * cand_frame_stride + c.slot_off;
-    for (int i = tid; i < nsurv; i += kFastThreads) {
-        const int q = surv[i];
-        const uint32_t wd = bits[q >> 5];
-        if ((wd >> (q & 31)) & 1u) {
-            const int rank = (int)wbase[q >> 5] + __popc(wd & ((1u << (q & 31)) - 1u));
-            const int y = q / iw, x = q - y * iw;
-            const int m = mt[(y + 1) * m_pitch + x + 1];
-            // coordinates relative to minBorder (= level coordinates - 16), as vToDistributeKeys holds them (:865-866)
-            const uint32_t px = (uint32_t)(c.x0 + 3 + x - 16), py = (uint32_t)(c.y0 + 3 + y - 16);
-            if (rank < c.slot_cap) out[rank] = pack_key(px, py, (uint32_t)(m - 1));
-        }
-    }
-    if (tid == 0) cell_count[(size_t)frame * n_cells + cell_idx] = min(total, c.slot_cap);
-    ORBX_FTICK(5)
-#ifdef ORBX_FAST_TIMING
-    if (tid == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&d_fast_prof[6], (unsigned long long)nsurv); atomicAdd(&d_fast_prof[7], 1ull); }
-#endif
-}
-#undef ORBX_B
+#include "orbx_fast_strips.inc"
 
 // ------------------------------------------------------------------------------------------------
 // E3: DistributeOctTree.  One wave per (frame, level).  The std::list of nodes is an index-linked list
@@ -727,7 +503,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 {
     __shared__ __align__(16) uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
     __shared__ __align__(16) uint16_t s_h[(kBlurTH + 6) * kBlurTW];
-    const int tile_idx = xcd_remap(blockIdx.x, blockIdx.y);     // contiguous tile range per XCD (see k_fast_cells)
+    const int tile_idx = xcd_remap(blockIdx.x, blockIdx.y);     // contiguous tile range per XCD (see k_fast_strips)
     if (tile_idx >= n_tiles) return;
     const TileDesc T = tiles[tile_idx];
     const LevelDesc L = levels[T.level];
