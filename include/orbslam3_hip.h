@@ -115,6 +115,10 @@ int orbx_debug_blurred_level(orbx_extractor* h, int frame, int level, uint8_t* d
 int orbx_debug_candidates(orbx_extractor* h, int frame, int level, OrbxKeyPoint* out, int cap, int* n);
 /* per-level keypoints after DistributeOctTree + orientation, level coordinates, list order (:874-895). */
 int orbx_debug_level_keypoints(orbx_extractor* h, int frame, int level, OrbxKeyPoint* out, int cap, int* n);
+/* Test hook: capacity of the per-wave corner lists of the FAST kernel (cap <= 0: default).  A small value sends ordinary images
+ * through the kernel's overflow path (every pixel of a wave's rows goes through non-maximum suppression and emission), which
+ * otherwise only pathological images reach; results must not change. */
+int orbx_debug_set_fast_corner_cap(orbx_extractor* h, int cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Matcher -- replaces ORB_SLAM3::ORBmatcher (include/ORBmatcher.h:40-106)

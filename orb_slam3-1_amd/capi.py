@@ -234,6 +234,11 @@ class Extractor:
         _check(lib.orbx_debug_blurred_level(self._h, frame, level, _p(out), out.strides[0]))
         return out
 
+    def debug_set_fast_corner_cap(self, cap):
+        """test hook: shrink the FAST kernel's per-wave corner lists so that its overflow path runs"""
+        lib.orbx_debug_set_fast_corner_cap.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.orbx_debug_set_fast_corner_cap(self._h, int(cap)))
+
     def candidates(self, level, frame=0, cap=200000):
         out = np.zeros(cap, KP_DTYPE)
         n = C.c_int()

@@ -106,6 +106,7 @@ struct orbx_extractor {
     int cand_frame_entries = 0, sel_frame_entries = 0;
     std::vector<StripDesc> strips;       // FAST work items: runs of adjacent cells of one cell row
     FastLds fast_layout;
+    int fast_corner_cap = 0;             // 0 = kCornerCap; tests shrink it to drive the overflow path (orbx_debug_set_fast_corner_cap)
     size_t fast_lds = 0, oct_lds = 0;
     int oct_pool = 0, oct_lds_keys = 0, oct_small_keys = 0;
     size_t oct_small_lds = 0;
@@ -297,36 +298,34 @@ int orbx_extractor::setup_geometry(int w, int h)
     // FAST kernel LDS: sized for the largest strip (orbx_fast_strips.inc)
     {
         if (cells.size() > 32767) return fail(ORBX_ERR_ARG, "%zu FAST cells exceed the strip table's 16-bit cell index", cells.size());
-        int max_ngx = 1, max_sth = 7, max_items = 1, max_ncell = 1, max_int = 1, max_kp = 1;
+        int max_nch = 1, max_ngx = 1, max_sth = 7, max_ent = 1, max_ncell = 1, max_int = 1;
         for (const StripDesc& sd : strips) {
             const int g0 = (sd.x0 + 3) >> 2, g1 = (sd.x1 - 4) >> 2, ngx = g1 - g0 + 1, sth = sd.y1 - sd.y0, ih = sth - 6;
             if (ngx > 64 || ih > 127) return fail(ORBX_ERR_ARG, "FAST strip of %dx%d px exceeds the 64-quad x 127-row work item index", sd.x1 - sd.x0, sth);
-            int kp = 0;
-            for (int j = 0; j < sd.ncell; j++) {
-                const CellDesc& c = cells[sd.cell0 + j];
-                max_int = std::max(max_int, (c.x1 - c.x0 - 6) * ih);
-                kp += c.slot_cap;
-            }
-            max_ngx = std::max(max_ngx, ngx); max_sth = std::max(max_sth, sth); max_items = std::max(max_items, ngx * ih);
-            max_ncell = std::max(max_ncell, (int)sd.ncell); max_kp = std::max(max_kp, kp);
+            const int xa = (4 * (g0 - 1)) & ~15, qoff = 4 * g0 - xa;
+            max_nch = std::max(max_nch, (qoff + 4 * ngx + 4 + 15) >> 4);
+            for (int j = 0; j < sd.ncell; j++) { const CellDesc& c = cells[sd.cell0 + j]; max_int = std::max(max_int, (c.x1 - c.x0 - 6) * ih); }
+            max_ngx = std::max(max_ngx, ngx); max_sth = std::max(max_sth, sth);
+            max_ent = std::max(max_ent, ((ih + 3) / 4) * ngx);
+            max_ncell = std::max(max_ncell, (int)sd.ncell);
         }
         if (max_int > 8191) return fail(ORBX_ERR_ARG, "FAST cell interior of %d px exceeds the 8191-px bitmask", max_int);
         FastLds& Z = fast_layout;
         auto al16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
         size_t o = 0;
-        Z.tile_pitch = 4 * (max_ngx + 2);
+        Z.tile_pitch = 16 * max_nch;
         o = al16((size_t)max_sth * Z.tile_pitch);
         Z.map_off = (int)o; Z.map_pitch = 4 * max_ngx + 8;
         o = al16(o + (size_t)(max_sth - 6 + 2) * Z.map_pitch);
         Z.colcell_off = (int)o; o = al16(o + Z.map_pitch);
-        Z.ent_off = (int)o; o = al16(o + 4 * (size_t)max_items);
+        Z.ent_cap = (max_ent + 7) & ~7;
+        Z.ent_off = (int)o; o = al16(o + 2 * 4 * (size_t)Z.ent_cap);
+        Z.px_off = (int)o; o = al16(o + 2 * 4 * (size_t)kPxCap);
+        Z.corner_cap = fast_corner_cap > 0 ? fast_corner_cap : kCornerCap;
+        Z.corner_off = (int)o; o = al16(o + 2 * 4 * (size_t)Z.corner_cap);
         Z.wpc = (max_int + 31) / 32;
         Z.pre_off = (int)o; o = al16(o + 4 * (size_t)max_ncell * Z.wpc);
         Z.bits_off = (int)o; o = al16(o + 4 * (size_t)max_ncell * Z.wpc);
-        Z.px_cap = 2048;
-        Z.px_off = (int)o; o = al16(o + 2 * (size_t)Z.px_cap);
-        Z.kp_cap = max_kp;
-        Z.kp_off = (int)o; o = al16(o + 4 * (size_t)max_kp);
         Z.total = (int)o;
         fast_lds = o;
         if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST strip of %d quads x %d rows does not fit LDS", max_ngx, max_sth);
@@ -715,6 +714,16 @@ int orbx_debug_level_keypoints(orbx_extractor* e, int frame, int level, OrbxKeyP
     const int m = std::min(cnt, cap);
     if (m > 0)
         ORBX_HIP(hipMemcpy(out, e->d_lvl_kps.p + (size_t)frame * e->sel_frame_entries + L.sel_off, sizeof(OrbxKeyPoint) * m, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// Test hook: shrinks the per-wave corner list of the FAST kernel so that ordinary images take its overflow path (every pixel of
+// the wave's rows goes through nms / emission).  cap <= 0 restores the default.  Takes effect at the next geometry setup.
+int orbx_debug_set_fast_corner_cap(orbx_extractor* e, int cap)
+{
+    if (!e) return fail(ORBX_ERR_ARG, "NULL handle");
+    e->fast_corner_cap = cap > 0 ? std::min(cap, 4096) : 0;
+    e->geo_w = e->geo_h = 0;            // force setup_geometry to rebuild the LDS layout
     return ORBX_OK;
 }
 

@@ -130,3 +130,50 @@ def test_constructor_tables_match_oracle(pkg, oracle, args):
         assert ex.features_per_level().sum() == args[0]
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("cap", [1, 7, 40])
+def test_fast_corner_list_overflow_path(pkg, oracle, synth, cap):
+    """the FAST kernel lists at most `corner_cap` corners per wave and scans all the pixels of the wave's rows beyond that:
+    with a tiny capacity every strip takes that path, and candidates, keypoints and descriptors stay the oracle's"""
+    img = synth.make_frame(4)
+    oex = oracle.extractor(1000, 1.2, 8, 20, 7)
+    r0, okps, odesc = oex.extract(img, (0, 1000))
+    ex = pkg.Extractor(1000, 1.2, 8, 20, 7)
+    try:
+        ex.debug_set_fast_corner_cap(cap)
+        mono, kps, desc = ex(img, (0, 1000))
+        for l in range(8):
+            oc, gc = oex.level_candidates(l), ex.candidates(l)
+            assert len(oc) == len(gc)
+            for f in ("x", "y", "response"):
+                np.testing.assert_array_equal(gc[f], oc[f], err_msg="level %d %s" % (l, f))
+        _assert_kps_equal(kps, okps, "overflow path")
+        np.testing.assert_array_equal(desc, odesc)
+    finally:
+        ex.close()
+
+
+def test_fast_threshold_fallback_cells(pkg, oracle):
+    """cells without a keypoint at iniThFAST are searched again at minThFAST (:843-846): a faint texture (contrast between
+    the two thresholds) next to strong corners, flat cells, and a frame that is faint everywhere"""
+    rs = np.random.RandomState(12)
+    img = np.full((240, 320), 100, np.uint8)
+    img[:, :160] = (100 + 12 * (rs.uniform(size=(240, 160)) < 0.5)).astype(np.uint8)       # |step| 12: corners at 7, none at 20
+    img[40:200:16, 200:300:16] = 255                                                        # isolated bright dots: corners at 20
+    faint = (100 + 10 * (rs.uniform(size=(240, 320)) < 0.5)).astype(np.uint8)
+    for im in (img, faint, np.full((240, 320), 7, np.uint8)):
+        oex = oracle.extractor(500, 1.2, 6, 20, 7)
+        r0, okps, odesc = oex.extract(im, (0, 1000))
+        ex = pkg.Extractor(500, 1.2, 6, 20, 7)
+        try:
+            mono, kps, desc = ex(im, (0, 1000))
+            for l in range(6):
+                oc, gc = oex.level_candidates(l), ex.candidates(l)
+                assert len(oc) == len(gc), "level %d: %d vs %d candidates" % (l, len(gc), len(oc))
+                for f in ("x", "y", "response"):
+                    np.testing.assert_array_equal(gc[f], oc[f], err_msg="level %d %s" % (l, f))
+            _assert_kps_equal(kps, okps, "fallback")
+            np.testing.assert_array_equal(desc, odesc)
+        finally:
+            ex.close()
