@@ -38,19 +38,17 @@ struct TileDesc {
 };
 
 // Workgroups are dispatched round-robin over the 8 XCDs, so workgroups b and b+8 share an L2 (MI355X_MICROARCH.md,
-// "Workgroup dispatch").  With a grid of 8*chunk workgroups this gives XCD k the contiguous items [k*chunk, (k+1)*chunk).
-// A speed-only mapping: any placement yields the same results.
-// Items are taken in groups of 8*kXcdRun: inside a group XCD k owns the run [k*kXcdRun, (k+1)*kXcdRun) of neighbouring
-// items (locality: shared image rows / 128-B lines stay in one L2), while successive groups and a per-frame rotation
-// spread cheap and expensive items (pyramid levels differ) evenly over the XCDs.
-constexpr int kXcdRun = 16;
-__host__ __device__ inline int xcd_remap(int block, int frame)
+// "Workgroup dispatch").  With a grid of 8*chunk workgroups per frame this gives every XCD a contiguous run of `chunk` items
+// (neighbouring items share image rows / 128-B lines: they stay in one L2); the run an XCD gets rotates with the frame, so
+// that cheap and expensive runs (pyramid levels differ) spread evenly over the XCDs.  A speed-only mapping: any placement
+// yields the same results.  The grid is padded to a multiple of 8 only -- empty workgroups still cost a dispatch slot, and the
+// dispatcher starts only about two workgroups per nanosecond.
+__host__ __device__ inline int xcd_grid(int n_items) { return 8 * ((n_items + 7) / 8); }
+__host__ __device__ inline int xcd_remap(int block, int grid, int frame)
 {
-    const int group = block / (8 * kXcdRun), within = block - group * (8 * kXcdRun);
-    const int xcd = (within + frame) & 7, j = within >> 3;
-    return group * (8 * kXcdRun) + xcd * kXcdRun + j;
+    const int chunk = grid >> 3;
+    return (((block & 7) + frame) & 7) * chunk + (block >> 3);
 }
-__host__ __device__ inline int xcd_grid(int n_items) { return (8 * kXcdRun) * ((n_items + 8 * kXcdRun - 1) / (8 * kXcdRun)); }
 
 // candidate / key record: x (12 bits), y (12 bits) relative to minBorder, FAST response (8 bits)
 __host__ __device__ inline uint32_t pack_key(uint32_t x, uint32_t y, uint32_t resp) { return (x << 20) | (y << 8) | resp; }

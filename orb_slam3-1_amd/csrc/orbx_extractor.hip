@@ -116,8 +116,10 @@ struct orbx_extractor {
     DevBuf<CellDesc> d_cells;
     DevBuf<TileDesc> d_tiles;
     DevBuf<StripDesc> d_strips;
-    std::vector<DevBuf<int> > d_xofs, d_yofs;
-    std::vector<DevBuf<short> > d_ialpha, d_ibeta;
+    // resize tables per destination level: per quad of columns the first source column, 4 v_perm selectors, 4 coefficient pairs
+    std::vector<DevBuf<int> > d_qsx0, d_yofs;
+    std::vector<DevBuf<uint4> > d_qsel, d_qalpha;
+    std::vector<DevBuf<short> > d_ibeta;
 
     // per-batch scratch
     int batch_cap = 0, last_batch = 0;
@@ -187,7 +189,7 @@ int orbx_extractor::setup_geometry(int w, int h)
     strips.clear();
     size_t off = 0;
     int cand_off = 0, sel_off = 0, max_tw = 0, max_th = 0, max_nfeat = 0;
-    d_xofs.resize(nlevels); d_yofs.resize(nlevels); d_ialpha.resize(nlevels); d_ibeta.resize(nlevels);
+    d_qsx0.resize(nlevels); d_yofs.resize(nlevels); d_qsel.resize(nlevels); d_qalpha.resize(nlevels); d_ibeta.resize(nlevels);
     for (int l = 0; l < nlevels; l++) {
         LevelDesc& L = levels[l];
         L.w = (int)std::nearbyintf((float)w * inv_scale[l]);      // ComputePyramid :1175
@@ -288,8 +290,29 @@ int orbx_extractor::setup_geometry(int w, int h)
                 ib[2 * dy] = sat((1.f - fy) * 2048);
                 ib[2 * dy + 1] = sat(fy * 2048);
             }
+            // per quad of destination columns (k_resize): sx0, selectors of (S[sx], S[sx+1]) inside the 8 bytes from sx0 on,
+            // coefficient pairs; columns past the level's width get coefficient 0 (they land in the row padding as 0)
+            const int nq = wpad / 4;
+            std::vector<int> qsx0(nq);
+            std::vector<uint4> qsel(nq), qal(nq);
+            for (int q = 0; q < nq; q++) {
+                qsx0[q] = xofs[4 * q];
+                uint32_t se[4], al[4];
+                for (int k = 0; k < 4; k++) {
+                    const int dx = 4 * q + k;
+                    if (dx < L.w) {
+                        const int o = xofs[dx] - qsx0[q];
+                        if (o < 0 || o > 6) return fail(ORBX_ERR_INTERNAL, "resize table: source offset %d outside the 8-byte window", o);
+                        se[k] = (uint32_t)o | 0x0C000C00u | ((uint32_t)(o + 1) << 16);
+                        al[k] = (uint32_t)(uint16_t)ia[2 * dx] | ((uint32_t)(uint16_t)ia[2 * dx + 1] << 16);
+                    } else { se[k] = 0x0C0C0C0Cu; al[k] = 0u; }
+                }
+                qsel[q] = make_uint4(se[0], se[1], se[2], se[3]);
+                qal[q] = make_uint4(al[0], al[1], al[2], al[3]);
+            }
             int r;
-            if ((r = d_xofs[l].upload(xofs)) || (r = d_yofs[l].upload(yofs)) || (r = d_ialpha[l].upload(ia)) || (r = d_ibeta[l].upload(ib))) return r;
+            if ((r = d_qsx0[l].upload(qsx0)) || (r = d_yofs[l].upload(yofs)) || (r = d_qsel[l].upload(qsel)) || (r = d_qalpha[l].upload(qal)) ||
+                (r = d_ibeta[l].upload(ib))) return r;
         }
     }
     pyr_frame_bytes = off;
@@ -404,7 +427,15 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     auto mark = [&]() { if (profile && mark_i < kProfEvents) (void)hipEventRecord(prof_ev[mark_i++], st); };
 #define ORBX_LAUNCHED(name) do { const hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) return fail(ORBX_ERR_HIP, "launch of %s: %s", name, hipGetErrorString(le_)); } while (0)
     mark();
-    if (!level0_ready) {
+    // Level 0 is the caller's image.  When its rows can be read with aligned 16-byte loads it is used in place: the resize to
+    // level 1, FAST and the blur read it where it lies, and the blur -- which touches every pixel anyway -- leaves the copy in
+    // the pyramid that the later readers of level 0 (descriptors, stereo matching, orbx_pyramid_level) use.  Otherwise it is
+    // copied first (k_copy_level0), as it is when the host-pointer entry points have uploaded it into the pyramid themselves.
+    SrcImage lvl0;
+    lvl0.base = nullptr; lvl0.frame_stride = 0; lvl0.stride = 0; lvl0.w = levels[0].w; lvl0.h = levels[0].h;
+    const bool in_place = !level0_ready && ((uintptr_t)d_imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+    if (in_place) { lvl0.base = d_imgs; lvl0.frame_stride = frame_stride; lvl0.stride = row_stride; }
+    if (!level0_ready && !in_place) {
         const LevelDesc& L0 = levels[0];
         dim3 g((L0.w / 4 + 255) / 256, L0.h, B);
         hipLaunchKernelGGL(k_copy_level0, g, dim3(256), 0, st, d_imgs, row_stride, frame_stride, d_pyr.p, pyr_frame_bytes, L0);
@@ -413,15 +444,19 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     mark();
     for (int l = 1; l < nlevels; l++) {
         const LevelDesc& D = levels[l];
-        dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + 3) / 4)), B);
-        hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, d_pyr.p, pyr_frame_bytes, levels[l - 1], D,
-                           d_xofs[l].p, d_ialpha[l].p, d_yofs[l].p, d_ibeta[l].p);
+        dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + kResizeRows - 1) / kResizeRows)), B);
+        const LevelDesc& P = levels[l - 1];
+        SrcImage src;
+        src.base = d_pyr.p + P.off; src.frame_stride = pyr_frame_bytes; src.stride = P.stride; src.w = P.w; src.h = P.h;
+        if (l == 1 && in_place) src = lvl0;
+        hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, src, d_pyr.p, pyr_frame_bytes, D,
+                           d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
         ORBX_LAUNCHED("k_resize");
     }
     mark();
     const int n_cells = (int)cells.size();
     if (n_cells > 0)
-        hipLaunchKernelGGL(k_fast_strips, dim3(xcd_grid((int)strips.size()), B), dim3(256), fast_lds, st, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
+        hipLaunchKernelGGL(k_fast_strips, dim3(xcd_grid((int)strips.size()), B), dim3(256), fast_lds, st, lvl0, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
                            d_strips.p, (int)strips.size(), n_cells, ini_th, min_th, fast_layout, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p);
     ORBX_LAUNCHED("k_fast_strips");
     mark();
@@ -432,7 +467,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     if (overlap) {
         ORBX_HIP(hipEventRecord(ev_fork, st));
         ORBX_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
-        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, side_stream, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
+        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, side_stream, lvl0, d_pyr.p, in_place ? d_pyr.p : nullptr, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
                            (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
         ORBX_HIP(hipEventRecord(ev_join, side_stream));
     }
@@ -454,7 +489,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     mark();
     if (overlap) ORBX_HIP(hipStreamWaitEvent(st, ev_join, 0));
     else
-        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
+        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, lvl0, d_pyr.p, in_place ? d_pyr.p : nullptr, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
                            (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
     mark();
     const int quads = (sel_frame_entries + 3) / 4;
@@ -538,9 +573,10 @@ void orbx_destroy(orbx_extractor* e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     e->d_levels.release(); e->d_cells.release(); e->d_tiles.release(); e->d_strips.release();
-    for (auto& b : e->d_xofs) b.release();
+    for (auto& b : e->d_qsx0) b.release();
     for (auto& b : e->d_yofs) b.release();
-    for (auto& b : e->d_ialpha) b.release();
+    for (auto& b : e->d_qsel) b.release();
+    for (auto& b : e->d_qalpha) b.release();
     for (auto& b : e->d_ibeta) b.release();
     e->d_pyr.release(); e->d_blur.release(); e->d_cand.release(); e->d_scratch.release(); e->d_sel.release();
     e->d_cell_count.release(); e->d_sel_count.release(); e->d_kp_dst.release(); e->d_lvl_kps.release();

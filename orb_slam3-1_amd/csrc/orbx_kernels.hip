@@ -29,86 +29,81 @@ __device__ __align__(16) const signed char d_pattern[1024] = {
 // umax of the radius-15 disc (reference :453-468); fixed because HALF_PATCH_SIZE is a constant.
 __device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+
 // ------------------------------------------------------------------------------------------------
-// E1: bilinear resize, OpenCV fixed-point scheme.  One thread -> 4 horizontally adjacent output
-// pixels (one aligned dword store).  Tables (xofs, ialpha, yofs, ibeta) are built on the host.
+// E1: bilinear resize, OpenCV fixed-point scheme (cv::resize INTER_LINEAR 8UC1).  One thread -> 4 horizontally
+// adjacent output pixels (one aligned dword store); a wave = 256 pixels of one output row, a workgroup = 4 rows.
+// Everything that depends on the output column only is a host-built table per QUAD of columns: the first source column
+// sx0, and per pixel a v_perm selector that pulls (S[sx], S[sx + 1]) out of the 8 source bytes starting at sx0 as a u16 pair,
+// and the coefficient pair (ialpha0, ialpha1) -- so the horizontal pass of a pixel and source row is v_perm + v_dot2.
+// The source rows are read straight from L2 / HBM (three dwords per row and thread, no LDS staging, no barrier).
+// The source is addressed on its own (base, frame stride, row stride): level 1 is made from the caller's image in place.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, size_t frame_stride,
-                                                LevelDesc src, LevelDesc dst,
-                                                const int* __restrict__ xofs, const short* __restrict__ ialpha,
+struct SrcImage {
+    const uint8_t* base;        // first pixel of frame 0
+    size_t frame_stride;        // bytes between frames
+    int32_t stride, w, h;       // row stride in bytes (multiple of 4), size
+};
+
+constexpr int kResizeRows = 32;      // output rows per workgroup (8 per wave): few, fat workgroups -- the dispatcher starts only ~2 workgroups per ns
+
+__global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc dst,
+                                                const int* __restrict__ q_sx0, const uint4* __restrict__ q_sel, const uint4* __restrict__ q_alpha,
                                                 const int* __restrict__ yofs, const short* __restrict__ ibeta)
 {
-    // 256 threads = 64 column quads x 4 rows; tiles are numbered row-major and handed to the XCDs in contiguous bands
-    // (xcd_remap), so the 2 source rows a destination row needs are fetched by one L2 only.
-    const int tiles_x = (dst.w + 255) >> 8, tiles_y = (dst.h + 3) >> 2;
-    const int tile = xcd_remap(blockIdx.x, blockIdx.y);
+    // tiles of 256 x 32 outputs are numbered row-major and handed to the XCDs in contiguous bands (xcd_remap), so the source
+    // rows a band of destination rows needs are fetched by one L2 only
+    const int tiles_x = (dst.w + 255) >> 8, tiles_y = (dst.h + kResizeRows - 1) / kResizeRows;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x, blockIdx.y);
     if (tile >= tiles_x * tiles_y) return;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int x4 = (tx * 64 + (threadIdx.x & 63)) * 4;
-    const int dy = ty * 4 + (threadIdx.x >> 6);
-    const uint8_t* sbase = pyr + (size_t)blockIdx.y * frame_stride + src.off;
-    uint8_t* dbase = pyr + (size_t)blockIdx.y * frame_stride + dst.off;
-    // stage the source window of this 256 x 4 destination tile in LDS with coalesced dword loads (source rows are 64-B
-    // aligned); the bilinear taps then come from LDS instead of 16 scattered global byte loads per thread
-    constexpr int kPitch = 352, kRows = 8;          // 256 * 1.34 + slack; 4 dst rows need at most 7 source rows at scale >= 1
-    __shared__ __align__(16) uint8_t s_win[kRows * kPitch];
-    const int dx_first = tx * 256, dx_last = min(dx_first + 255, dst.w - 1);
-    const int dy_first = ty * 4, dy_last = min(dy_first + 3, dst.h - 1);
-    const int sy_lo = min(max(yofs[dy_first], 0), src.h - 1);
-    const int sy_hi = min(max(yofs[dy_last] + 1, 0), src.h - 1);
-    const int xa = xofs[dx_first] & ~3;
-    const int x_hi = min(xofs[dx_last] + 1, src.w - 1);
-    const int ndw = ((x_hi - xa) >> 2) + 1, nrows = sy_hi - sy_lo + 1;
-    const bool staged = (ndw * 4 <= kPitch) && (nrows <= kRows);      // always true for scale factors >= 1.0
-    if (staged) {
-        for (int i = threadIdx.x; i < nrows * ndw; i += 256) {
-            const int r = i / ndw, q = i - r * ndw;
-            *(uint32_t*)(s_win + r * kPitch + 4 * q) = *(const uint32_t*)(sbase + (size_t)(sy_lo + r) * src.stride + xa + 4 * q);
-        }
-    }
-    __syncthreads();
-    if (x4 >= dst.w || dy >= dst.h) return;
-    int sy0 = yofs[dy], sy1 = sy0 + 1;
-    sy0 = min(max(sy0, 0), src.h - 1);
-    sy1 = min(max(sy1, 0), src.h - 1);
-    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
-    // the coefficient tables are padded to a multiple of 4 entries: one 16-B load each instead of 12 scalar ones
-    const int4 sx4 = *(const int4*)(xofs + x4);
-    const uint4 al4 = *(const uint4*)(ialpha + 2 * x4);
-    const int sxs[4] = {sx4.x, sx4.y, sx4.z, sx4.w};
-    const uint32_t als[4] = {al4.x, al4.y, al4.z, al4.w};
-    // inlined twice so that each call site keeps its address space (LDS reads vs global loads, no flat accesses)
-    auto taps = [&](const uint8_t* S0, const uint8_t* S1) -> uint32_t {
-        uint32_t packed = 0;
+    const int q = tx * 64 + (threadIdx.x & 63);
+    if (4 * q >= dst.w) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sx0 = q_sx0[q];
+    const uint4 sel = q_sel[q], al = q_alpha[q];
+    const uint32_t sels[4] = {sel.x, sel.y, sel.z, sel.w}, als[4] = {al.x, al.y, al.z, al.w};
+    const int a = sx0 & ~3;
+    const uint32_t sh = (uint32_t)(sx0 & 3);
+    const int last = src.stride - 4;                            // last dword of a row: bytes past the row's pixels only meet coefficient 0
+    const int o0 = a, o1 = min(a + 4, last), o2 = min(a + 8, last);
+    const uint8_t* S = src.base + (size_t)blockIdx.y * src.frame_stride;
+    uint8_t* D = pyr + (size_t)blockIdx.y * frame_stride + dst.off + 4 * q;
+    const int dy0 = ty * kResizeRows + wave * (kResizeRows / 4);
+#pragma unroll 2
+    for (int r = 0; r < kResizeRows / 4; r++) {
+        const int dy = dy0 + r;
+        if (dy >= dst.h) break;
+        const int sy = yofs[dy];
+        const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
+        const uint32_t b0 = (uint32_t)(int)ibeta[2 * dy], b1 = (uint32_t)(int)ibeta[2 * dy + 1];
+        const uint8_t* r0p = S + (size_t)sy0 * src.stride;
+        const uint8_t* r1p = S + (size_t)sy1 * src.stride;
+        const uint32_t u0 = *(const uint32_t*)(r0p + o0), u1 = *(const uint32_t*)(r0p + o1), u2 = *(const uint32_t*)(r0p + o2);
+        const uint32_t v0 = *(const uint32_t*)(r1p + o0), v1 = *(const uint32_t*)(r1p + o1), v2 = *(const uint32_t*)(r1p + o2);
+        // the 8 source bytes from column sx0 on, per row
+        const uint32_t ulo = __builtin_amdgcn_alignbyte(u1, u0, sh), uhi = __builtin_amdgcn_alignbyte(u2, u1, sh);
+        const uint32_t vlo = __builtin_amdgcn_alignbyte(v1, v0, sh), vhi = __builtin_amdgcn_alignbyte(v2, v1, sh);
+        uint32_t out[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int dx = x4 + k;
-            if (dx < dst.w) {
-                const int sx = sxs[k];
-                const int sx1 = min(sx + 1, src.w - 1);
-                const int a0 = (int)(short)(als[k] & 0xFFFFu), a1 = (int)(short)(als[k] >> 16);
-                const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-                const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-                int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-                v = min(max(v, 0), 255);
-                packed |= (uint32_t)v << (8 * k);
-            }
+            const us2 ak = as_us2(als[k]);
+            const uint32_t h0 = __builtin_amdgcn_udot2(as_us2(__builtin_amdgcn_perm(uhi, ulo, sels[k])), ak, 0u, false);    // S0[sx] a0 + S0[sx+1] a1
+            const uint32_t h1 = __builtin_amdgcn_udot2(as_us2(__builtin_amdgcn_perm(vhi, vlo, sels[k])), ak, 0u, false);
+            const uint32_t v = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;
+            out[k] = min(v, 255u);
         }
-        return packed;
-    };
-    uint32_t packed;
-    if (staged) packed = taps(s_win + (sy0 - sy_lo) * kPitch - xa, s_win + (sy1 - sy_lo) * kPitch - xa);
-    else packed = taps(sbase + (size_t)sy0 * src.stride, sbase + (size_t)sy1 * src.stride);
-    *(uint32_t*)(dbase + (size_t)dy * dst.stride + x4) = packed;    // stride is a multiple of 64: in-row padding exists
+        // columns past dst.w: coefficients 0 -> 0; the row padding absorbs the tail of the last dword
+        *(uint32_t*)(D + (size_t)dy * dst.stride) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // E2: FAST-9/16 on strips of cells -- orbx_fast_strips.inc
 // ------------------------------------------------------------------------------------------------
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
-__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
-
 #include "orbx_fast_strips.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -495,81 +490,102 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
-constexpr int kBlurTW = 64, kBlurTH = 32;
+constexpr int kBlurTW = 64, kBlurTH = 58;        // outputs per tile; 58 + 6 = 64 staged rows = 32 row pairs
 
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, size_t frame_stride,
-                                              const LevelDesc* __restrict__ levels, const TileDesc* __restrict__ tiles, int n_tiles,
+// 256 threads per 64 x 58 output tile.  The (64 + 6) x (58 + 6) source window is staged in LDS as 16-byte chunks (rows start
+// 16 bytes left of the tile so that every chunk is an aligned dwordx4 load; chunks that touch the image border are
+// assembled byte by byte with BORDER_REFLECT_101).
+//   horizontal  one work item = 2 rows x 4 columns: per output two byte dot products (v_dot4_u32_u8) on v_alignbyte windows;
+//               the Q8.8 results of the two rows are stored as ONE dword per column (row 2p | row 2p+1 << 16)
+//   vertical    one work item = 2 rows x 4 columns: the 7 taps of an output are 4 x v_dot2_u32_u16 on those row pairs
+//               (even output row: (t0 t1)(t2 t3)(t2 t1)(t0 0), odd: (0 t0)(t1 t2)(t3 t2)(t1 t0)), rounding folded into the
+//               first accumulator, the four result bytes gathered with v_perm.
+// raw_out != nullptr (level 0 taken from the caller's image): the tile's own pixels are also copied into the pyramid, which
+// is what later readers of level 0 (descriptors, stereo matching, the mvImagePyramid getter) use.
+__global__ __launch_bounds__(256) void k_blur(SrcImage lvl0, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ raw_out, uint8_t* __restrict__ blur,
+                                              size_t frame_stride, const LevelDesc* __restrict__ levels, const TileDesc* __restrict__ tiles, int n_tiles,
                                               int t0, int t1, int t2, int t3)
 {
-    __shared__ __align__(16) uint8_t s_src[(kBlurTH + 6) * (kBlurTW + 8)];
-    __shared__ __align__(16) uint16_t s_h[(kBlurTH + 6) * kBlurTW];
-    const int tile_idx = xcd_remap(blockIdx.x, blockIdx.y);     // contiguous tile range per XCD (see k_fast_strips)
+    constexpr int SP = kBlurTW + 32, SR = kBlurTH + 6;      // LDS row = source columns x0-16 .. x0+79 (6 chunks); staged rows
+    __shared__ __align__(16) uint8_t s_src[SR * SP];
+    __shared__ __align__(16) uint32_t s_hp[(SR / 2) * kBlurTW];
+    const int tile_idx = xcd_remap(blockIdx.x, gridDim.x, blockIdx.y);     // contiguous tile range per XCD (see k_fast_strips)
     if (tile_idx >= n_tiles) return;
     const TileDesc T = tiles[tile_idx];
     const LevelDesc L = levels[T.level];
-    const uint8_t* img = pyr + (size_t)blockIdx.y * frame_stride + L.off;
+    const bool ext = T.level == 0 && lvl0.base != nullptr;
+    const uint8_t* img = ext ? lvl0.base + (size_t)blockIdx.y * lvl0.frame_stride : pyr + (size_t)blockIdx.y * frame_stride + L.off;
+    const int istride = ext ? lvl0.stride : L.stride;
     uint8_t* dst = blur + (size_t)blockIdx.y * frame_stride + L.off;
     const int tid = threadIdx.x;
     const int x0 = T.x0, y0 = T.y0;
-    constexpr int SP = kBlurTW + 8;         // LDS row = source columns x0-4 .. x0+67 (18 dwords)
-    const bool interior = (x0 >= 4) && (x0 + kBlurTW + 4 <= L.stride) && (x0 + kBlurTW + 3 <= L.w) && (y0 >= 3) && (y0 + kBlurTH + 3 <= L.h);
-    if (interior) {
-        // rows are 64-B aligned and x0 is a multiple of 64: aligned dword loads, no reflection needed
-        for (int i = tid; i < (kBlurTH + 6) * (SP / 4); i += 256) {
-            const int r = i / (SP / 4), q = i - r * (SP / 4);
-            *(uint32_t*)(s_src + r * SP + 4 * q) = *(const uint32_t*)(img + (size_t)(y0 + r - 3) * L.stride + x0 - 4 + 4 * q);
+    for (int i = tid; i < SR * (SP / 16); i += 256) {
+        const int r = i / (SP / 16), q = i - r * (SP / 16);
+        const int sy = reflect101(y0 + r - 3, L.h), cx = x0 - 16 + 16 * q;
+        uint4 v;
+        if (cx >= 0 && cx + 16 <= L.w) v = *(const uint4*)(img + (size_t)sy * istride + cx);
+        else {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            for (int b = 0; b < 16; b++) {
+                const int col = cx + b;
+                if (col >= x0 - 3 && col <= x0 + kBlurTW + 2) w[b >> 2] |= (uint32_t)img[(size_t)sy * istride + reflect101(col, L.w)] << (8 * (b & 3));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
-    } else {
-        for (int i = tid; i < (kBlurTH + 6) * SP; i += 256) {
-            const int r = i / SP, c = i - r * SP;
-            const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 - 4 + c, L.w);
-            s_src[i] = img[(size_t)sy * L.stride + sx];
-        }
+        *(uint4*)(s_src + r * SP + 16 * q) = v;
     }
     __syncthreads();
+    if (ext && raw_out != nullptr) {        // level 0 of the pyramid = the caller's image (what k_copy_level0 would have written)
+        uint8_t* raw = raw_out + (size_t)blockIdx.y * frame_stride + L.off;
+        for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
+            const int r = i >> 4, q = i & 15;
+            if (y0 + r < L.h && x0 + 4 * q < L.w) *(uint32_t*)(raw + (size_t)(y0 + r) * L.stride + x0 + 4 * q) = *(const uint32_t*)(s_src + (r + 3) * SP + 16 + 4 * q);
+        }
+    }
     const uint32_t tapA = (uint32_t)t0 | ((uint32_t)t1 << 8) | ((uint32_t)t2 << 16) | ((uint32_t)t3 << 24);
     const uint32_t tapB = (uint32_t)t2 | ((uint32_t)t1 << 8) | ((uint32_t)t0 << 16);
-    // horizontal pass: one work item = 4 adjacent outputs, fed by three aligned dword LDS reads (12 source bytes)
-    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW / 4); i += 256) {
-        const int r = i / (kBlurTW / 4), q = i - r * (kBlurTW / 4);
-        const uint32_t* w = (const uint32_t*)(s_src + r * SP) + q;
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        // output column 4q+k uses source bytes k+1 .. k+7 of the 12: two byte dot products (v_dot4_u32_u8) per output,
-        // taps (t0 t1 t2 t3) on bytes k+1..k+4 and (t2 t1 t0 0) on bytes k+5..k+8; the windows come from v_alignbyte.
-        // The taps sum to 256, so a sum never exceeds 255 * 256 = 65280: no clamp needed.
-        uint32_t o[4];
-        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), tapB, 0u, false), false);
-        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), tapB, 0u, false), false);
-        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), tapB, 0u, false), false);
-        o[3] = __builtin_amdgcn_udot4(w1, tapA, __builtin_amdgcn_udot4(w2, tapB, 0u, false), false);
-        uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
-        *(uint2*)(s_h + r * kBlurTW + 4 * q) = pk;
+    // ---- horizontal: output column 4q+k of a row uses source bytes k+1 .. k+7 of the 12 bytes w0 w1 w2 (taps (t0 t1 t2 t3) on
+    // k+1..k+4, (t2 t1 t0 0) on k+5..k+8).  The taps sum to 256, so a sum never exceeds 255 * 256 = 65280: it fits 16 bits. ----
+    for (int i = tid; i < (SR / 2) * (kBlurTW / 4); i += 256) {
+        const int p = i >> 4, q = i & 15;
+        uint32_t o[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint32_t* w = (const uint32_t*)(s_src + (2 * p + rr) * SP + 12) + q;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            o[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), tapB, 0u, false), false);
+            o[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), tapB, 0u, false), false);
+            o[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), tapA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), tapB, 0u, false), false);
+            o[rr][3] = __builtin_amdgcn_udot4(w1, tapA, __builtin_amdgcn_udot4(w2, tapB, 0u, false), false);
+        }
+        *(uint4*)(s_hp + p * kBlurTW + 4 * q) = make_uint4(o[0][0] | (o[1][0] << 16), o[0][1] | (o[1][1] << 16), o[0][2] | (o[1][2] << 16), o[0][3] | (o[1][3] << 16));
     }
     __syncthreads();
-    // vertical pass: one work item = 2 rows x 4 columns of outputs, fed by eight 8-byte LDS reads
-    {
-        const int q = tid & 15, g = tid >> 4;          // 16 column quads x 16 row pairs
-        const int c4 = 4 * q, r0 = 2 * g;
-        uint32_t h[8][4];
+    // ---- vertical ----
+    const us2 cE0 = as_us2((uint32_t)t0 | ((uint32_t)t1 << 16)), cE1 = as_us2((uint32_t)t2 | ((uint32_t)t3 << 16)),
+              cE2 = as_us2((uint32_t)t2 | ((uint32_t)t1 << 16)), cE3 = as_us2((uint32_t)t0);
+    const us2 cO0 = as_us2((uint32_t)t0 << 16), cO1 = as_us2((uint32_t)t1 | ((uint32_t)t2 << 16)),
+              cO2 = as_us2((uint32_t)t3 | ((uint32_t)t2 << 16)), cO3 = as_us2((uint32_t)t1 | ((uint32_t)t0 << 16));
+    for (int i = tid; i < (kBlurTH / 2) * (kBlurTW / 4); i += 256) {
+        const int m = i >> 4, q = i & 15;
+        const int oy = y0 + 2 * m, ox = x0 + 4 * q;
+        if (oy >= L.h || ox >= L.w) continue;
+        const uint4 P0 = *(const uint4*)(s_hp + m * kBlurTW + 4 * q), P1 = *(const uint4*)(s_hp + (m + 1) * kBlurTW + 4 * q),
+                    P2 = *(const uint4*)(s_hp + (m + 2) * kBlurTW + 4 * q), P3 = *(const uint4*)(s_hp + (m + 3) * kBlurTW + 4 * q);
+        const uint32_t a0[4] = {P0.x, P0.y, P0.z, P0.w}, a1[4] = {P1.x, P1.y, P1.z, P1.w}, a2[4] = {P2.x, P2.y, P2.z, P2.w}, a3[4] = {P3.x, P3.y, P3.z, P3.w};
+        uint32_t e[4], o[4];
 #pragma unroll
-        for (int rr = 0; rr < 8; rr++) {
-            const uint2 v = *(const uint2*)(s_h + (r0 + rr) * kBlurTW + c4);
-            h[rr][0] = v.x & 0xFFFFu; h[rr][1] = v.x >> 16; h[rr][2] = v.y & 0xFFFFu; h[rr][3] = v.y >> 16;
+        for (int k = 0; k < 4; k++) {       // Q16.16 sums + 0x8000: the result byte is bits 16..23 (at most 255 * 65536 + 32768)
+            e[k] = __builtin_amdgcn_udot2(as_us2(a3[k]), cE3, __builtin_amdgcn_udot2(as_us2(a2[k]), cE2, __builtin_amdgcn_udot2(as_us2(a1[k]), cE1,
+                   __builtin_amdgcn_udot2(as_us2(a0[k]), cE0, 0x8000u, false), false), false), false);
+            o[k] = __builtin_amdgcn_udot2(as_us2(a3[k]), cO3, __builtin_amdgcn_udot2(as_us2(a2[k]), cO2, __builtin_amdgcn_udot2(as_us2(a1[k]), cO1,
+                   __builtin_amdgcn_udot2(as_us2(a0[k]), cO0, 0x8000u, false), false), false), false);
         }
-#pragma unroll
-        for (int orow = 0; orow < 2; orow++) {
-            const int oy = y0 + r0 + orow;
-            if (oy < L.h && x0 + c4 < L.w) {
-                uint32_t packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t acc = (uint32_t)t0 * (h[orow][k] + h[orow + 6][k]) + (uint32_t)t1 * (h[orow + 1][k] + h[orow + 5][k]) +
-                                         (uint32_t)t2 * (h[orow + 2][k] + h[orow + 4][k]) + (uint32_t)t3 * h[orow + 3][k];
-                    packed |= min((acc + 0x8000u) >> 16, 255u) << (8 * k);
-                }
-                *(uint32_t*)(dst + (size_t)oy * L.stride + x0 + c4) = packed;   // row padding absorbs the tail of the last dword
-            }
-        }
+        // bytes 2 of four accumulators -> one dword
+        const uint32_t pe = __builtin_amdgcn_perm(__builtin_amdgcn_perm(e[3], e[2], 0x0C0C0602u), __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0602u), 0x05040100u);
+        const uint32_t po = __builtin_amdgcn_perm(__builtin_amdgcn_perm(o[3], o[2], 0x0C0C0602u), __builtin_amdgcn_perm(o[1], o[0], 0x0C0C0602u), 0x05040100u);
+        *(uint32_t*)(dst + (size_t)oy * L.stride + ox) = pe;                       // the row padding absorbs the tail of the last dword
+        if (oy + 1 < L.h) *(uint32_t*)(dst + (size_t)(oy + 1) * L.stride + ox) = po;
     }
 }
 
