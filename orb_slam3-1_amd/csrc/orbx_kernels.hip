@@ -48,6 +48,7 @@ struct SrcImage {
     int32_t stride, w, h;       // row stride in bytes (multiple of 4), size
 };
 
+struct __attribute__((aligned(4))) Dwords3 { uint32_t x, y, z; };     // 12 bytes at dword alignment: one global_load_dwordx3
 constexpr int kResizeRows = 32;      // output rows per workgroup (8 per wave): few, fat workgroups -- the dispatcher starts only ~2 workgroups per ns
 
 __global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc dst,
@@ -73,28 +74,43 @@ __global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restric
     const uint8_t* S = src.base + (size_t)blockIdx.y * src.frame_stride;
     uint8_t* D = pyr + (size_t)blockIdx.y * frame_stride + dst.off + 4 * q;
     const int dy0 = ty * kResizeRows + wave * (kResizeRows / 4);
-#pragma unroll 2
-    for (int r = 0; r < kResizeRows / 4; r++) {
-        const int dy = dy0 + r;
-        if (dy >= dst.h) break;
+    constexpr int NR = kResizeRows / 4;
+    // all the loads of the wave's rows are issued before the first result is stored (the compiler cannot move a load above a
+    // store through pointers it cannot tell apart): 48 dwords in flight per thread instead of 6
+    uint32_t u[NR][3], v[NR][3], bb[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int dy = __builtin_amdgcn_readfirstlane(min(dy0 + r, dst.h - 1));       // wave-uniform: scalar table loads
         const int sy = yofs[dy];
         const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
-        const uint32_t b0 = (uint32_t)(int)ibeta[2 * dy], b1 = (uint32_t)(int)ibeta[2 * dy + 1];
+        bb[r] = ((const uint32_t*)ibeta)[dy];                      // (ibeta0, ibeta1) as one scalar dword
         const uint8_t* r0p = S + (size_t)sy0 * src.stride;
         const uint8_t* r1p = S + (size_t)sy1 * src.stride;
-        const uint32_t u0 = *(const uint32_t*)(r0p + o0), u1 = *(const uint32_t*)(r0p + o1), u2 = *(const uint32_t*)(r0p + o2);
-        const uint32_t v0 = *(const uint32_t*)(r1p + o0), v1 = *(const uint32_t*)(r1p + o1), v2 = *(const uint32_t*)(r1p + o2);
+        if (a + 8 <= last) {        // one 12-byte load per row: the address unit handles 4 lanes per clock whatever the width
+            const Dwords3 tu = *(const Dwords3*)(r0p + a), tv = *(const Dwords3*)(r1p + a);
+            u[r][0] = tu.x; u[r][1] = tu.y; u[r][2] = tu.z;
+            v[r][0] = tv.x; v[r][1] = tv.y; v[r][2] = tv.z;
+        } else {                    // the last quads of a row: never read past the row's last dword
+            u[r][0] = *(const uint32_t*)(r0p + o0); u[r][1] = *(const uint32_t*)(r0p + o1); u[r][2] = *(const uint32_t*)(r0p + o2);
+            v[r][0] = *(const uint32_t*)(r1p + o0); v[r][1] = *(const uint32_t*)(r1p + o1); v[r][2] = *(const uint32_t*)(r1p + o2);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int dy = dy0 + r;
+        if (dy >= dst.h) break;
+        const uint32_t b0 = bb[r] & 0xFFFFu, b1 = bb[r] >> 16;
         // the 8 source bytes from column sx0 on, per row
-        const uint32_t ulo = __builtin_amdgcn_alignbyte(u1, u0, sh), uhi = __builtin_amdgcn_alignbyte(u2, u1, sh);
-        const uint32_t vlo = __builtin_amdgcn_alignbyte(v1, v0, sh), vhi = __builtin_amdgcn_alignbyte(v2, v1, sh);
+        const uint32_t ulo = __builtin_amdgcn_alignbyte(u[r][1], u[r][0], sh), uhi = __builtin_amdgcn_alignbyte(u[r][2], u[r][1], sh);
+        const uint32_t vlo = __builtin_amdgcn_alignbyte(v[r][1], v[r][0], sh), vhi = __builtin_amdgcn_alignbyte(v[r][2], v[r][1], sh);
         uint32_t out[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const us2 ak = as_us2(als[k]);
             const uint32_t h0 = __builtin_amdgcn_udot2(as_us2(__builtin_amdgcn_perm(uhi, ulo, sels[k])), ak, 0u, false);    // S0[sx] a0 + S0[sx+1] a1
             const uint32_t h1 = __builtin_amdgcn_udot2(as_us2(__builtin_amdgcn_perm(vhi, vlo, sels[k])), ak, 0u, false);
-            const uint32_t v = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;
-            out[k] = min(v, 255u);
+            const uint32_t val = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;
+            out[k] = min(val, 255u);
         }
         // columns past dst.w: coefficients 0 -> 0; the row padding absorbs the tail of the last dword
         *(uint32_t*)(D + (size_t)dy * dst.stride) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
