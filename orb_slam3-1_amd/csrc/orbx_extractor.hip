@@ -387,15 +387,16 @@ int orbx_extractor::ensure_batch(int batch)
     if (batch <= batch_cap) return ORBX_OK;
     int r;
     const size_t B = (size_t)batch;
-    if ((r = d_pyr.ensure(B * pyr_frame_bytes)) || (r = d_blur.ensure(B * pyr_frame_bytes)) ||
+    // + 64: the 16-byte patch chunks of k_orient_desc may start up to 45 bytes right of a key point's last patch column
+    if ((r = d_pyr.ensure(B * pyr_frame_bytes + 64)) || (r = d_blur.ensure(B * pyr_frame_bytes + 64)) ||
         (r = d_cand.ensure(B * cand_frame_entries)) || (r = d_scratch.ensure(B * 2 * cand_frame_entries)) ||
         (r = d_sel.ensure(B * sel_frame_entries)) || (r = d_cell_count.ensure(B * std::max<size_t>(cells.size(), 1))) ||
         (r = d_sel_count.ensure(B * nlevels)) || (r = d_kp_dst.ensure(B * sel_frame_entries)) ||
         (r = d_lvl_kps.ensure(B * sel_frame_entries)) || (r = d_n.ensure(B)) || (r = d_mono.ensure(B)) || (r = d_status.ensure(B)))
         return r;
     // the pyramid row padding is read by dword loads at row ends; keep it defined
-    ORBX_HIP(hipMemset(d_pyr.p, 0, B * pyr_frame_bytes));
-    ORBX_HIP(hipMemset(d_blur.p, 0, B * pyr_frame_bytes));
+    ORBX_HIP(hipMemset(d_pyr.p, 0, B * pyr_frame_bytes + 64));
+    ORBX_HIP(hipMemset(d_blur.p, 0, B * pyr_frame_bytes + 64));
     batch_cap = batch;
     return ORBX_OK;
 }

@@ -26,9 +26,6 @@ __device__ __align__(16) const signed char d_pattern[1024] = {
 #include "orb_pattern_31.inc"
 };
 
-// umax of the radius-15 disc (reference :453-468); fixed because HALF_PATCH_SIZE is a constant.
-__device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -609,6 +606,24 @@ __global__ __launch_bounds__(256) void k_blur(SrcImage lvl0, const uint8_t* __re
 // E5 + E7 + E8: one wave per keypoint.  IC_Angle on the unblurred level, steered BRIEF on the blurred
 // level, then the cv::KeyPoint record and the 32-byte descriptor are written to their output row.
 // ------------------------------------------------------------------------------------------------
+// mask of the radius-15 disc (umax, :453-468) per patch row, as byte masks of the 8 dwords that hold columns u = -15 .. 16
+struct IcMask { uint32_t m[32][8]; };
+constexpr IcMask make_ic_mask()
+{
+    IcMask t{};
+    const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int r = 0; r < 31; r++) {
+        const int v = r - 15, av = v < 0 ? -v : v;
+        for (int j = 0; j < 8; j++)
+            for (int k = 0; k < 4; k++) {
+                const int u = -15 + 4 * j + k, au = u < 0 ? -u : u;
+                if (u <= 15 && au <= um[av]) t.m[r][j] |= 0xFFu << (8 * k);
+            }
+    }
+    return t;
+}
+__device__ const IcMask d_ic_mask = make_ic_mask();
+
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur, size_t frame_stride,
                                                      const LevelDesc* __restrict__ levels, int n_levels,
                                                      const uint32_t* __restrict__ sel, int sel_frame_stride,
@@ -618,12 +633,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
                                                      OrbxKeyPoint* __restrict__ lvl_kps /* optional: per-level keypoints, level coords */,
                                                      int quads_per_frame, int batch)
 {
-    // Both patches a keypoint needs -- the 31x31 disc of the unblurred level (IC_Angle) and the 37x37 window
-    // of the blurred level that the rotated pattern can reach (|coordinate| <= 18 < EDGE_THRESHOLD) -- are fetched up front
-    // with aligned dword loads into a wave-private LDS window, so a wave sees two dependent memory round trips (selection
-    // record, patches) instead of four, and 11 dword requests per lane instead of 24 byte requests.
-    constexpr int kBR = 18, kBW = 10, kPR = 15, kPW = 9;        // blur: 37 rows x 10 dwords; pyr: 31 rows x 9 dwords
-    __shared__ uint32_t s_patch[4][(2 * kBR + 1) * kBW + (2 * kPR + 1) * kPW];
+    // Both patches a keypoint needs -- the 31x31 disc of the unblurred level (IC_Angle) and the 37x37 window of the blurred
+    // level that the rotated pattern can reach (|coordinate| <= 18 < EDGE_THRESHOLD) -- are fetched up front as aligned 16-byte
+    // chunks into a wave-private LDS window (the address unit takes 16 clocks per wave-wide load whatever its width: 5 wide
+    // loads per lane instead of 11 dword loads), so a wave sees two dependent memory round trips (selection record, patches).
+    constexpr int kBR = 18, kBP = 64, kPR = 15, kPP = 48;       // blur: 37 rows x 4 chunks; pyr: 31 rows x 3 chunks
+    constexpr int kBBytes = (2 * kBR + 1) * kBP, kPBytes = (2 * kPR + 1) * kPP;
+    __shared__ __align__(16) uint8_t s_patch[4][kBBytes + kPBytes];
     // 1-D grid of quads_per_frame * batch workgroups.  Workgroup w runs on XCD w % 8: giving XCD k the contiguous range
     // [k * total / 8, (k + 1) * total / 8) of (frame, quad) pairs keeps all the patches of a frame in ONE L2 (2.4 MB of
     // pyramid + blur per frame against 4 MB of L2) instead of fetching every frame into all eight.
@@ -647,19 +663,19 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; q++) pw[q] = ((const uint32_t*)d_pattern)[lane + 64 * q];       // one dword = (x0, y0, x1, y1) as int8
     const int px = (int)key_x(e) + 16, py = (int)key_y(e) + 16;     // level coordinates (:885-886)
-    uint32_t* sb = s_patch[wave];
-    uint32_t* sp = sb + (2 * kBR + 1) * kBW;
-    const int xb = (px - kBR) & ~3, xp = (px - kPR) & ~3;           // dword-aligned window starts (rows are 64-B aligned)
+    uint8_t* sb = s_patch[wave];
+    uint8_t* sp = sb + kBBytes;
+    const int xb = (px - kBR) & ~15, xp = (px - kPR) & ~15;         // 16-byte aligned window starts (rows are 64-B aligned)
     if (live) {
         const uint8_t* bbase = blur + (size_t)frame * frame_stride + L.off + (size_t)(py - kBR) * L.stride + xb;
         const uint8_t* pbase = pyr + (size_t)frame * frame_stride + L.off + (size_t)(py - kPR) * L.stride + xp;
-        for (int i = lane; i < (2 * kBR + 1) * kBW; i += 64) {
-            const int r = i / kBW, c = i - r * kBW;
-            sb[i] = *(const uint32_t*)(bbase + (size_t)r * L.stride + 4 * c);
+        for (int i = lane; i < (2 * kBR + 1) * 4; i += 64) {
+            const int r = i >> 2, c = i & 3;
+            *(uint4*)(sb + r * kBP + 16 * c) = *(const uint4*)(bbase + (size_t)r * L.stride + 16 * c);
         }
-        for (int i = lane; i < (2 * kPR + 1) * kPW; i += 64) {
-            const int r = i / kPW, c = i - r * kPW;
-            sp[i] = *(const uint32_t*)(pbase + (size_t)r * L.stride + 4 * c);
+        for (int i = lane; i < (2 * kPR + 1) * 3; i += 64) {
+            const int r = (i * 43) >> 7, c = i - 3 * r;              // i / 3 for i < 128
+            *(uint4*)(sp + r * kPP + 16 * c) = *(const uint4*)(pbase + (size_t)r * L.stride + 16 * c);
         }
     }
     // the LDS window is private to the wave: its own writes are ordered before its own reads by the LDS queue; only the
@@ -669,22 +685,27 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!live) return;
 
-    // ---- IC_Angle: lanes 0..30 take column u = lane-15 of rows v = 0..15, lanes 32..62 the same column of rows -1..-15
-    const uint8_t* img = (const uint8_t*)sp + kPR * (4 * kPW) + (px - xp);      // patch centre
-    const int half = lane >> 5;
-    const int u = (lane & 31) - 15, au = u < 0 ? -u : u;
-    const unsigned long long kUmax = 0x3689ABCDDEEEFFFFull;     // umax[v] of the radius-15 disc (:453-468), 4 bits each
+    // ---- IC_Angle (:76-103): lane r < 31 owns patch row v = r - 15: its 31 bytes as 8 byte-aligned dwords, masked to the disc;
+    // the row sums  a = sum I  and  b = sum (u + 15) I  are byte dot products, m10 += b - 15 a, m01 += v a ----
     int m10 = 0, m01 = 0;
-    if ((lane & 31) < 31) {
+    if (lane < 2 * kPR + 1) {
+        const int c0 = px - kPR - xp;                                 // byte of column u = -15 inside the window row (wave-uniform)
+        const uint32_t* rw = (const uint32_t*)(sp + lane * kPP + (c0 & ~3));
+        const uint32_t sh = (uint32_t)(c0 & 3);
+        uint32_t w[9];
 #pragma unroll
-        for (int vi = 0; vi < 16; vi++) {
-            const int v = half ? -(vi + 1) : vi;
-            const int av = half ? vi + 1 : vi;
-            const bool in = (av <= 15) && (au <= (int)((kUmax >> (4 * (av & 15))) & 15));
-            const int val = in ? (int)img[v * (4 * kPW) + u] : 0;
-            m10 += u * val;
-            m01 += v * val;
+        for (int j = 0; j < 9; j++) w[j] = rw[j];
+        const uint4 ma = *(const uint4*)&d_ic_mask.m[lane][0], mb = *(const uint4*)&d_ic_mask.m[lane][4];
+        const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+        uint32_t a = 0u, b = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t d = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh) & mk[j];
+            a = __builtin_amdgcn_udot4(d, 0x01010101u, a, false);
+            b = __builtin_amdgcn_udot4(d, 0x03020100u + 0x04040404u * (uint32_t)j, b, false);
         }
+        m10 = (int)b - 15 * (int)a;
+        m01 = (lane - kPR) * (int)a;
     }
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -693,15 +714,15 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
     float a, b;
     sincos_f32(angle * factorPI, &a, &b);
-    const uint8_t* bimg = (const uint8_t*)sb + kBR * (4 * kBW) + (px - xb);
+    const uint8_t* bimg = sb + kBR * kBP + (px - xb);
     unsigned long long w[4];
     int t0s[4], t1s[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float x0 = (float)(signed char)(pw[q] & 0xFF), y0 = (float)(signed char)((pw[q] >> 8) & 0xFF);
         const float x1 = (float)(signed char)((pw[q] >> 16) & 0xFF), y1 = (float)(signed char)(pw[q] >> 24);
-        t0s[q] = bimg[cv_round_f(x0 * b + y0 * a) * (4 * kBW) + cv_round_f(x0 * a - y0 * b)];
-        t1s[q] = bimg[cv_round_f(x1 * b + y1 * a) * (4 * kBW) + cv_round_f(x1 * a - y1 * b)];
+        t0s[q] = bimg[cv_round_f(x0 * b + y0 * a) * kBP + cv_round_f(x0 * a - y0 * b)];
+        t1s[q] = bimg[cv_round_f(x1 * b + y1 * a) * kBP + cv_round_f(x1 * a - y1 * b)];
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) w[q] = __ballot(t0s[q] < t1s[q]);
