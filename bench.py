@@ -73,12 +73,12 @@ def stage_algorithmic_bytes(level_sizes, n_kp, n_cand):
     px = [w * h for (w, h) in level_sizes]
     return {
         "resize": sum(px[:-1]) + sum(px[1:]),               # read levels 0..L-2, write levels 1..L-1
-        "fast_cells": sum(px) + 4 * n_cand,                 # every level read once + candidate records
+        "fast_strips": sum(px) + 4 * n_cand,                 # every level read once + candidate records
         "octree": 2 * 4 * n_cand + 4 * n_kp,                # candidate keys in/out (latency-bound stage)
         "index": 8 * n_kp,
         "blur": 2 * sum(px),                                # read + write every level
         "orient_desc": n_kp * (31 * 31 + 37 * 37) + n_kp * 60,   # patch reads + 28 B keypoint + 32 B descriptor
-        "copy_level0": 2 * px[0],
+        "copy_level0": 2 * px[0],                            # only when the input cannot be read in place (unaligned)
     }
 
 
@@ -250,17 +250,6 @@ def main():
                            "pipeline_frac": ALGO_BYTES_PER_FRAME * value / 1e9 / HBM_PEAK_GBS,
                            "launch_ms": acc[dom], "algorithmic_bytes_per_launch": sb[dom] * B,
                            "stage_ms": acc, "stage_gbs": {k: sb[k] * B / (max(acc[k], 1e-6) * 1e-3) / 1e9 for k in acc}}
-        # The HBM fraction above is what the contract asks for, but it is not what bounds this kernel: FAST is integer VALU work.
-        # SQ_INSTS_VALU of one launch (a separate rocprofv3 --pmc pass, profiles/r01_n_sq_counters.txt: 4.34e8 wave-instructions
-        # for 256 frames; the count is a property of the images, not of the run) against the chip's VALU issue rate
-        # (256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz) with the launch time measured in THIS run.
-        if dom == "fast_cells":
-            valu_insts = 4.34e8 * B / 256.0
-            peak_issue = 256 * 4 * 2.4e9 / 4.0
-            out["roofline"]["valu_issue"] = {"achieved": valu_insts / (acc[dom] * 1e-3), "peak": peak_issue, "unit": "wave-instructions/s",
-                                             "frac": valu_insts / (acc[dom] * 1e-3) / peak_issue,
-                                             "source": "SQ_INSTS_VALU per launch from profiles/r01_n_sq_counters.txt, launch time from this run"}
-
         # ---- extra leg: the batch cut over S independent streams (one Extractor handle + BoW plan per stream, like the
         # reference's one ORBextractor per camera thread).  Stages with different bottlenecks (FAST: VALU, octree /
         # descriptors / BoW: latency) then overlap across streams and across steps.  Not the headline: per-kernel
@@ -319,18 +308,22 @@ def main():
             mflop = LBA_MFLOP_FIRST_TRIAL * iters + LBA_MFLOP_EXTRA_TRIAL * (trials - iters)
             achieved_tf = mflop * 1e-6 / dt
             stage = {}
-            try:
-                stage = sh.stage_profile(3)          # {kernel: ms per trial}, HIP events around every launch of three trials
+            try:                                      # HIP events on the solver's stream around every group of launches, one more solve
+                sh.reset(); sh.profile_enable(True)
+                sp = dmod.sharded_bundle_adjustment(ad, None, None, max_iters=10)
+                stage = {k: v / max(sp["trials"], 1) for k, v in sh.profile_read().items()}
+                sh.profile_enable(False)
             except Exception as e:  # noqa: BLE001
                 log("lba stage profile unavailable: %r" % (e,))
-            dom_k = max(stage, key=stage.get) if stage else None
+            dom_s = max((k for k in stage if k != "gaps"), key=stage.get) if stage else None
+            dom_k = pkg.LbaShard.STAGE_KERNEL.get(dom_s) if dom_s else None
             out["lba"] = {"metric": "LocalBA outer iterations/s", "value": iters / dt, "unit": "iters/s", "dtype": "f64",
                           "workload": "50 opt + 10 fixed KF, 2000 MP, %d mono edges, optimize(10)" % len(w["edge_point"]),
                           "iterations_per_solve": stats["iterations"], "trials_per_solve": stats["trials"],
                           "ms_per_iteration": 1e3 * dt / max(iters, 1), "ms_per_trial": 1e3 * dt / max(trials, 1),
                           "roofline": {"bound": "mfma", "kernel": dom_k, "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": achieved_tf / FP64_PEAK_TFLOPS, "mflop_per_iteration": LBA_MFLOP_FIRST_TRIAL,
-                                       "kernel_ms_per_trial": stage.get(dom_k) if dom_k else None, "traffic": None},
+                                       "kernel_ms_per_trial": stage.get(dom_s) if dom_s else None, "traffic": None},
                           "stage_ms_per_trial": stage,
                           "lba_solve_call_ms_incl_upload": 1e3 * dt_call, "chi2_initial": stats["chi2_initial"], "chi2_final": stats["chi2_final"]}
             sh.close(); solver.close()

@@ -406,6 +406,18 @@ int lba_shard_hint_lambda(lba_shard* s, double lambda);
 int lba_shard_set_reduce_buffer(lba_shard* s, double* device_buffer);
 /* local != 0: world size 1, no all-reduce between reduce() and finish() -> lambda is folded into the Schur kernel, no sync */
 int lba_shard_set_local(lba_shard* s, int local);
+/* Stream hand-over for the exchange step without a host synchronisation: fence_out makes `other_stream` (a hipStream_t, the
+ * collective's stream) wait for the shard's work enqueued so far, fence_in makes the shard's stream wait for `other_stream`.
+ * After lba_shard_set_async_reduce(s, 1), lba_shard_reduce() only enqueues; the caller brackets its all-reduce of the reduce
+ * buffer with the two fences. */
+int lba_shard_fence_out(lba_shard* s, void* other_stream);
+int lba_shard_fence_in(lba_shard* s, void* other_stream);
+int lba_shard_set_async_reduce(lba_shard* s, int on);
+/* Per-stage device time, HIP events on the shard's stream: enable(1) starts a fresh profile, read() returns the milliseconds
+ * accumulated since per stage: {linearise, Schur complement, factorisation, substitution, update + errors, reductions,
+ * gaps between the groups of launches}. */
+int lba_shard_profile_enable(lba_shard* s, int on);
+int lba_shard_profile_read(lba_shard* s, float* stage_ms, int n_stages);
 int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses_local, double* max_diag_landmarks_local);
 int lba_shard_reduce(lba_shard* s, double lambda);
 /* returns 1 if the reduced system was solved, 0 if it was not positive definite (step is rejected), <0 on error.

@@ -207,7 +207,7 @@ class Extractor:
         lib.orbx_profile_enable.argtypes = [C.c_void_p, C.c_int]
         _check(lib.orbx_profile_enable(self._h, int(on)))
 
-    STAGES = ("copy_level0", "resize", "fast_cells", "octree", "index", "blur", "orient_desc")
+    STAGES = ("copy_level0", "resize", "fast_strips", "octree", "index", "blur", "orient_desc")
 
     def profile_read(self):
         """per-stage device milliseconds of the last call (HIP events on the launch stream)"""
@@ -663,6 +663,33 @@ class LbaShard:
 
     def accept(self, ok):
         _check(lib.lba_shard_accept(self._h, int(ok)))
+
+    STAGES = ("linearize", "schur", "factor", "solve", "update", "reduce", "gaps")
+    STAGE_KERNEL = {"linearize": "k_lin_all", "schur": "k_schur_blocks", "factor": "k_chol_step", "solve": "k_chol_solve",
+                    "update": "k_backsub_update", "reduce": "k_reduce", "gaps": None}
+
+    def profile_enable(self, on=True):
+        lib.lba_shard_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.lba_shard_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """milliseconds per stage (HIP events on the shard's stream) accumulated since profile_enable(True)"""
+        lib.lba_shard_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        ms = np.zeros(len(self.STAGES), np.float32)
+        _check(lib.lba_shard_profile_read(self._h, _p(ms), len(ms)))
+        return dict(zip(self.STAGES, [float(v) for v in ms]))
+
+    def fence_out(self, other_stream):
+        lib.lba_shard_fence_out.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib.lba_shard_fence_out(self._h, C.c_void_p(other_stream)))
+
+    def fence_in(self, other_stream):
+        lib.lba_shard_fence_in.argtypes = [C.c_void_p, C.c_void_p]
+        _check(lib.lba_shard_fence_in(self._h, C.c_void_p(other_stream)))
+
+    def set_async_reduce(self, on=True):
+        lib.lba_shard_set_async_reduce.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.lba_shard_set_async_reduce(self._h, int(on)))
 
     def reset(self):
         lib.lba_shard_reset.argtypes = [C.c_void_p]

@@ -437,29 +437,33 @@ __device__ __forceinline__ double rsqrt_newton(double d)
     inv = inv * fma(-0.5 * d * inv, inv, 1.5);
     return inv * fma(-0.5 * d * inv, inv, 1.5);
 }
-__device__ __forceinline__ bool chol_tile4(double (&Lr)[4][4], int nb, double* __restrict__ Li, CholVec4& sv)
+// TG x TG threads, E x E elements each (TG * E = 64): 16 x 16 threads with 4 x 4 tiles (the form in use), or 32 x 32 threads with
+// 2 x 2 tiles.
+template <int TG, int E>
+__device__ __forceinline__ bool chol_tile4(double (&Lr)[E][E], int nb, double* __restrict__ Li, CholVec4& sv)
 {
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    double Xr[4][4];
+    static_assert(TG * E == 64, "the padded block is 64 x 64");
+    const int tid = threadIdx.x, ty = tid / TG, tx = tid % TG;
+    double Xr[E][E];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < E; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) Xr[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
+        for (int b = 0; b < E; b++) Xr[a][b] = (ty + TG * a == tx + TG * b) ? 1.0 : 0.0;
     bool failed = false;
 #pragma unroll
-    for (int ja = 0; ja < 4; ja++) {
-        for (int jy = 0; jy < 16; jy += 4) {
-            const int j0 = 16 * ja + jy;
+    for (int ja = 0; ja < E; ja++) {
+        for (int jy = 0; jy < TG; jy += 4) {
+            const int j0 = TG * ja + jy;
             if (j0 >= nb || failed) break;                  // a partial last group pairs with the identity padding
             const int p = (jy >> 2) & 1;
             const int ko = tx - jy, kr = ty - jy;           // 0..3: this thread owns a pivot column / a pivot row
             if (ko >= 0 && ko < 4) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) sv.col[p][ko][ty + 16 * a] = Lr[a][ja];
+                for (int a = 0; a < E; a++) sv.col[p][ko][ty + TG * a] = Lr[a][ja];
             }
             if (kr >= 0 && kr < 4) {
 #pragma unroll
-                for (int b = 0; b < 4; b++) sv.row[p][kr][tx + 16 * b] = Xr[ja][b];
+                for (int b = 0; b < E; b++) sv.row[p][kr][tx + TG * b] = Xr[ja][b];
             }
             __syncthreads();
             // pivot block (lower triangle): P[k][m] = column m, row j0 + k
@@ -486,11 +490,11 @@ __device__ __forceinline__ bool chol_tile4(double (&Lr)[4][4], int nb, double* _
             const double M20 = -fma(l21, M10, l20 * M00) * i2, M21 = -(l21 * M11) * i2;
             const double M30 = -fma(l32, M20, fma(l31, M10, l30 * M00)) * i3, M31 = -fma(l32, M21, l31 * M11) * i3, M32 = -(l32 * M22) * i3;
             // ja is a compile-time constant inside the unrolled outer loop, so whole register tiles drop out
-            double u[4][4], v[4][4], xn[4][4];              // [k][a], [k][b], [k][b]
+            double u[4][E], v[4][E], xn[4][E];              // [k][a], [k][b], [k][b]
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+            for (int a = 0; a < E; a++) {
                 if (a < ja) continue;
-                const int r = ty + 16 * a;
+                const int r = ty + TG * a;
                 const double c0 = sv.col[p][0][r], c1 = sv.col[p][1][r], c2 = sv.col[p][2][r], c3 = sv.col[p][3][r];
                 const bool below = r > j0 + 3;              // rows of the pivot block and above take no update
                 u[0][a] = below ? M00 * c0 : 0.0;
@@ -499,8 +503,8 @@ __device__ __forceinline__ bool chol_tile4(double (&Lr)[4][4], int nb, double* _
                 u[3][a] = below ? fma(M33, c3, fma(M32, c2, fma(M31, c1, M30 * c0))) : 0.0;
             }
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int c = tx + 16 * b;
+            for (int b = 0; b < E; b++) {
+                const int c = tx + TG * b;
                 if (b >= ja) {
                     const double c0 = sv.col[p][0][c], c1 = sv.col[p][1][c], c2 = sv.col[p][2][c], c3 = sv.col[p][3][c];
                     v[0][b] = M00 * c0;
@@ -517,11 +521,11 @@ __device__ __forceinline__ bool chol_tile4(double (&Lr)[4][4], int nb, double* _
                 }
             }
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
+            for (int a = 0; a < E; a++) {
                 if (a < ja) continue;
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int c = tx + 16 * b;
+                for (int b = 0; b < E; b++) {
+                    const int c = tx + TG * b;
                     if (b > ja) {
                         if (b <= a) Lr[a][b] -= fma(u[3][a], v[3][b], fma(u[2][a], v[2][b], fma(u[1][a], v[1][b], u[0][a] * v[0][b])));
                     } else if (b < ja) {
@@ -536,7 +540,7 @@ __device__ __forceinline__ bool chol_tile4(double (&Lr)[4][4], int nb, double* _
             }
             if (kr >= 0 && kr < 4) {                        // the pivot rows of X are final: X[j0 + k][:] = Xn[k][:]
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
+                for (int b = 0; b < E; b++) {
                     if (b > ja) continue;
                     const double val = kr == 0 ? xn[0][b] : (kr == 1 ? xn[1][b] : (kr == 2 ? xn[2][b] : xn[3][b]));
                     Xr[ja][b] = val;
@@ -546,15 +550,18 @@ __device__ __forceinline__ bool chol_tile4(double (&Lr)[4][4], int nb, double* _
     }
     if (failed) return false;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < E; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int r = ty + 16 * a, c = tx + 16 * b;
+        for (int b = 0; b < E; b++) {
+            const int r = ty + TG * a, c = tx + TG * b;
             if (r < nb && c < nb) Li[r * NB + c] = (c <= r) ? Xr[a][b] : 0.0;
         }
     return true;
 }
 
+// (Measured, round 2: the 32 x 32-thread form <32, 2> of the same code takes 26.1 us per 60-column block against 19.4 us for
+// <16, 4>: the step is bound by the dependent chain -- four pivots of rsqrt + two Newton steps at ~15 clocks per dependent
+// v_fma_f64 (tools/probes/f64_rates.hip) plus one barrier -- not by f64 issue, and sixteen waves make the barrier dearer.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
                                                    double* __restrict__ Linv, double* __restrict__ scal)
 {
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const int r = ty + 16 * a, c = tx + 16 * b;
             Lr[a][b] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
         }
-    if (!chol_tile4(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+    if (!chol_tile4<16, 4>(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
 }
 
 // One launch per block column K (instead of panel + update + the next diagonal factorisation): the workgroup of trailing
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
     LBA_STICK(5)
     if (factor_here) {
-        if (!chol_tile4(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+        if (!chol_tile4<16, 4>(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
     }
     LBA_STICK(6)
 #ifdef LBA_STEP_TIMING
@@ -954,6 +961,11 @@ __global__ void k_normalize_poses(double* poses, int n)
 
 }  // namespace lba
 
+namespace lba {
+// stages of the per-stage profile (lba_shard_profile_read); kStageIdle = host gaps between the groups of launches
+enum { kStageLinearize = 0, kStageSchur = 1, kStageFactor = 2, kStageSolve = 3, kStageUpdate = 4, kStageReduce = 5, kStageIdle = 6, kStageCount = 7 };
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -984,6 +996,21 @@ struct lba_shard {
     bool err_valid = false;
     bool err_current = false;           // d.err / d.rho0 belong to the accepted state poses[cur]
     double chi_current = 0, chi_trial = 0, mdp_cached = 0, mdl_cached = 0;
+
+    // optional per-stage timing with HIP events on the shard's stream (lba_shard_profile_*): mark(stage) closes the previous
+    // interval and opens one that is charged to `stage`
+    static constexpr int kProfMarks = 1024;
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_stage;
+    int prof_n = 0;
+    hipEvent_t ev_fence = nullptr;      // stream hand-over to / from the collective's stream (lba_shard_fence_*)
+    void mark(int stage)
+    {
+        if (!profile || prof_n >= kProfMarks) return;
+        (void)hipEventRecord(prof_ev[prof_n], stream);
+        prof_stage[prof_n++] = stage;
+    }
 
     // optional bump arena owned by an lba_solver (avoids ~40 hipMalloc/hipFree per LocalBundleAdjustment call)
     uint8_t* arena = nullptr;
@@ -1248,6 +1275,8 @@ void lba_shard_destroy(lba_shard* s)
     if (s->stream) { (void)hipStreamSynchronize(s->stream); if (s->owns_stream) (void)hipStreamDestroy(s->stream); }
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->h_scal && s->owns_hscal) (void)hipHostFree(s->h_scal);
+    for (hipEvent_t e : s->prof_ev) (void)hipEventDestroy(e);
+    if (s->ev_fence) (void)hipEventDestroy(s->ev_fence);
     delete s;
 }
 
@@ -1261,6 +1290,69 @@ int lba_shard_set_local(lba_shard* s, int local)
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
     s->lambda_in_reduce = local != 0;
     s->sync_after_reduce = local == 0;
+    return ORBX_OK;
+}
+
+// Per-stage device time (HIP events on the shard's stream).  enable: start a fresh profile; read: milliseconds per stage summed
+// over everything recorded since, stage_ms[7] = {linearise, Schur complement, factorisation, substitution, update + errors,
+// reductions, host gaps}.  The events serialise nothing, but the profile is meant for measurement runs, not for production.
+int lba_shard_profile_enable(lba_shard* s, int on)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    if (on && s->prof_ev.empty()) {
+        s->prof_ev.resize(lba_shard::kProfMarks);
+        s->prof_stage.assign(lba_shard::kProfMarks, 0);
+        for (auto& e : s->prof_ev) LBA_HIP(hipEventCreate(&e));
+    }
+    s->profile = on != 0;
+    s->prof_n = 0;
+    return ORBX_OK;
+}
+
+int lba_shard_profile_read(lba_shard* s, float* stage_ms, int n_stages)
+{
+    if (!s || !stage_ms) return fail(ORBX_ERR_ARG, "NULL argument");
+    LBA_HIP(hipSetDevice(s->device));
+    LBA_HIP(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < n_stages; i++) stage_ms[i] = 0.f;
+    for (int i = 0; i + 1 < s->prof_n; i++) {
+        float ms = 0.f;
+        LBA_HIP(hipEventElapsedTime(&ms, s->prof_ev[i], s->prof_ev[i + 1]));
+        if (s->prof_stage[i] < n_stages) stage_ms[s->prof_stage[i]] += ms;
+    }
+    s->prof_n = 0;
+    return ORBX_OK;
+}
+
+// Stream hand-over for the sharded global BA (no host synchronisation): fence_out makes `other` (the collective's stream) wait
+// for everything enqueued on the shard's stream so far; fence_in makes the shard's stream wait for `other`.  With
+// lba_shard_set_async_reduce(1) lba_shard_reduce() returns without synchronising and the caller brackets its all-reduce with
+// the two fences.
+int lba_shard_fence_out(lba_shard* s, void* other)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    if (!s->ev_fence) LBA_HIP(hipEventCreateWithFlags(&s->ev_fence, hipEventDisableTiming));
+    LBA_HIP(hipEventRecord(s->ev_fence, s->stream));
+    LBA_HIP(hipStreamWaitEvent((hipStream_t)other, s->ev_fence, 0));
+    return ORBX_OK;
+}
+
+int lba_shard_fence_in(lba_shard* s, void* other)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    LBA_HIP(hipSetDevice(s->device));
+    if (!s->ev_fence) LBA_HIP(hipEventCreateWithFlags(&s->ev_fence, hipEventDisableTiming));
+    LBA_HIP(hipEventRecord(s->ev_fence, (hipStream_t)other));
+    LBA_HIP(hipStreamWaitEvent(s->stream, s->ev_fence, 0));
+    return ORBX_OK;
+}
+
+int lba_shard_set_async_reduce(lba_shard* s, int on)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    s->sync_after_reduce = on == 0 && !s->lambda_in_reduce;
     return ORBX_OK;
 }
 
@@ -1312,14 +1404,18 @@ int lba_shard_linearize(lba_shard* s, double* chi2_local, double* max_diag_poses
     // the quadratic forms are rebuilt, with no host synchronisation.  The diagonal maxima are only refreshed on the
     // synchronising path (they are needed for lambda initialisation at the first iteration only).
     const bool reuse = s->err_current;
+    s->mark(lba::kStageLinearize);
     if (!reuse && d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, P, X);
     // one launch for both sides; with a lambda hint (lba_shard_hint_lambda) the landmark workgroups also do their part of the Schur complement
     const double hint = s->hint_lambda;
     s->hint_lambda = -1.0;
     if (d.nP + d.nL > 0) hipLaunchKernelGGL(lba::k_lin_all, dim3(d.nP + (d.nL + 31) / 32), dim3(256), 0, s->stream, d, P, X, hint);
     s->schur_lambda = hint;
+    s->mark(lba::kStageIdle);
     if (!reuse) {
+        s->mark(lba::kStageReduce);
         hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 0, s->d_hmap, ++s->seq);
+        s->mark(lba::kStageIdle);
         LBA_HIP(hipGetLastError());
         int r = read_scalars(s);
         if (r) return r;
@@ -1343,6 +1439,7 @@ int lba_shard_reduce(lba_shard* s, double lambda)
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
     LBA_HIP(hipSetDevice(s->device));
     const lba::Dev& d = s->d;
+    s->mark(lba::kStageSchur);
     if (d.nL > 0 && !(s->schur_lambda >= 0.0 && s->schur_lambda == lambda))
         hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, lambda);
     s->schur_lambda = -1.0;                 // W / Dinv / Z now belong to this lambda only until the next trial changes it
@@ -1350,6 +1447,7 @@ int lba_shard_reduce(lba_shard* s, double lambda)
         hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks + d.nP), dim3(256), 0, s->stream, d, s->S(),
                            s->lambda_in_reduce ? lambda : 0.0, s->bs(), s->bpf(), s->diag());
     s->lambda_added = s->lambda_in_reduce;
+    s->mark(lba::kStageIdle);
     LBA_HIP(hipGetLastError());
     if (s->sync_after_reduce) LBA_HIP(hipStreamSynchronize(s->stream));      // the caller hands the buffer to RCCL on another stream
     return ORBX_OK;
@@ -1368,6 +1466,7 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
     double* Pn = s->poses[1 - s->cur];
     double* Xn = s->pts[1 - s->cur];
     LBA_HIP(hipMemsetAsync(d.scal + 5, 0, sizeof(double), s->stream));
+    s->mark(lba::kStageFactor);
     if (n > 0) {
         if (!s->lambda_added) hipLaunchKernelGGL(lba::k_add_lambda, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->S(), n, lambda);
         const bool fused = s->nblk <= lba::kFusedMaxBlocks;
@@ -1390,14 +1489,18 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
                 hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, n + 1, k0, nb, (const double*)d.scal);
             }
         }
+        s->mark(lba::kStageSolve);
         hipLaunchKernelGGL(fused ? lba::k_chol_solve<true> : lba::k_chol_solve<false>, dim3(1), dim3(1024),
                            ((size_t)n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double), s->stream,
                            (const double*)(fused ? s->Lp : s->S()), n, (const double*)s->Linv,
                            (const double*)(fused ? s->Lp + (size_t)n * n : s->bs()), (const double*)s->bs(), d.x, (const double*)d.scal, fused ? 1 : 0);
     }
+    s->mark(lba::kStageUpdate);
     hipLaunchKernelGGL(lba::k_backsub_update, dim3((d.nL + d.nPoses + 63) / 64), dim3(64), 0, s->stream, d, lambda, s->bpf(), P, X, Pn, Xn);
     if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, (const double*)Pn, (const double*)Xn);
+    s->mark(lba::kStageReduce);
     hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 1, s->d_hmap, ++s->seq);
+    s->mark(lba::kStageIdle);
     LBA_HIP(hipGetLastError());
     int r = read_scalars(s);
     if (r) return r;

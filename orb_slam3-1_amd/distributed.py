@@ -42,7 +42,7 @@ class _NoDist:
     """world_size 1: the collectives are identities."""
     world = 1
 
-    def sum_(self, t):
+    def sum_(self, t, shard=None):
         return t
 
     def sum_scalars(self, vals):
@@ -63,18 +63,27 @@ class TorchDist:
         self.world = dist.get_world_size()
         self._events = []           # (start, end) event pairs around the reduce-buffer all-reduces (device tensors only)
 
-    def sum_(self, t):
+    def sum_(self, t, shard=None):
+        """All-reduce of the reduce buffer.  RCCL enqueues it on torch's current stream while the shard's kernels run on the
+        shard's own stream: with a shard that offers stream fences (capi.LbaShard) the two streams are ordered by events and the
+        host never waits here -- the factorisation is enqueued behind the collective while it is still running; otherwise the
+        host synchronises the collective's stream."""
         cuda = getattr(t, "is_cuda", False)
+        fences = cuda and shard is not None and hasattr(shard, "fence_out")
         if cuda:
+            st = self.torch.cuda.current_stream(t.device)
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
-            e0.record(self.torch.cuda.current_stream(t.device))
+            if fences:
+                shard.fence_out(st.cuda_stream)          # the collective waits for the shard's partial sums
+            e0.record(st)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        # RCCL enqueues the all-reduce on torch's current stream and returns; the shard kernels that consume the buffer
-        # run on the shard's own stream, so the host waits here (the LM loop needs the scalars of this trial anyway)
         if cuda:
-            e1.record(self.torch.cuda.current_stream(t.device))
+            e1.record(st)
             self._events.append((e0, e1))
-            self.torch.cuda.current_stream(t.device).synchronize()
+            if fences:
+                shard.fence_in(st.cuda_stream)           # the shard's next kernels wait for the summed buffer
+            else:
+                st.synchronize()
         return t
 
     @property
@@ -127,7 +136,7 @@ def sharded_bundle_adjustment(shard, reduce_tensor, comm=None, max_iters=10, lam
                 # plus the summed pose diagonal (section 4 of the buffer) after a lambda-free reduce
                 if reduce_tensor is not None:       # world size 1: linearize() already returned the true maxima
                     shard.reduce(0.0)
-                    comm.sum_(reduce_tensor)
+                    comm.sum_(reduce_tensor, getattr(shard, "s", None))
                 mdp = shard.max_pose_diag()
                 mdl = comm.max_scalars([mdl_l])[0]
                 lam = 1e-5 * max(mdp, mdl)
@@ -136,7 +145,7 @@ def sharded_bundle_adjustment(shard, reduce_tensor, comm=None, max_iters=10, lam
         while True:
             shard.reduce(lam)
             if reduce_tensor is not None:
-                comm.sum_(reduce_tensor)
+                comm.sum_(reduce_tensor, getattr(shard, "s", None))
             solved, chi_new_l, sp, sl_l = shard.finish(lam)
             chi_new, sl, ok_all = comm.sum_scalars([chi_new_l, sl_l, float(solved)])
             temp_chi = chi_new if ok_all >= comm.world - 0.5 else float("inf")
@@ -208,6 +217,8 @@ class HipShard:
         self.n_red = lba_shard.reduce_len()
         self.tensor = torch.zeros(self.n_red, dtype=torch.float64, device=device)
         lba_shard.set_reduce_buffer(self.tensor.data_ptr())
+        if hasattr(lba_shard, "set_async_reduce"):
+            lba_shard.set_async_reduce(True)        # TorchDist.sum_ orders the two streams with events: no host wait per trial
         # n*n + 3n = n_red  ->  n
         self.n = int(round((-3 + math.sqrt(9 + 4 * self.n_red)) / 2))
 
