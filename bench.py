@@ -50,7 +50,7 @@ def compact_line(out):
         line["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms",
                                                "pipeline_frac", "stage_ms") if k in r}
         if "stage_ms" in line["roofline"]:
-            line["roofline"]["stage_ms"] = {k: round(v, 4) for k, v in line["roofline"]["stage_ms"].items()}
+            line["roofline"]["stage_ms"] = {k: round(v, 3) for k, v in line["roofline"]["stage_ms"].items()}
     for k in ("cpu_baseline", "speedup_vs_cpu_1core"):
         if k in out:
             line[k] = out[k]
@@ -61,7 +61,14 @@ def compact_line(out):
     if "gba" in out:
         line["gba"] = out["gba"]
     line["detail"] = "gpurun_out/bench_detail.json"
-    return line
+
+    def shorten(o):         # six significant digits are plenty for a headline line
+        if isinstance(o, float):
+            return float("%.6g" % o)
+        if isinstance(o, dict):
+            return {k: shorten(v) for k, v in o.items()}
+        return o
+    return shorten(line)
 
 
 def log(*a):
@@ -210,8 +217,8 @@ def main():
         "metric": "tracking frames/s (ORB extract+match)", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "ORBextractor::operator() 640x480 mono, 8 levels, 1000 features (BASELINE configs[1]) + "
-                               "ORBmatcher::SearchByBoW 1000x1000 descriptors per frame (configs[2])",
+        "config": {"workload": "ORBextractor::operator() 640x480 mono, 8 levels, 1000 features (configs[1]) + "
+                               "ORBmatcher::SearchByBoW 1000x1000 per frame (configs[2])",
                    "batch_per_gpu": B, "frames_per_step": world * B, "keypoints_per_frame": n_kp,
                    "bow_matches_per_pair": float(np.mean([b[0] for b in bow])), "sharding": "frames, no collective"},
         "pipeline_gbs": ALGO_BYTES_PER_FRAME * value / 1e9,
@@ -242,7 +249,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(dom)
-                traffic_from = "profiles/pmc_traffic.json (%s)" % tj.get("_source", "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+                traffic_from = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)"
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -2,12 +2,11 @@
 does not share the oracle's grid code (reference src/ORBmatcher.cc:43-138 and :1676-1887, Frame::GetFeaturesInArea
 src/Frame.cc:744-810).  The reference ships no fixtures for this path: PARITY UNPINNED, this pins the restatement to a
 second, independently written one."""
-import importlib
-
 import numpy as np
 import pytest
 
-sm = importlib.import_module("orb_slam3-1_amd.synth_match")
+# (the synthetic-case module comes in through the `sm` fixture: importing the package at collection time would load the HIP
+# library before torch and leave torch without a GPU in the same process -- see conftest.pkg)
 
 
 def _visit_order(g):
@@ -122,7 +121,7 @@ def numpy_search_mp(g, dF, scale, mp, th, nnratio, assign, occupied, b_far, th_f
 
 @pytest.mark.parametrize("frac,lw,th,ori", [(None, 0, 15.0, True), (0.0, 0, 15.0, True), (0.5, 0, 15.0, True), (1.0, 0, 7.0, True),
                                             (0.5, 1, 15.0, True), (0.5, 2, 15.0, False), (1.0, 1, 7.0, True), (1.0, 2, 15.0, True)])
-def test_last_frame_search_vs_numpy(oracle, frac, lw, th, ori):
+def test_last_frame_search_vs_numpy(oracle, sm, frac, lw, th, ori):
     g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(3, n=500, n_last=400, stereo_frac=frac, level_window=lw)
     a0, o0 = assign.copy(), occ.copy()
     n0 = oracle.search_by_projection_last(g, dF, angF, scale, last, th, ori, a0, o0)
@@ -133,7 +132,7 @@ def test_last_frame_search_vs_numpy(oracle, frac, lw, th, ori):
 
 
 @pytest.mark.parametrize("frac,th,far", [(None, 3.0, False), (0.0, 3.0, False), (0.5, 1.0, False), (0.5, 3.0, True), (1.0, 3.0, False)])
-def test_map_point_search_vs_numpy(oracle, frac, th, far):
+def test_map_point_search_vs_numpy(oracle, sm, frac, th, far):
     g, dF, angF, scale, mp, assign, occ = sm.make_projection_case(5, n=500, n_mp=400, stereo_frac=frac)
     a0, o0 = assign.copy(), occ.copy()
     n0 = oracle.search_by_projection(g, dF, scale, mp, th, 0.8, a0, o0, b_far=far, th_far=20.0)
@@ -143,7 +142,7 @@ def test_map_point_search_vs_numpy(oracle, frac, th, far):
     np.testing.assert_array_equal(a0, a1); np.testing.assert_array_equal(o0, o1)
 
 
-def test_stereo_gate_properties(oracle):
+def test_stereo_gate_properties(oracle, sm):
     """What the gates mean: u_right all < 0 is the monocular search; a full stereo frame loses exactly the candidates
     whose right columns disagree; the level windows bound the octave of every match."""
     base = sm.make_last_frame_case(7, n=600, n_last=500)

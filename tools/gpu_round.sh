@@ -19,12 +19,16 @@ timeout -k 10 200 python bench.py --streams 4 --no-cpu --no-lba > $OUT/bench_str
 # per-kernel times of the two BA solvers alone (profiles/<tag>_lba_kernel_stats.csv, <tag>_inertial_ba_kernel_stats.csv)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lbaprof -- python tools/lba_prof.py 5 > $OUT/lbaprof.log 2>&1 || echo "lba profile failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/libaprof -- python tools/liba_prof.py 5 > $OUT/libaprof.log 2>&1 || echo "inertial ba profile failed"
+cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
+bash tools/pmc_lba.sh $TAG/lba_pmc > $OUT/lba_pmc.log 2>&1 || echo "lba mfma counter pass failed"
 python - <<PY
 import json
 d = json.load(open("$OUT/bench.json"))
-print("frames/s %.0f  x%.0f vs cpu  roofline %s frac %.4f" % (d["value"], d.get("speedup_vs_cpu_1core", 0), d["roofline"]["kernel"], d["roofline"]["frac"]))
+print("frames/s %.0f  x%.0f vs cpu  roofline %s frac %.4f pipeline frac %.4f" % (d["value"], d.get("speedup_vs_cpu_1core", 0), d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"].get("pipeline_frac", 0)))
 print({k: round(v, 3) for k, v in d["roofline"]["stage_ms"].items()})
-print("lba iters/s %.0f  x%.1f vs cpu  call_ms %.2f" % (d["lba"]["value"], d["lba"].get("speedup_vs_cpu_1core", 0), d["lba"]["lba_solve_call_ms_incl_upload"]))
+l = d["lba"]
+print("lba iters/s %.0f  x%.1f vs cpu  ms/iteration %.3f ms/trial %.3f  roofline %s" % (l["value"], l.get("speedup_vs_cpu_1core", 0), l["ms_per_iteration"], l["ms_per_trial"], l["roofline"]))
 t = json.load(open("$OUT/pmc_traffic.json"))
 print("traffic MB/launch", {k: round(v / 1e6, 1) for k, v in t.items() if not k.startswith("_")})
+print("line length", len(open("$OUT/bench.json").read()))
 PY
