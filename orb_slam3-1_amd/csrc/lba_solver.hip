@@ -437,33 +437,39 @@ __device__ __forceinline__ double rsqrt_newton(double d)
     inv = inv * fma(-0.5 * d * inv, inv, 1.5);
     return inv * fma(-0.5 * d * inv, inv, 1.5);
 }
-// TG x TG threads, E x E elements each (TG * E = 64): 16 x 16 threads with 4 x 4 tiles (the form in use), or 32 x 32 threads with
-// 2 x 2 tiles.
-template <int TG, int E>
-__device__ __forceinline__ bool chol_tile4(double (&Lr)[E][E], int nb, double* __restrict__ Li, CholVec4& sv)
+// The rank-4 updates of the step run on the f64 matrix pipe.  A 256-thread workgroup is one wave per SIMD,
+// where a v_fma_f64 issues every ~8.5 clocks and v_mfma_f64_16x16x4 (2048 FLOP) every 64 (tools/probes/f64_rates.hip): the
+// 128 FMAs per thread of the register-tile update become at most 5 MFMAs, and a lane only prepares the operands the MFMA takes
+// from it (one value of U, one of V or Xn per column block: 4 FMAs each on M's row k = lane >> 4) instead of the 48 values
+// its 4 x 4 tile would need.  Thread (ty, tx) = lane (ty & 3) * 16 + tx of wave ty >> 2 owns rows ty + 16 a: exactly the rows
+// of accumulator component a when the wave feeds the MFMA rows m -> 4 w + (m & 3) + 16 (m >> 2) (as k_chol_step does), so
+// Lacc[b][a] / Xacc[b][a] ARE the thread's elements (ty + 16 a, tx + 16 b).
+__device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, double* __restrict__ Li, CholVec4& sv)
 {
-    static_assert(TG * E == 64, "the padded block is 64 x 64");
-    const int tid = threadIdx.x, ty = tid / TG, tx = tid % TG;
-    double Xr[E][E];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int lk = ty & 3, wv4 = ty & ~3;                   // MFMA k index of this lane; first row of the wave's row group
+    const int r_u = wv4 + (tx & 3) + 16 * (tx >> 2);        // the row whose U value this lane feeds (MFMA row m = tx)
+    mfma_d4 Lacc[4], Xacc[4];
 #pragma unroll
-    for (int a = 0; a < E; a++)
+    for (int b = 0; b < 4; b++)
 #pragma unroll
-        for (int b = 0; b < E; b++) Xr[a][b] = (ty + TG * a == tx + TG * b) ? 1.0 : 0.0;
+        for (int a = 0; a < 4; a++) { Lacc[b][a] = Lr[a][b]; Xacc[b][a] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0; }
     bool failed = false;
 #pragma unroll
-    for (int ja = 0; ja < E; ja++) {
-        for (int jy = 0; jy < TG; jy += 4) {
-            const int j0 = TG * ja + jy;
+    for (int ja = 0; ja < 4; ja++) {
+        for (int jy = 0; jy < 16; jy += 4) {
+            const int j0 = 16 * ja + jy;
             if (j0 >= nb || failed) break;                  // a partial last group pairs with the identity padding
             const int p = (jy >> 2) & 1;
-            const int ko = tx - jy, kr = ty - jy;           // 0..3: this thread owns a pivot column / a pivot row
+            const int ko = tx - jy;                         // 0..3: this thread owns a pivot column
+            const bool own_rows = wv4 == jy;                // wave-uniform: this wave owns the pivot rows j0 + (ty & 3)
             if (ko >= 0 && ko < 4) {
 #pragma unroll
-                for (int a = 0; a < E; a++) sv.col[p][ko][ty + TG * a] = Lr[a][ja];
+                for (int a = 0; a < 4; a++) sv.col[p][ko][ty + 16 * a] = Lacc[ja][a];
             }
-            if (kr >= 0 && kr < 4) {
+            if (own_rows) {
 #pragma unroll
-                for (int b = 0; b < E; b++) sv.row[p][kr][tx + TG * b] = Xr[ja][b];
+                for (int b = 0; b < 4; b++) sv.row[p][lk][tx + 16 * b] = Xacc[b][ja];
             }
             __syncthreads();
             // pivot block (lower triangle): P[k][m] = column m, row j0 + k
@@ -484,84 +490,48 @@ __device__ __forceinline__ bool chol_tile4(double (&Lr)[E][E], int nb, double* _
             const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, P33)));
             if (!(d3 > 0.0) || !isfinite(d3)) { failed = true; break; }
             const double i3 = rsqrt_newton(d3);
-            // M = Lp^-1 (lower triangular)
-            const double M00 = i0, M11 = i1, M22 = i2, M33 = i3;
-            const double M10 = -(l10 * M00) * i1;
-            const double M20 = -fma(l21, M10, l20 * M00) * i2, M21 = -(l21 * M11) * i2;
-            const double M30 = -fma(l32, M20, fma(l31, M10, l30 * M00)) * i3, M31 = -fma(l32, M21, l31 * M11) * i3, M32 = -(l32 * M22) * i3;
-            // ja is a compile-time constant inside the unrolled outer loop, so whole register tiles drop out
-            double u[4][E], v[4][E], xn[4][E];              // [k][a], [k][b], [k][b]
+            // M = Lp^-1 (lower triangular); this lane needs row lk of it
+            const double M10 = -(l10 * i0) * i1;
+            const double M20 = -fma(l21, M10, l20 * i0) * i2, M21 = -(l21 * i1) * i2;
+            const double M30 = -fma(l32, M20, fma(l31, M10, l30 * i0)) * i3, M31 = -fma(l32, M21, l31 * i1) * i3, M32 = -(l32 * i2) * i3;
+            const double m0 = lk == 0 ? i0 : lk == 1 ? M10 : lk == 2 ? M20 : M30;
+            const double m1 = lk == 0 ? 0.0 : lk == 1 ? i1 : lk == 2 ? M21 : M31;
+            const double m2 = lk < 2 ? 0.0 : lk == 2 ? i2 : M32;
+            const double m3 = lk < 3 ? 0.0 : i3;
+            // A operand: -U[r_u][lk], zero for the rows of the pivot block and above (they take no update)
+            double au = fma(m3, sv.col[p][3][r_u], fma(m2, sv.col[p][2][r_u], fma(m1, sv.col[p][1][r_u], m0 * sv.col[p][0][r_u])));
+            au = (r_u > j0 + 3) ? -au : 0.0;
 #pragma unroll
-            for (int a = 0; a < E; a++) {
-                if (a < ja) continue;
-                const int r = ty + TG * a;
-                const double c0 = sv.col[p][0][r], c1 = sv.col[p][1][r], c2 = sv.col[p][2][r], c3 = sv.col[p][3][r];
-                const bool below = r > j0 + 3;              // rows of the pivot block and above take no update
-                u[0][a] = below ? M00 * c0 : 0.0;
-                u[1][a] = below ? fma(M11, c1, M10 * c0) : 0.0;
-                u[2][a] = below ? fma(M22, c2, fma(M21, c1, M20 * c0)) : 0.0;
-                u[3][a] = below ? fma(M33, c3, fma(M32, c2, fma(M31, c1, M30 * c0))) : 0.0;
-            }
-#pragma unroll
-            for (int b = 0; b < E; b++) {
-                const int c = tx + TG * b;
-                if (b >= ja) {
-                    const double c0 = sv.col[p][0][c], c1 = sv.col[p][1][c], c2 = sv.col[p][2][c], c3 = sv.col[p][3][c];
-                    v[0][b] = M00 * c0;
-                    v[1][b] = fma(M11, c1, M10 * c0);
-                    v[2][b] = fma(M22, c2, fma(M21, c1, M20 * c0));
-                    v[3][b] = fma(M33, c3, fma(M32, c2, fma(M31, c1, M30 * c0)));
+            for (int b = 0; b < 4; b++) {
+                const int c = tx + 16 * b;
+                if (b >= ja) {      // columns right of the pivot group belong to L:  L -= U V^T
+                    double vb = fma(m3, sv.col[p][3][c], fma(m2, sv.col[p][2][c], fma(m1, sv.col[p][1][c], m0 * sv.col[p][0][c])));
+                    if (b == ja && c <= j0 + 3) vb = 0.0;
+                    Lacc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, vb, Lacc[b], 0, 0, 0);
                 }
-                if (b <= ja) {
-                    const double x0 = sv.row[p][0][c], x1 = sv.row[p][1][c], x2 = sv.row[p][2][c], x3 = sv.row[p][3][c];
-                    xn[0][b] = M00 * x0;
-                    xn[1][b] = fma(M11, x1, M10 * x0);
-                    xn[2][b] = fma(M22, x2, fma(M21, x1, M20 * x0));
-                    xn[3][b] = fma(M33, x3, fma(M32, x2, fma(M31, x1, M30 * x0)));
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < E; a++) {
-                if (a < ja) continue;
-#pragma unroll
-                for (int b = 0; b < E; b++) {
-                    const int c = tx + TG * b;
-                    if (b > ja) {
-                        if (b <= a) Lr[a][b] -= fma(u[3][a], v[3][b], fma(u[2][a], v[2][b], fma(u[1][a], v[1][b], u[0][a] * v[0][b])));
-                    } else if (b < ja) {
-                        Xr[a][b] -= fma(u[3][a], xn[3][b], fma(u[2][a], xn[2][b], fma(u[1][a], xn[1][b], u[0][a] * xn[0][b])));
-                    } else {
-                        // the 16-column block of the pivot: columns right of the pivot group belong to L, the others to X
-                        const double dl = fma(u[3][a], v[3][b], fma(u[2][a], v[2][b], fma(u[1][a], v[1][b], u[0][a] * v[0][b])));
-                        const double dx = fma(u[3][a], xn[3][b], fma(u[2][a], xn[2][b], fma(u[1][a], xn[1][b], u[0][a] * xn[0][b])));
-                        if (c > j0 + 3) Lr[a][b] -= dl; else Xr[a][b] -= dx;
-                    }
-                }
-            }
-            if (kr >= 0 && kr < 4) {                        // the pivot rows of X are final: X[j0 + k][:] = Xn[k][:]
-#pragma unroll
-                for (int b = 0; b < E; b++) {
-                    if (b > ja) continue;
-                    const double val = kr == 0 ? xn[0][b] : (kr == 1 ? xn[1][b] : (kr == 2 ? xn[2][b] : xn[3][b]));
-                    Xr[ja][b] = val;
+                if (b <= ja) {      // the others to X:  X -= U Xn, and the pivot rows of X become Xn
+                    double xb = fma(m3, sv.row[p][3][c], fma(m2, sv.row[p][2][c], fma(m1, sv.row[p][1][c], m0 * sv.row[p][0][c])));
+                    const double xop = (b == ja && c > j0 + 3) ? 0.0 : xb;
+                    Xacc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, xop, Xacc[b], 0, 0, 0);
+                    if (own_rows) Xacc[b][ja] = xb;         // X[j0 + lk][c] = Xn[lk][c]
                 }
             }
         }
     }
     if (failed) return false;
 #pragma unroll
-    for (int a = 0; a < E; a++)
+    for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < E; b++) {
-            const int r = ty + TG * a, c = tx + TG * b;
-            if (r < nb && c < nb) Li[r * NB + c] = (c <= r) ? Xr[a][b] : 0.0;
+        for (int b = 0; b < 4; b++) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            if (r < nb && c < nb) Li[r * NB + c] = (c <= r) ? Xacc[b][a] : 0.0;
         }
     return true;
 }
 
-// (Measured, round 2: the 32 x 32-thread form <32, 2> of the same code takes 26.1 us per 60-column block against 19.4 us for
-// <16, 4>: the step is bound by the dependent chain -- four pivots of rsqrt + two Newton steps at ~15 clocks per dependent
-// v_fma_f64 (tools/probes/f64_rates.hip) plus one barrier -- not by f64 issue, and sixteen waves make the barrier dearer.)
+// (Measured, round 2, per 60-column block: register-tile VALU updates with 16 x 16 threads 19.4 us; the same with 32 x 32 threads
+// and 2 x 2 tiles 26.1 us; this MFMA form 18.7 us.  The step is bound by its dependent chain -- barrier, pivot loads, four pivots
+// of rsqrt + two Newton steps at ~15 clocks per dependent v_fma_f64 (tools/probes/f64_rates.hip) -- not by f64 issue.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
                                                    double* __restrict__ Linv, double* __restrict__ scal)
 {
@@ -575,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const int r = ty + 16 * a, c = tx + 16 * b;
             Lr[a][b] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
         }
-    if (!chol_tile4<16, 4>(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+    if (!chol_tile_mfma(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
 }
 
 // One launch per block column K (instead of panel + update + the next diagonal factorisation): the workgroup of trailing
@@ -725,7 +695,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
     LBA_STICK(5)
     if (factor_here) {
-        if (!chol_tile4<16, 4>(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+        if (!chol_tile_mfma(Lr, ncj, Linv + (size_t)bi * NB * NB, sv) && tid == 0) scal[5] = 1.0;
     }
     LBA_STICK(6)
 #ifdef LBA_STEP_TIMING
