@@ -109,6 +109,8 @@ struct orbx_extractor {
     int fast_corner_cap = 0;             // 0 = kCornerCap; tests shrink it to drive the overflow path (orbx_debug_set_fast_corner_cap)
     size_t fast_lds = 0, oct_lds = 0;
     int oct_pool = 0, oct_lds_keys = 0, oct_small_keys = 0;
+    bool oct_nodes_hbm = false;          // the octree's node pool does not fit LDS: it lives in d_oct_nodes
+    size_t oct_node_stride = 0;
     size_t oct_small_lds = 0;
     bool oct_keys_forced = false;
 
@@ -125,6 +127,7 @@ struct orbx_extractor {
     int batch_cap = 0, last_batch = 0;
     DevBuf<uint8_t> d_pyr, d_blur;
     DevBuf<uint32_t> d_cand, d_scratch, d_sel;
+    DevBuf<uint8_t> d_oct_nodes;
     DevBuf<int> d_cell_count, d_sel_count, d_kp_dst;
     DevBuf<OrbxKeyPoint> d_lvl_kps;
     // staging for the host-pointer API
@@ -355,25 +358,32 @@ int orbx_extractor::setup_geometry(int w, int h)
     }
     // octree kernel LDS
     oct_pool = max_nfeat + 16;
-    if (oct_pool > 16000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree", max_nfeat);
-    if ((size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 14 + 2 * kOctLogFactor) + (size_t)((oct_pool + 15) & ~15) > 150 * 1024)
-        return fail(ORBX_ERR_ARG, "%d features on one pyramid level do not fit the octree's LDS node pool (limit about 2600 per level)", max_nfeat);
+    if (oct_pool > 32000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree (16-bit node ids)", max_nfeat);
     const char* env = getenv("ORBX_OCT_LDS_KEYS");
     oct_lds_keys = env ? atoi(env) : 0;      // measured on MI355X: L2-resident HBM scratch + more resident waves beats LDS keys
     oct_keys_forced = env != nullptr;        // ... for large batches; small batches are latency-bound and take LDS keys (enqueue())
-    const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 14 + 2 * kOctLogFactor) + (size_t)((oct_pool + 15) & ~15);
-    if (node_bytes + 8 * (size_t)oct_lds_keys > 150 * 1024) oct_lds_keys = (int)((150 * 1024 - node_bytes) / 8);
+    const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 16 + 2 * kOctLogFactor) + (size_t)((oct_pool + 15) & ~15);
+    // the node pool of a level lives in LDS (about 2500 nodes); a level with more features takes the instantiation whose pool
+    // lives in an HBM scratch (ensure_batch allocates it)
+    oct_nodes_hbm = node_bytes > 150 * 1024;
+    oct_node_stride = (node_bytes + 255) & ~(size_t)255;
+    if (oct_nodes_hbm) oct_lds_keys = 0;
+    if (!oct_nodes_hbm && node_bytes + 8 * (size_t)oct_lds_keys > 150 * 1024) oct_lds_keys = (int)((150 * 1024 - node_bytes) / 8);
     if (oct_lds_keys < 0) oct_lds_keys = 0;
     oct_lds = node_bytes + 8 * (size_t)oct_lds_keys + 16;
     // second configuration for small batches: both key buffers of a level (up to 4096 candidates) live in LDS
     int max_cand_cap = 0;
     for (const LevelDesc& lv : levels) max_cand_cap = std::max(max_cand_cap, lv.cand_cap);
     oct_small_keys = max_cand_cap;
-    if (node_bytes + 8 * (size_t)oct_small_keys > 150 * 1024) oct_small_keys = 0;      // does not fit: small batches use the scratch path too
+    if (oct_nodes_hbm || node_bytes + 8 * (size_t)oct_small_keys > 150 * 1024) oct_small_keys = 0;      // does not fit: small batches use the scratch path too
     oct_small_lds = node_bytes + 8 * (size_t)oct_small_keys + 16;
     if (oct_lds_keys > 0 && oct_lds_keys < max_cand_cap) oct_lds_keys = 0;              // the LDS instantiation needs room for a whole level
-    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)node_bytes + 64));
-    ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(oct_lds, oct_small_lds)));
+    if (!oct_nodes_hbm) {
+        ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)node_bytes + 64));
+        ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(oct_lds, oct_small_lds)));
+    } else {
+        oct_lds = 64; oct_small_lds = 64;
+    }
     ORBX_HIP(hipFuncSetAttribute((const void*)k_fast_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
     int r;
     if ((r = d_levels.upload(levels)) || (r = d_cells.upload(cells)) || (r = d_tiles.upload(tiles)) || (r = d_strips.upload(strips))) return r;
@@ -394,6 +404,7 @@ int orbx_extractor::ensure_batch(int batch)
         (r = d_sel_count.ensure(B * nlevels)) || (r = d_kp_dst.ensure(B * sel_frame_entries)) ||
         (r = d_lvl_kps.ensure(B * sel_frame_entries)) || (r = d_n.ensure(B)) || (r = d_mono.ensure(B)) || (r = d_status.ensure(B)))
         return r;
+    if (oct_nodes_hbm && (r = d_oct_nodes.ensure(B * nlevels * oct_node_stride))) return r;
     // the pyramid row padding is read by dword loads at row ends; keep it defined
     ORBX_HIP(hipMemset(d_pyr.p, 0, B * pyr_frame_bytes + 64));
     ORBX_HIP(hipMemset(d_blur.p, 0, B * pyr_frame_bytes + 64));
@@ -478,10 +489,10 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     const bool small_batch = !oct_keys_forced && oct_small_keys > 0 && (long long)B * nlevels <= 512;
     const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
     const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
-    auto oct_kernel = o_keys > 0 ? k_octree<true> : k_octree<false>;
+    auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>);
     hipLaunchKernelGGL(oct_kernel, dim3(nlevels, B), dim3(64), o_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
                        d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
-                       d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status);
+                       d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status, d_oct_nodes.p, oct_node_stride);
     ORBX_LAUNCHED("k_octree / k_blur");
     mark();
     hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,
@@ -579,7 +590,7 @@ void orbx_destroy(orbx_extractor* e)
     for (auto& b : e->d_qsel) b.release();
     for (auto& b : e->d_qalpha) b.release();
     for (auto& b : e->d_ibeta) b.release();
-    e->d_pyr.release(); e->d_blur.release(); e->d_cand.release(); e->d_scratch.release(); e->d_sel.release();
+    e->d_pyr.release(); e->d_blur.release(); e->d_cand.release(); e->d_scratch.release(); e->d_sel.release(); e->d_oct_nodes.release();
     e->d_cell_count.release(); e->d_sel_count.release(); e->d_kp_dst.release(); e->d_lvl_kps.release();
     e->d_kps.release(); e->d_desc.release(); e->d_n.release(); e->d_mono.release(); e->d_status.release();
     e->d_sad.release(); e->d_stereo_io.release();

@@ -131,22 +131,27 @@ __device__ unsigned long long d_oct_prof[8];
 struct OctLds {
     short* ulx; short* uly; short* brx; short* bry;
     int* beg; int* cnt;
-    short* pidx; short* freelist; short* order;
+    int* pidx; short* freelist; short* order;       // pidx indexes the push log (6 x pool entries: beyond 16 bits for large pools)
     short* plog;            // push log: the std::list order is the REVERSE of this array without its tombstones (-1)
     uint8_t* flg;           // bit0: bNoMore, bit1: keys live in buffer 1
 };
 
 // LDS_KEYS: both ping-pong key buffers live in LDS (the host sizes them for the largest level, so the choice is static and
 // every key access is a ds_ instruction); otherwise they live in the L2-resident HBM scratch (global_ instructions).
-template <bool LDS_KEYS>
+// LDS_NODES: the node pool (boxes, key ranges, push log, the two sort arrays) lives in LDS, which holds about 2500 nodes; levels
+// that ask for more features than that (e.g. 12000 features per frame) take the instantiation whose pool lives in an HBM /
+// L2-resident scratch of its own -- the same code, global_ instead of ds_ instructions.
+template <bool LDS_KEYS, bool LDS_NODES = true>
 __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
                                                const uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                const int* __restrict__ cell_count, int n_cells,
                                                uint32_t* __restrict__ scratch, size_t scratch_frame_stride,
                                                int pool, int lds_keys_cap,
                                                uint32_t* __restrict__ sel, int sel_frame_stride,
-                                               int* __restrict__ sel_count, int n_levels, int* __restrict__ status)
+                                               int* __restrict__ sel_count, int n_levels, int* __restrict__ status,
+                                               uint8_t* __restrict__ node_scratch, size_t node_stride)
 {
+    static_assert(LDS_NODES || !LDS_KEYS, "a pool too large for LDS leaves no room for LDS keys");
     extern __shared__ __align__(16) uint8_t smem[];
     const int level = blockIdx.x, frame = blockIdx.y;
     const int lane = threadIdx.x;
@@ -159,14 +164,16 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
     // carve LDS
     OctLds S;
     {
-        uint8_t* p = smem;
+        uint8_t* p;
+        if constexpr (LDS_NODES) p = smem;
+        else p = node_scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * node_stride;
         SortNode* const ex0 = (SortNode*)p; p += sizeof(SortNode) * pool;      // (named, not an indexed pointer array: a pointer
         SortNode* const ex1 = (SortNode*)p; p += sizeof(SortNode) * pool;      //  picked with ?: keeps its LDS address space)
         S.beg = (int*)p; p += 4 * pool;
         S.cnt = (int*)p; p += 4 * pool;
         S.ulx = (short*)p; p += 2 * pool;  S.uly = (short*)p; p += 2 * pool;
         S.brx = (short*)p; p += 2 * pool;  S.bry = (short*)p; p += 2 * pool;
-        S.pidx = (short*)p; p += 2 * pool;
+        S.pidx = (int*)p; p += 4 * pool;
         S.freelist = (short*)p; p += 2 * pool; S.order = (short*)p; p += 2 * pool;
         S.plog = (short*)p; p += 2 * kOctLogFactor * pool;
         S.flg = p; p += (pool + 15) & ~15;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
         bool overflow = false;
         auto push = [&](int i) {
             if (np >= plog_cap) { overflow = true; return; }
-            S.plog[np] = (short)i; S.pidx[i] = (short)np;
+            S.plog[np] = (short)i; S.pidx[i] = np;
             np++; size++;
         };
         auto compact = [&]() {          // drop tombstones, order preserved (wave-parallel, in place)
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                 const int i = i0 + lane;
                 const int id = (i < np) ? (int)S.plog[i] : -1;
                 const unsigned long long m = __ballot(id >= 0);
-                if (id >= 0) { const int pos = w + __popcll(m & ((1ull << lane) - 1ull)); S.plog[pos] = (short)id; S.pidx[id] = (short)pos; }
+                if (id >= 0) { const int pos = w + __popcll(m & ((1ull << lane) - 1ull)); S.plog[pos] = (short)id; S.pidx[id] = pos; }
                 w += __popcll(m);
             }
             np = w;
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                     S.brx[ch] = (short)((lane & 1) ? brx : midx); S.bry[ch] = (short)((lane & 2) ? bry : midy);
                     S.beg[ch] = cb_me; S.cnt[ch] = cn_me;
                     S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn_me == 1 ? 1 : 0));
-                    S.plog[np + r] = (short)ch; S.pidx[ch] = (short)(np + r);      // push(): children n1..n4 in order
+                    S.plog[np + r] = (short)ch; S.pidx[ch] = np + r;               // push(): children n1..n4 in order
                     if (cn_me > 1 && n_ex + rx < pool) { SortNode sn; sn.count = cn_me; sn.ulx = ux; sn.node = ch; (cur_ex ? ex1 : ex0)[n_ex + rx] = sn; }
                 }
             }
