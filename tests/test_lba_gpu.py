@@ -72,6 +72,50 @@ def test_lba_stop_flag(pkg, oracle, synth):
     np.testing.assert_allclose(r1["points"], w["points"], rtol=0, atol=0)
 
 
+def test_lba_stop_flag_raised_mid_solve(pkg, oracle, synth):
+    """*pbStopFlag is written by the Tracking thread while LocalBundleAdjustment runs (src/LocalMapping.cc:158, plain bool):
+    a host thread raises it while lba_solve is in flight.  g2o polls it between trials / iterations, so the solve stops after k
+    completed outer iterations with stop_reason 3, and what it writes back is exactly the state after those k iterations --
+    the result of a run with maxIterations = k."""
+    import threading
+    import time
+    w = synth.make_ba_window(9, n_opt=50, n_fixed=10, n_points=2000, obs_per_point=10)
+    s = pkg.LbaSolver()
+    try:
+        full = s.solve(w, 10)
+        n_full = full["stats"]["iterations"]
+        assert n_full >= 4
+        t0 = time.perf_counter(); s.solve(w, 10); t_solve = time.perf_counter() - t0
+        hit = None
+        for attempt in range(12):                       # the race is real: try a few delays until the flag lands mid-solve
+            flag = np.zeros(1, np.uint8)
+            delay = t_solve * (0.25 + 0.05 * attempt)
+
+            def raiser():
+                time.sleep(delay)
+                flag[0] = 1
+            th = threading.Thread(target=raiser)
+            th.start()
+            r = s.solve(w, 10, stop_flag=flag)           # ctypes releases the GIL for the duration of the call
+            th.join()
+            if r["stats"]["stop_reason"] == 3 and 0 < r["stats"]["iterations"] < n_full:
+                hit = r
+                break
+        assert hit is not None, "the stop flag never landed inside the solve"
+        k = hit["stats"]["iterations"]
+        ref = s.solve(w, k)                              # optimize(k): the same k outer iterations, then the normal epilogue
+        assert np.isfinite(hit["chi2"]).all() and np.isfinite(hit["points"]).all()
+        if hit["stats"]["trials"] == ref["stats"]["trials"]:       # (a flag that cuts a rejected-trial loop short ends iteration k early)
+            np.testing.assert_array_equal(hit["pose_t"], ref["pose_t"])
+            np.testing.assert_array_equal(hit["pose_q"], ref["pose_q"])
+            np.testing.assert_array_equal(hit["points"], ref["points"])
+            r0 = oracle.lba_solve(w, k)
+            d0 = r0["points"] - w["points"]
+            assert np.abs((hit["points"] - w["points"]) - d0).max() <= 1e-4 * np.abs(d0).max()
+    finally:
+        s.close()
+
+
 def test_lba_outlier_epilogue(pkg, oracle, synth):
     """chi2 > 5.991 / depth test of the reference epilogue (src/Optimizer.cc:1417-1460) selects the same edges."""
     w = synth.make_ba_window(7, n_opt=20, n_fixed=4, n_points=500, obs_per_point=8, outlier_frac=0.08)

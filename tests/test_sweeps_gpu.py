@@ -65,7 +65,9 @@ def test_lba_sweep(pkg, oracle, synth, seed):
         s.close()
     s0, s1 = r0["stats"], r1["stats"]
     assert (s1["iterations"], s1["trials"], s1["stop_reason"]) == (s0["iterations"], s0["trials"], s0["stop_reason"]), kw
-    # weakly constrained windows (3 observations per point) amplify the rounding of the reduced solve: 5e-9 observed
+    # weakly constrained windows (3 observations per point) amplify the rounding of the reduced solve: 5.4e-9 relative is the
+    # largest difference measured (seed 4, gpurun_out/lba_fused.log, round 1).  FROZEN at 1e-7: three decades inside the 1e-4
+    # contract of BASELINE.json and twenty times the observed worst case -- a change that needs more is a regression.
     np.testing.assert_allclose(s1["chi2_final"], s0["chi2_final"], rtol=1e-7)
     d0, d1 = r0["points"] - w["points"], r1["points"] - w["points"]
     assert np.abs(d0 - d1).max() <= 1e-4 * max(np.abs(d0).max(), 1e-12), kw
