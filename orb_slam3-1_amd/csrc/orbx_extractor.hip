@@ -147,6 +147,11 @@ struct orbx_extractor {
     // side stream for the blur (runs beside the latency-bound octree)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // streams for the ranges a large batch is cut into (enqueue)
+    int split_parts = 1;                 // ORBX_SPLIT (measurement knob, see enqueue)
+    std::vector<hipStream_t> aux_streams;
+    hipEvent_t ev_parts_fork = nullptr;
+    std::vector<hipEvent_t> ev_parts_join;
 
     int setup_geometry(int w, int h);
     int ensure_batch(int batch);
@@ -438,77 +443,109 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     int mark_i = 0;
     auto mark = [&]() { if (profile && mark_i < kProfEvents) (void)hipEventRecord(prof_ev[mark_i++], st); };
 #define ORBX_LAUNCHED(name) do { const hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) return fail(ORBX_ERR_HIP, "launch of %s: %s", name, hipGetErrorString(le_)); } while (0)
-    mark();
     // Level 0 is the caller's image.  When its rows can be read with aligned 16-byte loads it is used in place: the resize to
     // level 1, FAST and the blur read it where it lies, and the blur -- which touches every pixel anyway -- leaves the copy in
     // the pyramid that the later readers of level 0 (descriptors, stereo matching, orbx_pyramid_level) use.  Otherwise it is
     // copied first (k_copy_level0), as it is when the host-pointer entry points have uploaded it into the pyramid themselves.
-    SrcImage lvl0;
-    lvl0.base = nullptr; lvl0.frame_stride = 0; lvl0.stride = 0; lvl0.w = levels[0].w; lvl0.h = levels[0].h;
     const bool in_place = !level0_ready && ((uintptr_t)d_imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
-    if (in_place) { lvl0.base = d_imgs; lvl0.frame_stride = frame_stride; lvl0.stride = row_stride; }
-    if (!level0_ready && !in_place) {
-        const LevelDesc& L0 = levels[0];
-        dim3 g((L0.w / 4 + 255) / 256, L0.h, B);
-        hipLaunchKernelGGL(k_copy_level0, g, dim3(256), 0, st, d_imgs, row_stride, frame_stride, d_pyr.p, pyr_frame_bytes, L0);
-        ORBX_LAUNCHED("k_copy_level0");
-    }
-    mark();
-    for (int l = 1; l < nlevels; l++) {
-        const LevelDesc& D = levels[l];
-        dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + kResizeRows - 1) / kResizeRows)), B);
-        const LevelDesc& P = levels[l - 1];
-        SrcImage src;
-        src.base = d_pyr.p + P.off; src.frame_stride = pyr_frame_bytes; src.stride = P.stride; src.w = P.w; src.h = P.h;
-        if (l == 1 && in_place) src = lvl0;
-        hipLaunchKernelGGL(k_resize, g, dim3(256), 0, st, src, d_pyr.p, pyr_frame_bytes, D,
-                           d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
-        ORBX_LAUNCHED("k_resize");
-    }
-    mark();
     const int n_cells = (int)cells.size();
-    if (n_cells > 0)
-        hipLaunchKernelGGL(k_fast_strips, dim3(xcd_grid((int)strips.size()), B), dim3(256), fast_lds, st, lvl0, d_pyr.p, pyr_frame_bytes, d_levels.p, d_cells.p,
-                           d_strips.p, (int)strips.size(), n_cells, ini_th, min_th, fast_layout, d_cand.p, (size_t)cand_frame_entries, d_cell_count.p);
-    ORBX_LAUNCHED("k_fast_strips");
-    mark();
-    // The octree is latency-bound (one wave per frame and level) and leaves most of the chip idle, while the blur only
-    // needs the pyramid: run the blur on a side stream next to octree + index and join before the descriptors.
-    // (Per-stage profiling keeps everything on one stream so that each stage is timed alone.)
-    const bool overlap = !profile && side_stream != nullptr;
-    if (overlap) {
-        ORBX_HIP(hipEventRecord(ev_fork, st));
-        ORBX_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
-        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, side_stream, lvl0, d_pyr.p, in_place ? d_pyr.p : nullptr, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
-                           (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
-        ORBX_HIP(hipEventRecord(ev_join, side_stream));
-    }
-    // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
-    // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
-    // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
-    const bool small_batch = !oct_keys_forced && oct_small_keys > 0 && (long long)B * nlevels <= 512;
-    const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
-    const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
-    auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>);
-    hipLaunchKernelGGL(oct_kernel, dim3(nlevels, B), dim3(64), o_lds, st, d_levels.p, d_cells.p, d_cand.p, (size_t)cand_frame_entries,
-                       d_cell_count.p, n_cells, d_scratch.p, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
-                       d_sel.p, sel_frame_entries, d_sel_count.p, nlevels, o_status, d_oct_nodes.p, oct_node_stride);
-    ORBX_LAUNCHED("k_octree / k_blur");
-    mark();
-    hipLaunchKernelGGL(k_index, dim3(B), dim3(64), 0, st, d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p,
-                       lap0, lap1, cap, d_kp_dst.p, sel_frame_entries, o_n, o_mono, o_status);
-    ORBX_LAUNCHED("k_index");
-    mark();
-    if (overlap) ORBX_HIP(hipStreamWaitEvent(st, ev_join, 0));
-    else
-        hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), B), dim3(256), 0, st, lvl0, d_pyr.p, in_place ? d_pyr.p : nullptr, d_blur.p, pyr_frame_bytes, d_levels.p, d_tiles.p,
-                           (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
-    mark();
     const int quads = (sel_frame_entries + 3) / 4;
-    hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)(((long long)quads * B + 7) / 8 * 8)), dim3(256), 0, st, d_pyr.p, d_blur.p, pyr_frame_bytes,
-                       d_levels.p, nlevels, d_sel.p, sel_frame_entries, d_sel_count.p, d_kp_dst.p, sel_frame_entries,
-                       o_kps, o_desc, cap, d_lvl_kps.p, quads, B);
-    mark();
+
+    // One range of frames [f0, f0 + nB) through the whole pipeline on stream `s`; the blur either on `blur_s` beside the octree
+    // (a single range: the octree is one wave per frame and level and leaves most of the chip idle) or on `s` itself.
+    auto run_range = [&](int f0, int nB, hipStream_t s, hipStream_t blur_s, bool marks) -> int {
+        uint8_t* pyr = d_pyr.p + (size_t)f0 * pyr_frame_bytes;
+        uint8_t* blr = d_blur.p + (size_t)f0 * pyr_frame_bytes;
+        SrcImage lvl0;
+        lvl0.base = nullptr; lvl0.frame_stride = 0; lvl0.stride = 0; lvl0.w = levels[0].w; lvl0.h = levels[0].h;
+        if (in_place) { lvl0.base = d_imgs + (size_t)f0 * frame_stride; lvl0.frame_stride = frame_stride; lvl0.stride = row_stride; }
+        if (marks) mark();
+        if (!level0_ready && !in_place) {
+            const LevelDesc& L0 = levels[0];
+            dim3 g((L0.w / 4 + 255) / 256, L0.h, nB);
+            hipLaunchKernelGGL(k_copy_level0, g, dim3(256), 0, s, d_imgs + (size_t)f0 * frame_stride, row_stride, frame_stride, pyr, pyr_frame_bytes, L0);
+            ORBX_LAUNCHED("k_copy_level0");
+        }
+        if (marks) mark();
+        for (int l = 1; l < nlevels; l++) {
+            const LevelDesc& D = levels[l];
+            dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + kResizeRows - 1) / kResizeRows)), nB);
+            const LevelDesc& P = levels[l - 1];
+            SrcImage src;
+            src.base = pyr + P.off; src.frame_stride = pyr_frame_bytes; src.stride = P.stride; src.w = P.w; src.h = P.h;
+            if (l == 1 && in_place) src = lvl0;
+            hipLaunchKernelGGL(k_resize, g, dim3(256), 0, s, src, pyr, pyr_frame_bytes, D,
+                               d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
+            ORBX_LAUNCHED("k_resize");
+        }
+        if (marks) mark();
+        uint32_t* cand = d_cand.p + (size_t)f0 * cand_frame_entries;
+        int* cell_cnt = d_cell_count.p + (size_t)f0 * std::max<size_t>(cells.size(), 1);
+        if (n_cells > 0)
+            hipLaunchKernelGGL(k_fast_strips, dim3(xcd_grid((int)strips.size()), nB), dim3(256), fast_lds, s, lvl0, pyr, pyr_frame_bytes, d_levels.p, d_cells.p,
+                               d_strips.p, (int)strips.size(), n_cells, ini_th, min_th, fast_layout, cand, (size_t)cand_frame_entries, cell_cnt);
+        ORBX_LAUNCHED("k_fast_strips");
+        if (marks) mark();
+        auto launch_blur = [&](hipStream_t bs) {
+            hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), nB), dim3(256), 0, bs, lvl0, pyr, in_place ? pyr : nullptr, blr, pyr_frame_bytes,
+                               d_levels.p, d_tiles.p, (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
+        };
+        if (blur_s) {
+            ORBX_HIP(hipEventRecord(ev_fork, s));
+            ORBX_HIP(hipStreamWaitEvent(blur_s, ev_fork, 0));
+            launch_blur(blur_s);
+            ORBX_HIP(hipEventRecord(ev_join, blur_s));
+        }
+        // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
+        // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
+        // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
+        const bool small_batch = !oct_keys_forced && oct_small_keys > 0 && (long long)B * nlevels <= 512;
+        const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
+        const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
+        uint32_t* sel = d_sel.p + (size_t)f0 * sel_frame_entries;
+        int* sel_cnt = d_sel_count.p + (size_t)f0 * nlevels;
+        int* kp_dst = d_kp_dst.p + (size_t)f0 * sel_frame_entries;
+        auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>);
+        hipLaunchKernelGGL(oct_kernel, dim3(nlevels, nB), dim3(64), o_lds, s, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
+                           cell_cnt, n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
+                           sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0,
+                           d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride);
+        ORBX_LAUNCHED("k_octree / k_blur");
+        if (marks) mark();
+        hipLaunchKernelGGL(k_index, dim3(nB), dim3(64), 0, s, d_levels.p, nlevels, sel, sel_frame_entries, sel_cnt,
+                           lap0, lap1, cap, kp_dst, sel_frame_entries, o_n + f0, o_mono + f0, o_status + f0);
+        ORBX_LAUNCHED("k_index");
+        if (marks) mark();
+        if (blur_s) ORBX_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        else launch_blur(s);
+        if (marks) mark();
+        hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)(((long long)quads * nB + 7) / 8 * 8)), dim3(256), 0, s, pyr, blr, pyr_frame_bytes,
+                           d_levels.p, nlevels, sel, sel_frame_entries, sel_cnt, kp_dst, sel_frame_entries,
+                           o_kps + (size_t)f0 * cap, o_desc + (size_t)f0 * cap * 32, cap, d_lvl_kps.p + (size_t)f0 * sel_frame_entries, quads, nB);
+        ORBX_LAUNCHED("k_orient_desc");
+        if (marks) mark();
+        return ORBX_OK;
+    };
+
+    // Optionally (ORBX_SPLIT=2..4) a large batch is cut into ranges, each on a stream of its own, so that one range's latency-bound
+    // stages (octree, the dependent resize launches) could hide behind the others' FAST / blur / descriptors.  Measured on MI355X
+    // (B = 256, round 2): 1 range 1.344 ms per step, 2 ranges 1.348, 3 ranges 1.637, 4 ranges 1.649 -- the blur beside the octree
+    // already fills the idle chip and whole-chip kernels of different streams do not co-run, so the default stays ONE range.
+    int parts = 1;
+    if (!profile && split_parts > 1 && B >= 32 * split_parts) parts = std::min(split_parts, 1 + (int)aux_streams.size());
+    int r;
+    if (parts == 1) {
+        if ((r = run_range(0, B, st, (!profile && side_stream) ? side_stream : nullptr, true))) return r;
+    } else {
+        ORBX_HIP(hipEventRecord(ev_parts_fork, st));
+        for (int p = 0; p < parts; p++) {
+            const int f0 = (int)((long long)B * p / parts), f1 = (int)((long long)B * (p + 1) / parts);
+            hipStream_t s = p == 0 ? st : aux_streams[p - 1];
+            if (p > 0) ORBX_HIP(hipStreamWaitEvent(s, ev_parts_fork, 0));
+            if ((r = run_range(f0, f1 - f0, s, nullptr, false))) return r;
+            if (p > 0) { ORBX_HIP(hipEventRecord(ev_parts_join[p - 1], s)); ORBX_HIP(hipStreamWaitEvent(st, ev_parts_join[p - 1], 0)); }
+        }
+    }
     prof_marks = mark_i;
     prof_stream = st;
     ORBX_HIP(hipGetLastError());
@@ -571,7 +608,17 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(ORBX_ERR_HIP, "stream create failed"); }
     if (hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_parts_fork, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
+    if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
+    for (int i = 0; i + 1 < e->split_parts; i++) {
+        hipStream_t s = nullptr; hipEvent_t ev = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            if (s) (void)hipStreamDestroy(s);
+            break;      // fewer ranges then
+        }
+        e->aux_streams.push_back(s); e->ev_parts_join.push_back(ev);
+    }
     *out = e;
     return ORBX_OK;
 }
@@ -584,6 +631,9 @@ void orbx_destroy(orbx_extractor* e)
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    for (hipStream_t s : e->aux_streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t ev : e->ev_parts_join) (void)hipEventDestroy(ev);
+    if (e->ev_parts_fork) (void)hipEventDestroy(e->ev_parts_fork);
     e->d_levels.release(); e->d_cells.release(); e->d_tiles.release(); e->d_strips.release();
     for (auto& b : e->d_qsx0) b.release();
     for (auto& b : e->d_yofs) b.release();
