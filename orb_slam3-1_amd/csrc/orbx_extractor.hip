@@ -255,7 +255,8 @@ int orbx_extractor::setup_geometry(int w, int h)
             while (c1 < (int)cells.size() && cells[c1].y0 == cells[c0].y0) c1++;
             const int n_row = c1 - c0;
             const int w_cell = std::max(cells[c0].x1 - cells[c0].x0 - 6, 1);
-            const int per = std::max(1, std::min(kStripMaxCells, (kStripWidth - 6) / w_cell));
+            static const int strip_width = getenv("ORBX_STRIP_WIDTH") ? std::max(48, std::min(atoi(getenv("ORBX_STRIP_WIDTH")), 250)) : kStripWidth;
+            const int per = std::max(1, std::min(kStripMaxCells, (strip_width - 6) / w_cell));
             const int n_strips_row = (n_row + per - 1) / per;
             for (int k = 0; k < n_strips_row; k++) {
                 const int a = c0 + (int)((long long)n_row * k / n_strips_row), b = c0 + (int)((long long)n_row * (k + 1) / n_strips_row);
@@ -831,7 +832,8 @@ int orbx_debug_introsort(int32_t* count, int32_t* ulx, int32_t* node, int n)
     if (n < 0) return ORBX_ERR_ARG;
     std::vector<SortNode> v(n);
     for (int i = 0; i < n; i++) { v[i].count = count[i]; v[i].ulx = ulx[i]; v[i].node = node[i]; }
-    introsort_nodes(v.data(), n);
+    std::vector<int> stack(3 * kIntrosortStack);
+    introsort_nodes(v.data(), n, stack.data());
     for (int i = 0; i < n; i++) { count[i] = v[i].count; ulx[i] = v[i].ulx; node[i] = v[i].node; }
     return ORBX_OK;
 }

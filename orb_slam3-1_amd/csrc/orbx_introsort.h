@@ -132,12 +132,14 @@ ORBX_SORT_HD inline void insertion_sort(SortNode* v, int first, int last)
 }  // namespace detail
 
 // std::sort(v, v+n, compareNodes)
-ORBX_SORT_HD inline void introsort_nodes(SortNode* v, int n)
+// `stack` = 3 * kIntrosortStack ints of caller-provided storage (LDS on the device: a private array would live in scratch memory)
+constexpr int kIntrosortStack = 64;
+ORBX_SORT_HD inline void introsort_nodes(SortNode* v, int n, int* stack)
 {
     using namespace detail;
     if (n <= 0) return;
     // __introsort_loop with an explicit stack of (first, last, depth) for the recursive right halves
-    int stack_first[64], stack_last[64], stack_depth[64];
+    int* const stack_first = stack; int* const stack_last = stack + kIntrosortStack; int* const stack_depth = stack + 2 * kIntrosortStack;
     int sp = 0;
     stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = floor_log2(n) * 2; sp = 1;
     while (sp > 0) {
@@ -168,7 +170,7 @@ ORBX_SORT_HD inline void introsort_nodes(SortNode* v, int n)
                 ++lo;
             }
             const int cut = lo;
-            if (sp < 64) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
+            if (sp < kIntrosortStack) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
             last = cut;
         }
     }

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
 {
     static_assert(LDS_NODES || !LDS_KEYS, "a pool too large for LDS leaves no room for LDS keys");
     extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_sort_stack[3 * kIntrosortStack];       // the introsort's explicit stack (in LDS, not in private scratch)
     const int level = blockIdx.x, frame = blockIdx.y;
     const int lane = threadIdx.x;
     const LevelDesc L = levels[level];
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
 #ifdef ORBX_OCT_TIMING
                     if (timed) t_prev = clock64();
 #endif
-                    if (lane == 0) introsort_nodes(pv, n_prev);     // std::sort(..., compareNodes) (:700)
+                    if (lane == 0) introsort_nodes(pv, n_prev, s_sort_stack);     // std::sort(..., compareNodes) (:700)
                     __syncthreads();
                     ORBX_OTICK(5)
                     cur_ex ^= 1;
