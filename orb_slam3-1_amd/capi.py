@@ -82,6 +82,7 @@ lib.orbx_debug_blurred_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_
 lib.orbx_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
 lib.orbx_debug_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
 lib.orbx_debug_introsort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+lib.orbx_debug_wave_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 lib.orbx_debug_fast_atan2.restype = C.c_float
 lib.orbx_debug_fast_atan2.argtypes = [C.c_float, C.c_float]
 lib.orbx_debug_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]

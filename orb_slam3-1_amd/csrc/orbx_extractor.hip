@@ -363,7 +363,7 @@ int orbx_extractor::setup_geometry(int w, int h)
         if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST strip of %d quads x %d rows does not fit LDS", max_ngx, max_sth);
     }
     // octree kernel LDS
-    oct_pool = max_nfeat + 16;
+    oct_pool = max_nfeat + 16 + 64;      // a batch of 64 divides takes its children before it returns the 64 parents
     if (oct_pool > 32000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree (16-bit node ids)", max_nfeat);
     const char* env = getenv("ORBX_OCT_LDS_KEYS");
     oct_lds_keys = env ? atoi(env) : 0;      // measured on MI355X: L2-resident HBM scratch + more resident waves beats LDS keys
@@ -838,6 +838,31 @@ int orbx_debug_introsort(int32_t* count, int32_t* ulx, int32_t* node, int n)
     return ORBX_OK;
 }
 
+// the octree's wave-parallel std::sort on the device (one wave, arrays staged in LDS exactly as k_octree holds them): pinned
+// against std::sort itself by tests/test_extractor_gpu.py
+int orbx_debug_wave_sort(int32_t* count, int32_t* ulx, int32_t* node, int n)
+{
+    if (n < 0 || n > 4000) return fail(ORBX_ERR_ARG, "n %d outside 0..4000", n);
+    if (n == 0) return ORBX_OK;
+    std::vector<SortNode> v(n);
+    for (int i = 0; i < n; i++) { v[i].count = count[i]; v[i].ulx = ulx[i]; v[i].node = node[i]; }
+    SortNode* d = nullptr;
+    ORBX_HIP(hipMalloc(&d, sizeof(SortNode) * n));
+    int r = ORBX_OK;
+    const size_t lds = 2 * sizeof(SortNode) * (size_t)n + 2 * (size_t)n + 16;
+    if (hipMemcpy(d, v.data(), sizeof(SortNode) * n, hipMemcpyHostToDevice) != hipSuccess) r = ORBX_ERR_HIP;
+    if (!r && hipFuncSetAttribute((const void*)k_debug_wave_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) r = ORBX_ERR_HIP;
+    if (!r) {
+        hipLaunchKernelGGL(k_debug_wave_sort, dim3(1), dim3(64), lds, 0, d, n);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) r = ORBX_ERR_HIP;
+    }
+    if (!r && hipMemcpy(v.data(), d, sizeof(SortNode) * n, hipMemcpyDeviceToHost) != hipSuccess) r = ORBX_ERR_HIP;
+    (void)hipFree(d);
+    if (r) return fail(r, "device sort failed");
+    for (int i = 0; i < n; i++) { count[i] = v[i].count; ulx[i] = v[i].ulx; node[i] = v[i].node; }
+    return ORBX_OK;
+}
+
 // Frame::ComputeStereoMatches (src/Frame.cc:931-1101) on the pyramids both extractors hold from their LAST extract call.
 static int stereo_enqueue(orbx_extractor* l, orbx_extractor* r, int frame0, int batch,
                           const OrbxKeyPoint* d_kps_l, const uint8_t* d_desc_l, const int32_t* d_n_l,
@@ -915,9 +940,9 @@ float orbx_debug_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 void orbx_debug_sincos(float a, float* c, float* s) { sincos_f32(a, c, s); }
 
 #ifdef ORBX_OCT_TIMING
-int orbx_debug_oct_prof(unsigned long long* out8)
+int orbx_debug_oct_prof(unsigned long long* out10)
 {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(d_oct_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return ORBX_ERR_HIP;
+    if (hipMemcpyFromSymbol(out10, HIP_SYMBOL(d_oct_prof), 10 * sizeof(unsigned long long)) != hipSuccess) return ORBX_ERR_HIP;
     return ORBX_OK;
 }
 #endif

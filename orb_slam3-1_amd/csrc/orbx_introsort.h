@@ -183,4 +183,122 @@ ORBX_SORT_HD inline void introsort_nodes(SortNode* v, int n, int* stack)
     }
 }
 
+
+#if defined(__HIPCC__)
+// The same std::sort, run by one 64-lane wave (the only wave of its workgroup) instead of by one lane.
+//
+// introsort's result is fixed by two things: the sequence of Hoare partitions (which elements get swapped) and the final
+// insertion sort.  Both have data-parallel restatements that move exactly the same elements:
+//  * __unguarded_partition(first + 1, last, pivot = v[first]): the left cursor only ever stops on elements that are
+//    not < pivot and the right cursor on elements the pivot is not <; between two swaps neither cursor crosses an element
+//    the other has touched, so the k-th stop of the left cursor is the k-th such position in ascending order of the
+//    UNSWAPPED array (L_k) and the k-th stop of the right cursor the k-th such position in descending order (R_k).  The loop
+//    swaps (L_k, R_k) while L_k < R_k -- K swaps -- and returns min(L_{K+1}, R_K).  One ballot pass ranks the stops, one pass
+//    swaps the K pairs.
+//  * __final_insertion_sort is a stable sort, and after the partition phase every leaf segment (<= 16 elements, or a
+//    heap-sorted one) is already in its final range: each element's final place is its segment's start plus its stable
+//    rank inside the segment (<= 16 comparisons).
+// `out` receives the sorted array; it doubles as scratch while partitioning (3 ints per element: left stops, right stops,
+// segment bounds).  `rank_tmp`: n shorts.  `stack`: 3 * kIntrosortStack ints.  All four live in the caller's LDS (or an HBM
+// scratch); every lane of the wave must call this with the same arguments.
+__device__ inline void wave_sort_nodes(SortNode* v, SortNode* out, int n, int* stack, short* rank_tmp)
+{
+    using namespace detail;
+    if (n <= 0) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int* const posL = (int*)out; int* const posR = posL + n; int* const seg = posR + n;
+    int* const stack_first = stack; int* const stack_last = stack + kIntrosortStack; int* const stack_depth = stack + 2 * kIntrosortStack;
+    int sp = 0;
+    int first = 0, last = n, depth = floor_log2(n) * 2;
+    while (true) {
+        while (last - first > 16) {
+            if (depth == 0) {           // __partial_sort(first, last, last): heapsort, one lane (adversarial inputs only)
+                if (lane == 0) heap_sort(v, first, last);
+                __syncthreads();
+                break;
+            }
+            --depth;
+            // __move_median_to_first(first, first + 1, mid, last - 1)
+            const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+            const SortNode A = v[ia], Bm = v[ib], Cc = v[ic], F = v[first];
+            int ch;
+            if (node_less(A, Bm)) ch = node_less(Bm, Cc) ? ib : (node_less(A, Cc) ? ic : ia);
+            else ch = node_less(A, Cc) ? ia : (node_less(Bm, Cc) ? ic : ib);
+            const SortNode piv = (ch == ia) ? A : ((ch == ib) ? Bm : Cc);
+            // rank the cursor stops on the array as it is after that swap (position ch now holds the old v[first])
+            int nL = 0, nR = 0;
+            for (int p0 = first + 1; p0 < last; p0 += 64) {
+                const int p = p0 + lane;
+                bool ge = false, le = false;
+                if (p < last) {
+                    SortNode e = v[p];
+                    if (p == ch) e = F;
+                    ge = !node_less(e, piv); le = !node_less(piv, e);
+                }
+                const unsigned long long mg = __ballot(ge), ml = __ballot(le);
+                if (ge) posL[nL + __popcll(mg & lt)] = p;
+                if (le) posR[nR + __popcll(ml & lt)] = p;           // ascending; the right cursor's k-th stop is posR[nR - 1 - k]
+                nL += __popcll(mg); nR += __popcll(ml);
+            }
+            __syncthreads();
+            if (lane == 0) { v[first] = piv; v[ch] = F; }
+            __syncthreads();
+            // K = number of swaps; the pairs are monotone (L ascending, R descending), so the test holds on a prefix
+            int K = 0, cutL = 0x7fffffff, cutR = 0x7fffffff;
+            const int kmax = nL < nR ? nL : nR;
+            for (int k0 = 0; k0 < kmax; k0 += 64) {
+                const int k = k0 + lane;
+                int a = 0, b = 0;
+                if (k < kmax) { a = posL[k]; b = posR[nR - 1 - k]; }
+                const unsigned long long m = __ballot(k < kmax && a < b);
+                K += __popcll(m);
+                if (m != ~0ull) break;
+            }
+            if (K < nL) cutL = posL[K];
+            if (K >= 1) cutR = posR[nR - K];
+            const int cut = cutL < cutR ? cutL : cutR;
+            for (int k0 = 0; k0 < K; k0 += 64) {
+                const int k = k0 + lane;
+                if (k < K) {
+                    const int a = posL[k], b = posR[nR - 1 - k];
+                    const SortNode x = v[a], y = v[b];
+                    v[a] = y; v[b] = x;
+                }
+            }
+            __syncthreads();
+            // __introsort_loop(cut, last, depth) -- later; continue with [first, cut)
+            if (sp < kIntrosortStack) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
+            last = cut;
+        }
+        // [first, last) is a leaf: every element's final place lies inside it
+        for (int p = first + lane; p < last; p += 64) seg[p] = first | (last << 16);
+        if (sp == 0) break;
+        __syncthreads();
+        --sp;
+        first = stack_first[sp]; last = stack_last[sp]; depth = stack_depth[sp];
+    }
+    __syncthreads();
+    // __final_insertion_sort: stable rank inside the leaf
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        int lo = 0, len = 0, rank = 0;
+        SortNode me; me.count = 0; me.ulx = 0; me.node = 0;
+        if (i < n) { const int sg = seg[i]; lo = sg & 0xFFFF; len = (sg >> 16) - lo; me = v[i]; }
+        for (int t = 0; __ballot(t < len) != 0ull; t++) {
+            if (t < len) {
+                const int j = lo + t;
+                const SortNode o = v[j];
+                const bool before = node_less(o, me) || (!node_less(me, o) && j < i);
+                rank += before ? 1 : 0;
+            }
+        }
+        if (i < n) rank_tmp[i] = (short)(lo + rank);
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) out[rank_tmp[i]] = v[i];
+    __syncthreads();
+}
+#endif
+
 }  // namespace orbx

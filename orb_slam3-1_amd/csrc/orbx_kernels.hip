@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restric
 // the stable 4-way key partition of DivideNode is wave-parallel (ballot + prefix popcount).
 // ------------------------------------------------------------------------------------------------
 #ifdef ORBX_OCT_TIMING      // cycle split of the (level 0, frame 0) wave (tools/oct_timing.py); never defined in the product build
-__device__ unsigned long long d_oct_prof[8];
+__device__ unsigned long long d_oct_prof[10];
 #endif
 struct OctLds {
     short* ulx; short* uly; short* brx; short* bry;
@@ -141,6 +141,13 @@ struct OctLds {
 // LDS_NODES: the node pool (boxes, key ranges, push log, the two sort arrays) lives in LDS, which holds about 2500 nodes; levels
 // that ask for more features than that (e.g. 12000 features per frame) take the instantiation whose pool lives in an HBM /
 // L2-resident scratch of its own -- the same code, global_ instead of ds_ instructions.
+//
+// One pass of the reference's loops is a BATCH of up to 64 independent DivideNode calls (the nodes of the list that can still
+// be divided, resp. the next 64 entries of the sorted to-expand vector), one lane per node: the lanes count their node's keys
+// per child (a node with many keys is counted and scattered by the whole wave instead), prefix sums over the lanes give every
+// child its node slot, its place in the push log and in the next to-expand vector in exactly the order the sequential loop
+// would have produced, and -- in the sorted phase -- the lane at which the running size reaches N (the reference breaks
+// there: later lanes do not divide).
 template <bool LDS_KEYS, bool LDS_NODES = true>
 __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
                                                const uint32_t* __restrict__ cand, size_t cand_frame_stride,
@@ -153,307 +160,387 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
 {
     static_assert(LDS_NODES || !LDS_KEYS, "a pool too large for LDS leaves no room for LDS keys");
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_sort_stack[3 * kIntrosortStack];       // the introsort's explicit stack (in LDS, not in private scratch)
+    __shared__ int s_sort_stack[3 * kIntrosortStack];       // the sort's explicit stack (in LDS, not in private scratch)
     const int level = blockIdx.x, frame = blockIdx.y;
     const int lane = threadIdx.x;
     const LevelDesc L = levels[level];
     const int N = L.nfeat;
+    const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef ORBX_OCT_TIMING
-    const long long t_kernel0 = clock64();
+    long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool timed = level == 0 && frame == 0 && lane == 0;
+    long long t_prev = clock64();
+    const long long t_kernel0 = t_prev;
+    int n_div = 0;
+#define ORBX_OTICK(k) if (timed) { const long long t_now = clock64(); tq[k] += t_now - t_prev; t_prev = t_now; }
+#else
+#define ORBX_OTICK(k)
 #endif
 
-    // carve LDS
+    // carve the node pool
     OctLds S;
-    {
-        uint8_t* p;
-        if constexpr (LDS_NODES) p = smem;
-        else p = node_scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * node_stride;
-        SortNode* const ex0 = (SortNode*)p; p += sizeof(SortNode) * pool;      // (named, not an indexed pointer array: a pointer
-        SortNode* const ex1 = (SortNode*)p; p += sizeof(SortNode) * pool;      //  picked with ?: keeps its LDS address space)
-        S.beg = (int*)p; p += 4 * pool;
-        S.cnt = (int*)p; p += 4 * pool;
-        S.ulx = (short*)p; p += 2 * pool;  S.uly = (short*)p; p += 2 * pool;
-        S.brx = (short*)p; p += 2 * pool;  S.bry = (short*)p; p += 2 * pool;
-        S.pidx = (int*)p; p += 4 * pool;
-        S.freelist = (short*)p; p += 2 * pool; S.order = (short*)p; p += 2 * pool;
-        S.plog = (short*)p; p += 2 * kOctLogFactor * pool;
-        S.flg = p; p += (pool + 15) & ~15;
-        // keys follow
-        uint32_t* lds_keys = (uint32_t*)p;
-        // ---- gather the level's candidates in vToDistributeKeys order (cell row-major, row-major inside a cell)
-        const uint32_t* fc = cand + (size_t)frame * cand_frame_stride;
-        const int* cc = cell_count + (size_t)frame * n_cells;
-        int total = 0;
-        for (int c0 = 0; c0 < L.cell_count; c0 += 64) {
-            const int ci = c0 + lane;
-            int v = (ci < L.cell_count) ? cc[L.cell_begin + ci] : 0;
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            total += v;
+    uint8_t* p;
+    if constexpr (LDS_NODES) p = smem;
+    else p = node_scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * node_stride;
+    SortNode* const ex_new = (SortNode*)p; p += sizeof(SortNode) * pool;    // the to-expand vector being appended to
+    SortNode* const ex_sorted = (SortNode*)p; p += sizeof(SortNode) * pool; // the sorted previous one (and the sort's scratch)
+    S.beg = (int*)p; p += 4 * pool;
+    S.cnt = (int*)p; p += 4 * pool;
+    S.ulx = (short*)p; p += 2 * pool;  S.uly = (short*)p; p += 2 * pool;
+    S.brx = (short*)p; p += 2 * pool;  S.bry = (short*)p; p += 2 * pool;
+    S.pidx = (int*)p; p += 4 * pool;
+    S.freelist = (short*)p; p += 2 * pool; S.order = (short*)p; p += 2 * pool;
+    S.plog = (short*)p; p += 2 * kOctLogFactor * pool;
+    S.flg = p; p += (pool + 15) & ~15;
+    // the two key buffers: kb[0 .. cap) and kb[cap .. 2 cap)
+    uint32_t* kb;
+    int cap;
+    if constexpr (LDS_KEYS) { kb = (uint32_t*)p; cap = lds_keys_cap; }
+    else { kb = scratch + (size_t)frame * scratch_frame_stride + 2 * (size_t)L.cand_off; cap = L.cand_cap; }
+
+    int* out_count = sel_count + (size_t)frame * n_levels + level;
+    uint32_t* out = sel + (size_t)frame * sel_frame_stride + L.sel_off;
+
+    // ---- gather the level's candidates in vToDistributeKeys order (cell row-major, row-major inside a cell): one lane per
+    // cell, the in-wave prefix of the cell counts gives each cell its place in the ordered list
+    const uint32_t* fc = cand + (size_t)frame * cand_frame_stride;
+    const int* cc = cell_count + (size_t)frame * n_cells;
+    int total = 0;
+    for (int c0 = 0; c0 < L.cell_count; c0 += 64) {
+        const int ci = c0 + lane;
+        int n = 0, slot_off = 0;
+        if (ci < L.cell_count) { n = cc[L.cell_begin + ci]; slot_off = cells[L.cell_begin + ci].slot_off; }
+        const int incl = wave_incl_scan(n);
+        const int base = total + incl - n;
+        if (base + n > cap) n = 0;          // cannot happen (the buffers hold a whole level); reported below
+        for (int k = 0; __ballot(k < n) != 0ull; k += 8) {
+            uint32_t e[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) e[u] = (k + u < n) ? fc[slot_off + k + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (k + u < n) kb[base + k + u] = e[u];
         }
-        uint32_t* keys[2];
-        if (LDS_KEYS) {
-            if (total > lds_keys_cap) {         // cannot happen: the host sizes the buffers for the largest level's capacity
-                if (lane == 0) { atomicExch(status + frame, ORBX_ERR_INTERNAL); sel_count[(size_t)frame * n_levels + level] = 0; }
-                return;
-            }
-            keys[0] = lds_keys; keys[1] = lds_keys + lds_keys_cap;
-        } else {
-            uint32_t* g = scratch + (size_t)frame * scratch_frame_stride + 2 * (size_t)L.cand_off;
-            keys[0] = g; keys[1] = g + L.cand_cap;
+        total += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (total > cap) {
+        if (lane == 0) { atomicExch(status + frame, ORBX_ERR_INTERNAL); *out_count = 0; }
+        return;
+    }
+    __syncthreads();
+    ORBX_OTICK(0)
+
+    const int width = (L.w - kEdge + 3) - (kEdge - 3), height = (L.h - kEdge + 3) - (kEdge - 3);
+    const int nIni = (height > 0) ? (int)roundf((float)width / (float)height) : 0;      // :559
+    if (total == 0 || nIni <= 0 || nIni > pool / 2) {
+        if (lane == 0) {
+            *out_count = 0;
+            if (total != 0 && nIni > pool / 2) atomicExch(status + frame, ORBX_ERR_INTERNAL);
         }
-        // one lane per cell: in-wave exclusive prefix of the cell counts gives each cell its place in the ordered list
-        int run = 0;
-        for (int c0 = 0; c0 < L.cell_count; c0 += 64) {
-            const int ci = c0 + lane;
-            int n = 0, slot_off = 0;
-            if (ci < L.cell_count) { n = cc[L.cell_begin + ci]; slot_off = cells[L.cell_begin + ci].slot_off; }
-            int incl = n;
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-            const int base = run + incl - n;
-            for (int k = 0; k < n; k++) keys[0][base + k] = fc[slot_off + k];
-            run += __shfl(incl, 63);
+        return;
+    }
+
+    // ---- the list.  std::list<ExtractorNode> with push_front / erase only needs an append-only push log: iterating the
+    // list from begin() is walking the log backwards, erase() leaves a tombstone, and nodes pushed while a pass is running
+    // sit behind its start index exactly like nodes pushed in front of a running list iterator.
+    const int plog_cap = kOctLogFactor * pool;
+    int np = 0, size = 0, nfree = pool, n_ex = 0;
+    for (int i = lane; i < pool; i += 64) S.freelist[i] = (short)(pool - 1 - i);
+    __syncthreads();
+    bool overflow = false;
+    auto compact = [&]() {          // drop tombstones, order preserved (wave-parallel, in place)
+        int w = 0;
+        for (int i0 = 0; i0 < np; i0 += 64) {
+            const int i = i0 + lane;
+            const int id = (i < np) ? (int)S.plog[i] : -1;
+            const unsigned long long m = __ballot(id >= 0);
+            if (id >= 0) { const int pos = w + __popcll(m & lt); S.plog[pos] = (short)id; S.pidx[id] = pos; }
+            w += __popcll(m);
         }
+        np = w;
         __syncthreads();
+    };
 
-        int* out_count = sel_count + (size_t)frame * n_levels + level;
-        uint32_t* out = sel + (size_t)frame * sel_frame_stride + L.sel_off;
-        const int width = (L.w - kEdge + 3) - (kEdge - 3), height = (L.h - kEdge + 3) - (kEdge - 3);
-        const int nIni = (height > 0) ? (int)roundf((float)width / (float)height) : 0;      // :559
-        if (total == 0 || nIni <= 0 || nIni > pool / 2) {
-            if (lane == 0) {
-                *out_count = 0;
-                if (total != 0 && nIni > pool / 2) atomicExch(status + frame, ORBX_ERR_INTERNAL);
-            }
-            return;
+    // ---- root nodes (:564-586): nIni vertical strips of width hX
+    const float hX = (float)width / (float)nIni;
+    if (nIni == 1) {
+        // one root that owns every key: they already stand in order in buffer 0 ((int)(x / hX) is 0 for every x < width)
+        if (lane == 0) {
+            const int id = S.freelist[nfree - 1];
+            S.ulx[id] = 0; S.uly[id] = 0; S.brx[id] = (short)(int)hX; S.bry[id] = (short)height;
+            S.beg[id] = 0; S.cnt[id] = total; S.flg[id] = (uint8_t)(total == 1 ? 1 : 0);
+            S.plog[0] = (short)id; S.pidx[id] = 0;
         }
-
-        // ---- list primitives (wave-uniform: every lane runs them on identical values) ----
-        // std::list<ExtractorNode> with push_front / erase only needs an append-only push log: iterating the list from
-        // begin() is walking the log backwards, erase() leaves a tombstone, and nodes pushed while a pass is running sit
-        // behind its start index exactly like nodes pushed in front of a running list iterator.  This keeps the
-        // dependent LDS round trips per DivideNode to a handful (no prev/next pointer chasing).
-        const int plog_cap = kOctLogFactor * pool;
-        int np = 0, size = 0, nfree = pool;
-        for (int i = lane; i < pool; i += 64) S.freelist[i] = (short)(pool - 1 - i);
+        nfree--; np = 1; size = 1;
         __syncthreads();
-        bool overflow = false;
-        auto push = [&](int i) {
-            if (np >= plog_cap) { overflow = true; return; }
-            S.plog[np] = (short)i; S.pidx[i] = np;
-            np++; size++;
-        };
-        auto compact = [&]() {          // drop tombstones, order preserved (wave-parallel, in place)
-            int w = 0;
-            for (int i0 = 0; i0 < np; i0 += 64) {
-                const int i = i0 + lane;
-                const int id = (i < np) ? (int)S.plog[i] : -1;
-                const unsigned long long m = __ballot(id >= 0);
-                if (id >= 0) { const int pos = w + __popcll(m & ((1ull << lane) - 1ull)); S.plog[pos] = (short)id; S.pidx[id] = pos; }
-                w += __popcll(m);
+    } else {
+        // stable partition of the keys by strip into buffer 1
+        int strip_beg = 0;
+        for (int s = 0; s < nIni; s++) {
+            int cnt = 0;
+            for (int k0 = 0; k0 < total; k0 += 64) {
+                const int k = k0 + lane;
+                bool in = false;
+                uint32_t e = 0;
+                if (k < total) { e = kb[k]; in = ((int)((float)key_x(e) / hX) == s); }
+                const unsigned long long m = __ballot(in);
+                if (in) kb[cap + strip_beg + cnt + __popcll(m & lt)] = e;
+                cnt += __popcll(m);
             }
-            np = w;
-            __syncthreads();
-        };
-
-        // ---- root nodes (:564-586): nIni vertical strips of width hX
-        const float hX = (float)width / (float)nIni;
-        {
-            // assign keys to strips, stable (keys are already in order; strips partition by x)
-            // count per strip with a wave pass, then scatter (nIni is 1 for 4:3 images: plain copy)
-            int strip_beg = 0;
-            for (int s = 0; s < nIni; s++) {
-                int cnt = 0;
-                for (int k0 = 0; k0 < total; k0 += 64) {
-                    const int k = k0 + lane;
-                    bool in = false;
-                    uint32_t e = 0;
-                    if (k < total) { e = keys[0][k]; in = ((int)((float)key_x(e) / hX) == s); }
-                    const unsigned long long m = __ballot(in);
-                    if (in) keys[1][strip_beg + cnt + __popcll(m & ((1ull << lane) - 1ull))] = e;
-                    cnt += __popcll(m);
-                }
-                int id = -1;
-                if (cnt > 0) {      // empty roots are erased (:595-596)
-                    id = S.freelist[--nfree];
+            int id = -1;
+            if (cnt > 0) {      // empty roots are erased (:595-596)
+                id = S.freelist[--nfree];
+                if (lane == 0) {
                     S.ulx[id] = (short)(int)(hX * (float)s);       S.uly[id] = 0;
                     S.brx[id] = (short)(int)(hX * (float)(s + 1)); S.bry[id] = (short)height;
                     S.beg[id] = strip_beg; S.cnt[id] = cnt;
                     S.flg[id] = (uint8_t)(2 | (cnt == 1 ? 1 : 0));
                 }
-                S.order[s] = (short)id;
-                strip_beg += cnt;
             }
-            // the reference push_back()s the roots in strip order; in push-log terms the first strip is pushed last
-            for (int s = nIni - 1; s >= 0; s--) { const int id = S.order[s]; if (id >= 0) push(id); }
-            __syncthreads();
+            if (lane == 0) S.order[s] = (short)id;
+            strip_beg += cnt;
         }
+        __syncthreads();
+        // the reference push_back()s the roots in strip order; in push-log terms the first strip is pushed last
+        for (int s = nIni - 1; s >= 0; s--) {
+            const int id = S.order[s];
+            if (id >= 0) { if (lane == 0) { S.plog[np] = (short)id; S.pidx[id] = np; } np++; size++; }
+        }
+        __syncthreads();
+    }
+    ORBX_OTICK(1)
 
-        int cur_ex = 0, n_ex = 0;
-#ifdef ORBX_OCT_TIMING
-        long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-        int n_div = 0;
-        const bool timed = level == 0 && frame == 0 && lane == 0;
-#define ORBX_OTICK(k) if (timed) { const long long t_now = clock64(); tq[k] += t_now - t_prev; t_prev = t_now; }
-#else
-#define ORBX_OTICK(k)
-#endif
-        // DivideNode + push children to the FRONT in order n1..n4 (:480-536, :639-676); then erase the parent
-        auto divide = [&](int id, int& n_to_expand) {
-#ifdef ORBX_OCT_TIMING
-            if (timed) { t_prev = clock64(); n_div++; }
-#endif
-            const int ulx = S.ulx[id], uly = S.uly[id], brx = S.brx[id], bry = S.bry[id];
-            const int beg = S.beg[id], cnt = S.cnt[id];
-            const int src = (S.flg[id] >> 1) & 1;
-            const int halfX = (brx - ulx + 1) >> 1;     // ceil(float(w)/2), w >= 0
-            const int halfY = (bry - uly + 1) >> 1;
-            const int midx = ulx + halfX, midy = uly + halfY;
-            const uint32_t* kin = src ? keys[1] : keys[0];
-            uint32_t* kout = src ? keys[0] : keys[1];
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            if (cnt <= 64) {
-                // the common case after the first passes: one load, four ballots, one store
+    // One batch of DivideNode calls (:480-536 and the loop bodies :610-676 / :706-750): lane l divides node `id` (or none: -1);
+    // lanes are in processing order.  sorted_phase: stop after the lane whose divide brings the list to N nodes; returns
+    // whether that happened.
+    auto divide_batch = [&](const int id, const bool sorted_phase, int& n_to_expand) -> bool {
+        const bool act = id >= 0;
+        int ulx = 0, uly = 0, brx = 0, bry = 0, beg = 0, cnt = 0, src = 0;
+        if (act) {
+            ulx = S.ulx[id]; uly = S.uly[id]; brx = S.brx[id]; bry = S.bry[id];
+            beg = S.beg[id]; cnt = S.cnt[id]; src = (S.flg[id] >> 1) & 1;
+        }
+        const int halfX = (brx - ulx + 1) >> 1;     // ceil(float(w)/2), w >= 0
+        const int halfY = (bry - uly + 1) >> 1;
+        const int midx = ulx + halfX, midy = uly + halfY;
+        const int in_off = (src ? cap : 0) + beg, out_off = (src ? 0 : cap) + beg;
+        // Scattering a node's keys into the other buffer is harmless when the node ends up not being divided (its range of
+        // the other buffer is dead space of its own), so counting and scattering do not wait for the cut.
+        const unsigned long long m_act = __ballot(act);
+        const int small_max = (__popcll(m_act) <= 6) ? 0 : 32;       // a handful of nodes: the whole wave takes them one by one
+        const bool small = act && cnt <= small_max;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (__ballot(small) != 0ull) {
+            // a lane per node: count, then stable scatter
+            for (int k = 0; __ballot(small && k < cnt) != 0ull; k += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (small && k + u < cnt) {
+                        const uint32_t e = kb[in_off + k + u];
+                        const int cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0);
+                        c0 += cls == 0; c1 += cls == 1; c2 += cls == 2; c3 += cls == 3;
+                    }
+                }
+            }
+            int w0 = out_off, w1 = out_off + c0, w2 = w1 + c1, w3 = w2 + c2;
+            for (int k = 0; __ballot(small && k < cnt) != 0ull; k += 4) {
+                uint32_t e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = (small && k + u < cnt) ? kb[in_off + k + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (small && k + u < cnt) {
+                        const bool r = (int)key_x(e[u]) >= midx, d = (int)key_y(e[u]) >= midy;
+                        const int pos = d ? (r ? w3 : w2) : (r ? w1 : w0);
+                        kb[pos] = e[u];
+                        w0 += (!d && !r); w1 += (!d && r); w2 += (d && !r); w3 += (d && r);
+                    }
+                }
+            }
+        }
+        for (unsigned long long mb = __ballot(act && !small); mb != 0ull; mb &= mb - 1ull) {
+            // the wave per node: ballot + prefix popcount
+            const int b = __builtin_ctzll(mb);
+            const int bin = __builtin_amdgcn_readlane(in_off, b), bout = __builtin_amdgcn_readlane(out_off, b);
+            const int bcnt = __builtin_amdgcn_readlane(cnt, b);
+            const int bmx = __builtin_amdgcn_readlane(midx, b), bmy = __builtin_amdgcn_readlane(midy, b);
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if (bcnt <= 64) {
                 int cls = -1;
                 uint32_t e = 0;
-                if (lane < cnt) { e = kin[beg + lane]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
+                if (lane < bcnt) { e = kb[bin + lane]; cls = ((int)key_x(e) >= bmx ? 1 : 0) + ((int)key_y(e) >= bmy ? 2 : 0); }
                 const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
-                c0 = __popcll(m0); c1 = __popcll(m1); c2 = __popcll(m2); c3 = __popcll(m3);
-                if (cls == 0) kout[beg + __popcll(m0 & lt)] = e;
-                else if (cls == 1) kout[beg + c0 + __popcll(m1 & lt)] = e;
-                else if (cls == 2) kout[beg + c0 + c1 + __popcll(m2 & lt)] = e;
-                else if (cls == 3) kout[beg + c0 + c1 + c2 + __popcll(m3 & lt)] = e;
+                s0 = __popcll(m0); s1 = __popcll(m1); s2 = __popcll(m2); s3 = __popcll(m3);
+                const unsigned long long mm = (cls == 0) ? m0 : (cls == 1) ? m1 : (cls == 2) ? m2 : m3;
+                const int basec = (cls == 0) ? 0 : (cls == 1) ? s0 : (cls == 2) ? s0 + s1 : s0 + s1 + s2;
+                if (cls >= 0) kb[bout + basec + __popcll(mm & lt)] = e;
             } else {
-                // pass 1: child sizes
-                for (int k0 = 0; k0 < cnt; k0 += 64) {
-                    const int k = k0 + lane;
-                    int cls = -1;
-                    if (k < cnt) { const uint32_t e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
-                    c0 += __popcll(__ballot(cls == 0)); c1 += __popcll(__ballot(cls == 1));
-                    c2 += __popcll(__ballot(cls == 2)); c3 += __popcll(__ballot(cls == 3));
+                // pass 1: child sizes (four chunks of 64 keys in flight)
+                for (int k0 = 0; k0 < bcnt; k0 += 256) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int k = k0 + 64 * u + lane; e[u] = (k < bcnt) ? kb[bin + k] : 0u; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int k = k0 + 64 * u + lane;
+                        const int cls = (k < bcnt) ? ((int)key_x(e[u]) >= bmx ? 1 : 0) + ((int)key_y(e[u]) >= bmy ? 2 : 0) : -1;
+                        s0 += __popcll(__ballot(cls == 0)); s1 += __popcll(__ballot(cls == 1));
+                        s2 += __popcll(__ballot(cls == 2)); s3 += __popcll(__ballot(cls == 3));
+                    }
                 }
                 // pass 2: stable scatter into the other buffer
-                int w0 = beg, w1 = beg + c0, w2 = beg + c0 + c1, w3 = beg + c0 + c1 + c2;
-                for (int k0 = 0; k0 < cnt; k0 += 64) {
-                    const int k = k0 + lane;
-                    int cls = -1;
-                    uint32_t e = 0;
-                    if (k < cnt) { e = kin[beg + k]; cls = ((int)key_x(e) >= midx ? 1 : 0) + ((int)key_y(e) >= midy ? 2 : 0); }
-                    const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
-                    if (cls == 0) kout[w0 + __popcll(m0 & lt)] = e;
-                    else if (cls == 1) kout[w1 + __popcll(m1 & lt)] = e;
-                    else if (cls == 2) kout[w2 + __popcll(m2 & lt)] = e;
-                    else if (cls == 3) kout[w3 + __popcll(m3 & lt)] = e;
-                    w0 += __popcll(m0); w1 += __popcll(m1); w2 += __popcll(m2); w3 += __popcll(m3);
-                }
-            }
-            ORBX_OTICK(0)
-            // children: lane c (< 4) writes child c -- its slot in the free list, the push log and the to-expand array is
-            // its rank among the non-empty (resp. still divisible) children before it, so the four are independent
-            const int e0 = c0 > 0, e1 = c1 > 0, e2 = c2 > 0, e3 = c3 > 0;
-            const int x0 = c0 > 1, x1 = c1 > 1, x2 = c2 > 1, x3 = c3 > 1;
-            const int ne = e0 + e1 + e2 + e3, nx = x0 + x1 + x2 + x3;
-            if (nfree < 4 || np + ne > plog_cap) { overflow = true; return; }
-            if (lane < 4) {
-                const int cn_me = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
-                if (cn_me > 0) {
-                    const int r = (lane > 0 ? e0 : 0) + (lane > 1 ? e1 : 0) + (lane > 2 ? e2 : 0);
-                    const int rx = (lane > 0 ? x0 : 0) + (lane > 1 ? x1 : 0) + (lane > 2 ? x2 : 0);
-                    const int cb_me = beg + (lane > 0 ? c0 : 0) + (lane > 1 ? c1 : 0) + (lane > 2 ? c2 : 0);
-                    const int ch = S.freelist[nfree - 1 - r];
-                    const int ux = (lane & 1) ? midx : ulx, uy = (lane & 2) ? midy : uly;
-                    S.ulx[ch] = (short)ux; S.uly[ch] = (short)uy;
-                    S.brx[ch] = (short)((lane & 1) ? brx : midx); S.bry[ch] = (short)((lane & 2) ? bry : midy);
-                    S.beg[ch] = cb_me; S.cnt[ch] = cn_me;
-                    S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn_me == 1 ? 1 : 0));
-                    S.plog[np + r] = (short)ch; S.pidx[ch] = np + r;               // push(): children n1..n4 in order
-                    if (cn_me > 1 && n_ex + rx < pool) { SortNode sn; sn.count = cn_me; sn.ulx = ux; sn.node = ch; (cur_ex ? ex1 : ex0)[n_ex + rx] = sn; }
-                }
-            }
-            np += ne; size += ne; nfree -= ne;
-            n_to_expand += nx; n_ex += nx;
-            if (lane == 0) { S.plog[S.pidx[id]] = -1; S.freelist[nfree] = (short)id; }       // kill(id)
-            nfree++; size--;
-            ORBX_OTICK(1)
-            __syncthreads();        // key scatter visible to every lane before the children are read
-            ORBX_OTICK(2)
-        };
-
-#ifdef ORBX_OCT_TIMING
-        if (timed) tq[3] = clock64() - t_kernel0;
-#endif
-        bool finish = false;
-        int guard = 0;
-        while (!finish && !overflow && guard++ < 64) {
-            const int prev_size = size;
-            int n_to_expand = 0;
-            n_ex = 0;
-            compact();
-            for (int idx = np - 1; idx >= 0 && !overflow; idx--) {      // children pushed by this pass land behind idx
-                const int cur = S.plog[idx];
-                if (cur >= 0 && !(S.flg[cur] & 1)) divide(cur, n_to_expand);
-            }
-            if (size >= N || size == prev_size) {
-                finish = true;
-            } else if (size + n_to_expand * 3 > N) {
-                int guard2 = 0;
-                while (!finish && !overflow && guard2++ < 4096) {
-                    const int prev_size2 = size;
-                    compact();
-                    const int n_prev = min(n_ex, pool);
-                    SortNode* pv = cur_ex ? ex1 : ex0;
-#ifdef ORBX_OCT_TIMING
-                    if (timed) t_prev = clock64();
-#endif
-                    if (lane == 0) introsort_nodes(pv, n_prev, s_sort_stack);     // std::sort(..., compareNodes) (:700)
-                    __syncthreads();
-                    ORBX_OTICK(5)
-                    cur_ex ^= 1;
-                    n_ex = 0;
-                    int dummy = 0;
-                    for (int j = n_prev - 1; j >= 0; j--) {
-                        divide(pv[j].node, dummy);
-                        if (size >= N || overflow) break;
+                int w0 = bout, w1 = bout + s0, w2 = w1 + s1, w3 = w2 + s2;
+                for (int k0 = 0; k0 < bcnt; k0 += 256) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int k = k0 + 64 * u + lane; e[u] = (k < bcnt) ? kb[bin + k] : 0u; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int k = k0 + 64 * u + lane;
+                        const int cls = (k < bcnt) ? ((int)key_x(e[u]) >= bmx ? 1 : 0) + ((int)key_y(e[u]) >= bmy ? 2 : 0) : -1;
+                        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+                        const unsigned long long mm = (cls == 0) ? m0 : (cls == 1) ? m1 : (cls == 2) ? m2 : m3;
+                        const int wc = (cls == 0) ? w0 : (cls == 1) ? w1 : (cls == 2) ? w2 : w3;
+                        if (cls >= 0) kb[wc + __popcll(mm & lt)] = e[u];
+                        w0 += __popcll(m0); w1 += __popcll(m1); w2 += __popcll(m2); w3 += __popcll(m3);
                     }
-                    if (size >= N || size == prev_size2) finish = true;
                 }
             }
+            if (lane == b) { c0 = s0; c1 = s1; c2 = s2; c3 = s3; }
         }
-        if (overflow || n_ex > pool) {
-            if (lane == 0) { atomicExch(status + frame, ORBX_ERR_INTERNAL); *out_count = 0; }
-            return;
-        }
+        ORBX_OTICK(2)
 
-        // ---- final list order, then the best-response key of every node, first wins ties (:758-776)
-#ifdef ORBX_OCT_TIMING
-        if (timed) t_prev = clock64();
-#endif
-        compact();
-        for (int k = lane; k < np && k < pool; k += 64) S.order[k] = S.plog[np - 1 - k];
-        __syncthreads();
-        const int n_out = min(size, L.sel_cap);
-        for (int k = lane; k < n_out; k += 64) {
-            const int id = S.order[k];
-            const uint32_t* kb = (((S.flg[id] >> 1) & 1) ? keys[1] : keys[0]) + S.beg[id];
-            const int cnt = S.cnt[id];
-            uint32_t best = kb[0];
-            for (int i = 1; i < cnt; i++) {
-                const uint32_t e = kb[i];
-                if (key_resp(e) > key_resp(best)) best = e;
+        // ---- bookkeeping, a lane per node
+        bool keep = act, reached = false;
+        if (sorted_phase) {
+            const int grow = act ? (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0) - 1 : 0;
+            const int incl_g = wave_incl_scan(grow);
+            const unsigned long long hit = __ballot(act && size + incl_g >= N);     // `if ((int)lNodes.size() >= N) break;` after this divide
+            if (hit != 0ull) { reached = true; keep = act && lane <= __builtin_ctzll(hit); }
+        }
+        const int ne = keep ? (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0) : 0;
+        const int nx = keep ? (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1) : 0;
+        const int incl_e = wave_incl_scan(ne), incl_x = wave_incl_scan(nx), incl_a = wave_incl_scan(keep ? 1 : 0);
+        const int tot_e = __builtin_amdgcn_readlane(incl_e, 63), tot_x = __builtin_amdgcn_readlane(incl_x, 63), tot_a = __builtin_amdgcn_readlane(incl_a, 63);
+        if (nfree < tot_e || np + tot_e > plog_cap || n_ex + tot_x > pool) { overflow = true; return true; }
+        if (keep) {
+            int slot = np + incl_e - ne, fl = nfree - 1 - (incl_e - ne), xs = n_ex + incl_x - nx, cb = beg;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int cn = (c == 0) ? c0 : (c == 1) ? c1 : (c == 2) ? c2 : c3;
+                if (cn > 0) {
+                    const int ch = S.freelist[fl--];
+                    const int ux = (c & 1) ? midx : ulx, uy = (c & 2) ? midy : uly;
+                    S.ulx[ch] = (short)ux; S.uly[ch] = (short)uy;
+                    S.brx[ch] = (short)((c & 1) ? brx : midx); S.bry[ch] = (short)((c & 2) ? bry : midy);
+                    S.beg[ch] = cb; S.cnt[ch] = cn;
+                    S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn == 1 ? 1 : 0));
+                    S.plog[slot] = (short)ch; S.pidx[ch] = slot; slot++;            // push_front, children n1..n4 in order
+                    if (cn > 1) { SortNode sn; sn.count = cn; sn.ulx = ux; sn.node = ch; ex_new[xs++] = sn; }
+                    cb += cn;
+                }
             }
-            out[k] = best;
+            S.plog[S.pidx[id]] = -1;        // erase the parent
         }
-        if (lane == 0) {
-            *out_count = n_out;
-            if (size > L.sel_cap) atomicExch(status + frame, ORBX_ERR_INTERNAL);
-        }
-        ORBX_OTICK(6)
+        __syncthreads();                    // the free-list reads above come before the writes below
+        np += tot_e; size += tot_e - tot_a; nfree -= tot_e;
+        if (keep) S.freelist[nfree + incl_a - 1] = (short)id;
+        nfree += tot_a;
+        n_to_expand += tot_x; n_ex += tot_x;
 #ifdef ORBX_OCT_TIMING
-        if (timed) { d_oct_prof[0] = (unsigned long long)tq[0]; d_oct_prof[1] = (unsigned long long)tq[1]; d_oct_prof[2] = (unsigned long long)tq[2];
-                     d_oct_prof[3] = (unsigned long long)n_div; d_oct_prof[4] = (unsigned long long)(clock64() - t_kernel0); d_oct_prof[5] = (unsigned long long)total;
-                     d_oct_prof[6] = (unsigned long long)tq[3]; d_oct_prof[7] = (unsigned long long)((tq[5] << 32) | (tq[6] & 0xFFFFFFFFll)); }
+        n_div += tot_a;
 #endif
+        __syncthreads();        // key scatter and node records visible before the next batch reads them
+        ORBX_OTICK(3)
+        return reached;
+    };
+
+    bool finish = false;
+    int guard = 0;
+    while (!finish && !overflow && guard++ < 64) {
+        const int prev_size = size;
+        int n_to_expand = 0;
+        n_ex = 0;
+        compact();
+        const int np0 = np;                 // children pushed by this pass land behind the pass
+        for (int b0 = 0; b0 < np0 && !overflow; b0 += 64) {
+            const int idx = np0 - 1 - (b0 + lane);
+            int id = -1;
+            if (idx >= 0) { const int cur = S.plog[idx]; if (cur >= 0 && !(S.flg[cur] & 1)) id = cur; }
+            if (__ballot(id >= 0) != 0ull) divide_batch(id, false, n_to_expand);
+        }
+        if (size >= N || size == prev_size) {
+            finish = true;
+        } else if (size + n_to_expand * 3 > N) {
+            int guard2 = 0;
+            while (!finish && !overflow && guard2++ < 4096) {
+                const int prev_size2 = size;
+                compact();
+                const int n_prev = min(n_ex, pool);
+                ORBX_OTICK(4)
+                wave_sort_nodes(ex_new, ex_sorted, n_prev, s_sort_stack, S.order);     // std::sort(..., compareNodes) (:700)
+                ORBX_OTICK(5)
+                n_ex = 0;
+                int dummy = 0;
+                for (int b0 = 0; b0 < n_prev && !overflow; b0 += 64) {          // for (j = size - 1; j >= 0; j--)
+                    const int j = n_prev - 1 - (b0 + lane);
+                    const int id = (j >= 0) ? ex_sorted[j].node : -1;
+                    if (divide_batch(id, true, dummy)) break;
+                }
+                if (size >= N || size == prev_size2) finish = true;
+            }
+        }
     }
+    if (overflow) {
+        if (lane == 0) { atomicExch(status + frame, ORBX_ERR_INTERNAL); *out_count = 0; }
+        return;
+    }
+    ORBX_OTICK(4)
+
+    // ---- final list order, then the best-response key of every node, first wins ties (:758-776)
+    compact();
+    for (int k = lane; k < np && k < pool; k += 64) S.order[k] = S.plog[np - 1 - k];
+    __syncthreads();
+    const int n_out = min(size, L.sel_cap);
+    for (int k0 = 0; k0 < n_out; k0 += 64) {
+        const int k = k0 + lane;
+        int off = 0, cnt = 0;
+        if (k < n_out) { const int id = S.order[k]; off = (((S.flg[id] >> 1) & 1) ? cap : 0) + S.beg[id]; cnt = S.cnt[id]; }
+        uint32_t best = 0;
+        for (int i = 0; __ballot(i < cnt) != 0ull; i += 4) {
+            uint32_t e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = (i + u < cnt) ? kb[off + i + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i + u < cnt && (i + u == 0 || key_resp(e[u]) > key_resp(best))) best = e[u];
+        }
+        if (k < n_out) out[k] = best;
+    }
+    if (lane == 0) {
+        *out_count = n_out;
+        if (size > L.sel_cap) atomicExch(status + frame, ORBX_ERR_INTERNAL);
+    }
+    ORBX_OTICK(6)
+#ifdef ORBX_OCT_TIMING
+    if (timed) {
+        for (int i = 0; i < 7; i++) d_oct_prof[i] = (unsigned long long)tq[i];
+        d_oct_prof[7] = (unsigned long long)(clock64() - t_kernel0);
+        d_oct_prof[8] = (unsigned long long)total; d_oct_prof[9] = (unsigned long long)n_div;
+    }
+#endif
+}
+
+// test hook: wave_sort_nodes on one array (orbx_debug_wave_sort)
+__global__ __launch_bounds__(64) void k_debug_wave_sort(SortNode* __restrict__ data, int n)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_stack[3 * kIntrosortStack];
+    SortNode* const v = (SortNode*)smem;
+    SortNode* const out = v + n;
+    short* const rank_tmp = (short*)(out + n);
+    for (int i = threadIdx.x; i < n; i += 64) v[i] = data[i];
+    __syncthreads();
+    wave_sort_nodes(v, out, n, s_stack, rank_tmp);
+    for (int i = threadIdx.x; i < n; i += 64) data[i] = out[i];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -177,3 +177,36 @@ def test_fast_threshold_fallback_cells(pkg, oracle):
             np.testing.assert_array_equal(desc, odesc)
         finally:
             ex.close()
+
+
+def _adversarial_counts(n):
+    # sorted, reversed, all-equal, organ-pipe and a median-of-3 killer: the depth limit / heapsort fallback
+    seqs = [np.arange(n), np.arange(n)[::-1], np.zeros(n), np.minimum(np.arange(n), n - np.arange(n))]
+    k = n // 2
+    killer = np.zeros(n, np.int64)
+    for i in range(k):
+        killer[i] = i + 1 if i % 2 == 0 else k + i + (1 if k % 2 == 0 else 0)
+        killer[k + i] = (i + 1) * 2
+    seqs.append(killer)
+    return seqs
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 18, 33, 64, 65, 100, 129, 217, 500, 1085, 3000])
+def test_wave_sort_is_std_sort(pkg, oracle, n):
+    """the octree's wave-parallel sort (ranked Hoare partitions + stable leaf ranks) moves elements exactly like libstdc++'s
+    std::sort with the reference's compareNodes, including the order of tied elements (ORBextractor.cc:538-553, :700)"""
+    rs = np.random.RandomState(n)
+    cases = []
+    for trial in range(6):
+        cases.append((rs.randint(2, 2 + max(1, (trial + 1) * 3), n), rs.randint(0, 1 + trial * 2, n) * 19))
+    cases.append((rs.randint(2, 2000, n), rs.randint(0, 600, n)))
+    if n >= 500:
+        cases += [(s, np.zeros(n)) for s in _adversarial_counts(n)]
+    for count, ulx in cases:
+        count = np.ascontiguousarray(count).astype(np.int32); ulx = np.ascontiguousarray(ulx).astype(np.int32)
+        tag = np.arange(n, dtype=np.int32)
+        c1, u1, t1 = count.copy(), ulx.copy(), tag.copy()
+        c2, u2, t2 = count.copy(), ulx.copy(), tag.copy()
+        oracle.lib.orb_oracle_sort_nodes(c1.ctypes.data, u1.ctypes.data, t1.ctypes.data, n)
+        assert pkg.lib.orbx_debug_wave_sort(c2.ctypes.data, u2.ctypes.data, t2.ctypes.data, n) == 0
+        np.testing.assert_array_equal(c2, c1); np.testing.assert_array_equal(u2, u1); np.testing.assert_array_equal(t2, t1)
