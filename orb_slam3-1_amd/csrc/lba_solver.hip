@@ -444,8 +444,17 @@ __device__ __forceinline__ double rsqrt_newton(double d)
 // its 4 x 4 tile would need.  Thread (ty, tx) = lane (ty & 3) * 16 + tx of wave ty >> 2 owns rows ty + 16 a: exactly the rows
 // of accumulator component a when the wave feeds the MFMA rows m -> 4 w + (m & 3) + 16 (m >> 2) (as k_chol_step does), so
 // Lacc[b][a] / Xacc[b][a] ARE the thread's elements (ty + 16 a, tx + 16 b).
+#ifdef LBA_STEP_TIMING       // cycle split of the 4-column groups of chol_tile_mfma (thread 0 of the factoring workgroup)
+__device__ unsigned long long d_tile_prof[8];
+#define LBA_TTICK(k) if (threadIdx.x == 0) { const long long t_now = clock64(); d_tile_prof[k] += (unsigned long long)(t_now - t_tile); t_tile = t_now; }
+#else
+#define LBA_TTICK(k)
+#endif
 __device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, double* __restrict__ Li, CholVec4& sv)
 {
+#ifdef LBA_STEP_TIMING
+    long long t_tile = clock64();
+#endif
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int lk = ty & 3, wv4 = ty & ~3;                   // MFMA k index of this lane; first row of the wave's row group
     const int r_u = wv4 + (tx & 3) + 16 * (tx >> 2);        // the row whose U value this lane feeds (MFMA row m = tx)
@@ -463,6 +472,7 @@ __device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, doubl
             const int p = (jy >> 2) & 1;
             const int ko = tx - jy;                         // 0..3: this thread owns a pivot column
             const bool own_rows = wv4 == jy;                // wave-uniform: this wave owns the pivot rows j0 + (ty & 3)
+            LBA_TTICK(0)
             if (ko >= 0 && ko < 4) {
 #pragma unroll
                 for (int a = 0; a < 4; a++) sv.col[p][ko][ty + 16 * a] = Lacc[ja][a];
@@ -471,7 +481,25 @@ __device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, doubl
 #pragma unroll
                 for (int b = 0; b < 4; b++) sv.row[p][lk][tx + 16 * b] = Xacc[b][ja];
             }
+            LBA_TTICK(1)
             __syncthreads();
+            LBA_TTICK(2)
+            // the operand reads go out first: they land while the pivot chain below runs
+            // A operand: -U[r_u][lk], zero for the rows of the pivot block and above (they take no update)
+            const double c0u = sv.col[p][0][r_u], c1u = sv.col[p][1][r_u], c2u = sv.col[p][2][r_u], c3u = sv.col[p][3][r_u];
+            double cv[4][4], rv[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = tx + 16 * b;
+                if (b >= ja) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) cv[b][k] = sv.col[p][k][c];
+                }
+                if (b <= ja) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) rv[b][k] = sv.row[p][k][c];
+                }
+            }
             // pivot block (lower triangle): P[k][m] = column m, row j0 + k
             const double P00 = sv.col[p][0][j0], P10 = sv.col[p][0][j0 + 1], P20 = sv.col[p][0][j0 + 2], P30 = sv.col[p][0][j0 + 3];
             const double P11 = sv.col[p][1][j0 + 1], P21 = sv.col[p][1][j0 + 2], P31 = sv.col[p][1][j0 + 3];
@@ -498,26 +526,37 @@ __device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, doubl
             const double m1 = lk == 0 ? 0.0 : lk == 1 ? i1 : lk == 2 ? M21 : M31;
             const double m2 = lk < 2 ? 0.0 : lk == 2 ? i2 : M32;
             const double m3 = lk < 3 ? 0.0 : i3;
-            // A operand: -U[r_u][lk], zero for the rows of the pivot block and above (they take no update)
-            double au = fma(m3, sv.col[p][3][r_u], fma(m2, sv.col[p][2][r_u], fma(m1, sv.col[p][1][r_u], m0 * sv.col[p][0][r_u])));
+#ifdef LBA_STEP_TIMING
+            if (threadIdx.x == 0 && m3 == 12345.678) d_tile_prof[7] += 1;      // (keeps the pivot chain ahead of the tick)
+#endif
+            LBA_TTICK(3)
+            // independent FMA trees the scheduler can interleave, the MFMAs back to back after them
+            double au = fma(m1, c1u, m0 * c0u) + fma(m3, c3u, m2 * c2u);
             au = (r_u > j0 + 3) ? -au : 0.0;
+            double vb[4], xb[4];
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const int c = tx + 16 * b;
                 if (b >= ja) {      // columns right of the pivot group belong to L:  L -= U V^T
-                    double vb = fma(m3, sv.col[p][3][c], fma(m2, sv.col[p][2][c], fma(m1, sv.col[p][1][c], m0 * sv.col[p][0][c])));
-                    if (b == ja && c <= j0 + 3) vb = 0.0;
-                    Lacc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, vb, Lacc[b], 0, 0, 0);
+                    vb[b] = fma(m1, cv[b][1], m0 * cv[b][0]) + fma(m3, cv[b][3], m2 * cv[b][2]);
+                    if (b == ja && c <= j0 + 3) vb[b] = 0.0;
                 }
-                if (b <= ja) {      // the others to X:  X -= U Xn, and the pivot rows of X become Xn
-                    double xb = fma(m3, sv.row[p][3][c], fma(m2, sv.row[p][2][c], fma(m1, sv.row[p][1][c], m0 * sv.row[p][0][c])));
-                    const double xop = (b == ja && c > j0 + 3) ? 0.0 : xb;
+                if (b <= ja)        // the others to X:  X -= U Xn, and the pivot rows of X become Xn
+                    xb[b] = fma(m1, rv[b][1], m0 * rv[b][0]) + fma(m3, rv[b][3], m2 * rv[b][2]);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = tx + 16 * b;
+                if (b >= ja) Lacc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, vb[b], Lacc[b], 0, 0, 0);
+                if (b <= ja) {
+                    const double xop = (b == ja && c > j0 + 3) ? 0.0 : xb[b];
                     Xacc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, xop, Xacc[b], 0, 0, 0);
-                    if (own_rows) Xacc[b][ja] = xb;         // X[j0 + lk][c] = Xn[lk][c]
+                    if (own_rows) Xacc[b][ja] = xb[b];      // X[j0 + lk][c] = Xn[lk][c]
                 }
             }
         }
     }
+    LBA_TTICK(0)
     if (failed) return false;
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -1216,6 +1255,13 @@ extern "C" int lba_debug_step_prof(unsigned long long* out8)
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lba::d_step_prof), sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(lba::d_step_prof), z, sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    return ORBX_OK;
+}
+extern "C" int lba_debug_tile_prof(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lba::d_tile_prof), sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lba::d_tile_prof), z, sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
     return ORBX_OK;
 }
 #endif

@@ -17,6 +17,7 @@ s = pkg.LbaSolver()
 s.solve(w, 10)
 out = (C.c_ulonglong * 8)()
 pkg.lib.lba_debug_step_prof(out)
+pkg.lib.lba_debug_tile_prof(out)
 for _ in range(5):
     s.solve(w, 10)
 pkg.lib.lba_debug_step_prof(out)
@@ -26,4 +27,7 @@ names = ["stage Linv / A into LDS", "X = A Linv^T", "store X to Lp", "load the t
 for k, nm in enumerate(names):
     print("%-26s %7.2f us" % (nm, v[k] / n / 100.0))
 print("%-26s %7.2f us over %d steps" % ("total", sum(v[:7]) / n / 100.0, v[7]))
+pkg.lib.lba_debug_tile_prof(out)
+t = list(out)
+print("chol_tile_mfma, cycles over all 4-column groups of all workgroups' thread 0: MFMA drain + loop %d, publish %d, barrier %d, pivot block + M %d" % (t[0], t[1], t[2], t[3]))
 s.close()
