@@ -147,6 +147,11 @@ struct orbx_extractor {
     // side stream for the blur (runs beside the latency-bound octree)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // second stream for the octree of the upper pyramid levels (their node pools are small: own launch, own LDS size)
+    hipStream_t oct_stream = nullptr;
+    hipEvent_t ev_oct_join = nullptr;
+    int oct_split = 0, oct_pool_hi = 0;  // levels [oct_split, nlevels) go to the second launch with a pool of oct_pool_hi nodes (0: one launch)
+    size_t oct_lds_hi = 0;
     // streams for the ranges a large batch is cut into (enqueue)
     int split_parts = 1;                 // ORBX_SPLIT (measurement knob, see enqueue)
     std::vector<hipStream_t> aux_streams;
@@ -363,12 +368,27 @@ int orbx_extractor::setup_geometry(int w, int h)
         if (fast_lds > 150 * 1024) return fail(ORBX_ERR_ARG, "FAST strip of %d quads x %d rows does not fit LDS", max_ngx, max_sth);
     }
     // octree kernel LDS
-    oct_pool = max_nfeat + 16 + 64;      // a batch of 64 divides takes its children before it returns the 64 parents
+    oct_pool = max_nfeat + 16;
     if (oct_pool > 32000) return fail(ORBX_ERR_ARG, "nfeatures per level %d too large for the device octree (16-bit node ids)", max_nfeat);
     const char* env = getenv("ORBX_OCT_LDS_KEYS");
     oct_lds_keys = env ? atoi(env) : 0;      // measured on MI355X: L2-resident HBM scratch + more resident waves beats LDS keys
     oct_keys_forced = env != nullptr;        // ... for large batches; small batches are latency-bound and take LDS keys (enqueue())
-    const size_t node_bytes = (size_t)oct_pool * (2 * sizeof(SortNode) + 8 + 16 + 2 * kOctLogFactor) + (size_t)((oct_pool + 15) & ~15);
+    auto pool_bytes = [](int pool) { return (size_t)pool * (2 * sizeof(SortNode) + 8 + 16 + 2 * kOctLogFactor) + (size_t)((pool + 15) & ~15); };
+    const size_t node_bytes = pool_bytes(oct_pool);
+    // Large batches run the octree beside the blur, and a workgroup's LDS is sized by its launch: with one launch every level
+    // would hold the node pool of the largest one (8 levels x 14 KB per frame and CU leave the blur no LDS to run in).  The upper
+    // levels -- fewer features each -- therefore get a launch of their own with a pool of their size; the split that minimises
+    // the LDS per frame is taken.
+    oct_split = 0; oct_pool_hi = 0; oct_lds_hi = 0;
+    {
+        size_t best = (size_t)nlevels * node_bytes;
+        for (int sp = 1; sp < nlevels; sp++) {
+            int hi = 0;
+            for (int l = sp; l < nlevels; l++) hi = std::max(hi, levels[l].nfeat);
+            const size_t cost = (size_t)sp * node_bytes + (size_t)(nlevels - sp) * pool_bytes(hi + 16);
+            if (cost < best) { best = cost; oct_split = sp; oct_pool_hi = hi + 16; oct_lds_hi = pool_bytes(hi + 16) + 16; }
+        }
+    }
     // the node pool of a level lives in LDS (about 2500 nodes); a level with more features takes the instantiation whose pool
     // lives in an HBM scratch (ensure_batch allocates it)
     oct_nodes_hbm = node_bytes > 150 * 1024;
@@ -507,10 +527,21 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         int* sel_cnt = d_sel_count.p + (size_t)f0 * nlevels;
         int* kp_dst = d_kp_dst.p + (size_t)f0 * sel_frame_entries;
         auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>);
-        hipLaunchKernelGGL(oct_kernel, dim3(nlevels, nB), dim3(64), o_lds, s, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
+        // (keys in LDS: one launch, the buffers are sized for the largest level anyway)
+        const bool two_launches = !oct_nodes_hbm && o_keys == 0 && oct_split > 0 && oct_stream && blur_s;
+        const int lv_lo = two_launches ? oct_split : nlevels;
+        if (two_launches) {
+            ORBX_HIP(hipStreamWaitEvent(oct_stream, ev_fork, 0));
+            hipLaunchKernelGGL(oct_kernel, dim3(nlevels - oct_split, nB), dim3(64), oct_lds_hi, oct_stream, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
+                               cell_cnt, n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, oct_pool_hi, 0,
+                               sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0, (uint8_t*)nullptr, (size_t)0, oct_split);
+            ORBX_HIP(hipEventRecord(ev_oct_join, oct_stream));
+        }
+        hipLaunchKernelGGL(oct_kernel, dim3(lv_lo, nB), dim3(64), o_lds, s, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
                            cell_cnt, n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
                            sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0,
-                           d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride);
+                           d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride, 0);
+        if (two_launches) ORBX_HIP(hipStreamWaitEvent(s, ev_oct_join, 0));
         ORBX_LAUNCHED("k_octree / k_blur");
         if (marks) mark();
         hipLaunchKernelGGL(k_index, dim3(nB), dim3(64), 0, s, d_levels.p, nlevels, sel, sel_frame_entries, sel_cnt,
@@ -610,7 +641,9 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
     if (hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_parts_fork, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
+        hipEventCreateWithFlags(&e->ev_parts_fork, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->oct_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_oct_join, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
     if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
     for (int i = 0; i + 1 < e->split_parts; i++) {
         hipStream_t s = nullptr; hipEvent_t ev = nullptr;
@@ -630,6 +663,8 @@ void orbx_destroy(orbx_extractor* e)
     (void)hipSetDevice(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    if (e->oct_stream) { (void)hipStreamSynchronize(e->oct_stream); (void)hipStreamDestroy(e->oct_stream); }
+    if (e->ev_oct_join) (void)hipEventDestroy(e->ev_oct_join);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (hipStream_t s : e->aux_streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }

@@ -156,12 +156,12 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
                                                int pool, int lds_keys_cap,
                                                uint32_t* __restrict__ sel, int sel_frame_stride,
                                                int* __restrict__ sel_count, int n_levels, int* __restrict__ status,
-                                               uint8_t* __restrict__ node_scratch, size_t node_stride)
+                                               uint8_t* __restrict__ node_scratch, size_t node_stride, int level_first)
 {
     static_assert(LDS_NODES || !LDS_KEYS, "a pool too large for LDS leaves no room for LDS keys");
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_sort_stack[3 * kIntrosortStack];       // the sort's explicit stack (in LDS, not in private scratch)
-    const int level = blockIdx.x, frame = blockIdx.y;
+    const int level = level_first + blockIdx.x, frame = blockIdx.y;     // (a launch covers the levels level_first ..: see enqueue())
     const int lane = threadIdx.x;
     const LevelDesc L = levels[level];
     const int N = L.nfeat;
@@ -417,39 +417,50 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
             const unsigned long long hit = __ballot(act && size + incl_g >= N);     // `if ((int)lNodes.size() >= N) break;` after this divide
             if (hit != 0ull) { reached = true; keep = act && lane <= __builtin_ctzll(hit); }
         }
-        const int ne = keep ? (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0) : 0;
-        const int nx = keep ? (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1) : 0;
-        const int incl_e = wave_incl_scan(ne), incl_x = wave_incl_scan(nx), incl_a = wave_incl_scan(keep ? 1 : 0);
-        const int tot_e = __builtin_amdgcn_readlane(incl_e, 63), tot_x = __builtin_amdgcn_readlane(incl_x, 63), tot_a = __builtin_amdgcn_readlane(incl_a, 63);
-        if (nfree < tot_e || np + tot_e > plog_cap || n_ex + tot_x > pool) { overflow = true; return true; }
-        if (keep) {
-            int slot = np + incl_e - ne, fl = nfree - 1 - (incl_e - ne), xs = n_ex + incl_x - nx, cb = beg;
+        // The children take their node slots before the parents return theirs.  Normally the free list holds enough for the whole
+        // batch; when it does not (the pool is only N + 16 nodes, as for the sequential loop), the batch goes in rounds: the longest
+        // prefix of the remaining lanes whose children fit.
+        for (unsigned long long rem = __ballot(keep); rem != 0ull;) {
+            const bool in = (rem >> lane) & 1ull;
+            const int ne = in ? (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0) : 0;
+            const int nx = in ? (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1) : 0;
+            const int incl_e = wave_incl_scan(ne), incl_x = wave_incl_scan(nx), incl_a = wave_incl_scan(in ? 1 : 0);
+            const bool take = in && incl_e <= nfree;
+            const unsigned long long m_take = __ballot(take);
+            if (m_take == 0ull) { overflow = true; return true; }
+            const int last = 63 - __builtin_clzll(m_take);
+            const int tot_e = __builtin_amdgcn_readlane(incl_e, last), tot_x = __builtin_amdgcn_readlane(incl_x, last), tot_a = __builtin_amdgcn_readlane(incl_a, last);
+            if (np + tot_e > plog_cap || n_ex + tot_x > pool) { overflow = true; return true; }
+            if (take) {
+                int slot = np + incl_e - ne, fl = nfree - 1 - (incl_e - ne), xs = n_ex + incl_x - nx, cb = beg;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int cn = (c == 0) ? c0 : (c == 1) ? c1 : (c == 2) ? c2 : c3;
-                if (cn > 0) {
-                    const int ch = S.freelist[fl--];
-                    const int ux = (c & 1) ? midx : ulx, uy = (c & 2) ? midy : uly;
-                    S.ulx[ch] = (short)ux; S.uly[ch] = (short)uy;
-                    S.brx[ch] = (short)((c & 1) ? brx : midx); S.bry[ch] = (short)((c & 2) ? bry : midy);
-                    S.beg[ch] = cb; S.cnt[ch] = cn;
-                    S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn == 1 ? 1 : 0));
-                    S.plog[slot] = (short)ch; S.pidx[ch] = slot; slot++;            // push_front, children n1..n4 in order
-                    if (cn > 1) { SortNode sn; sn.count = cn; sn.ulx = ux; sn.node = ch; ex_new[xs++] = sn; }
-                    cb += cn;
+                for (int c = 0; c < 4; c++) {
+                    const int cn = (c == 0) ? c0 : (c == 1) ? c1 : (c == 2) ? c2 : c3;
+                    if (cn > 0) {
+                        const int ch = S.freelist[fl--];
+                        const int ux = (c & 1) ? midx : ulx, uy = (c & 2) ? midy : uly;
+                        S.ulx[ch] = (short)ux; S.uly[ch] = (short)uy;
+                        S.brx[ch] = (short)((c & 1) ? brx : midx); S.bry[ch] = (short)((c & 2) ? bry : midy);
+                        S.beg[ch] = cb; S.cnt[ch] = cn;
+                        S.flg[ch] = (uint8_t)(((src ^ 1) << 1) | (cn == 1 ? 1 : 0));
+                        S.plog[slot] = (short)ch; S.pidx[ch] = slot; slot++;            // push_front, children n1..n4 in order
+                        if (cn > 1) { SortNode sn; sn.count = cn; sn.ulx = ux; sn.node = ch; ex_new[xs++] = sn; }
+                        cb += cn;
+                    }
                 }
+                S.plog[S.pidx[id]] = -1;        // erase the parent
             }
-            S.plog[S.pidx[id]] = -1;        // erase the parent
-        }
-        __syncthreads();                    // the free-list reads above come before the writes below
-        np += tot_e; size += tot_e - tot_a; nfree -= tot_e;
-        if (keep) S.freelist[nfree + incl_a - 1] = (short)id;
-        nfree += tot_a;
-        n_to_expand += tot_x; n_ex += tot_x;
+            __syncthreads();                    // the free-list reads above come before the writes below
+            np += tot_e; size += tot_e - tot_a; nfree -= tot_e;
+            if (take) S.freelist[nfree + incl_a - 1] = (short)id;
+            nfree += tot_a;
+            n_to_expand += tot_x; n_ex += tot_x;
 #ifdef ORBX_OCT_TIMING
-        n_div += tot_a;
+            n_div += tot_a;
 #endif
-        __syncthreads();        // key scatter and node records visible before the next batch reads them
+            rem &= ~m_take;
+            __syncthreads();        // key scatter and node records visible before the next round / batch reads them
+        }
         ORBX_OTICK(3)
         return reached;
     };
