@@ -504,20 +504,21 @@ __device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, doubl
             const double P00 = sv.col[p][0][j0], P10 = sv.col[p][0][j0 + 1], P20 = sv.col[p][0][j0 + 2], P30 = sv.col[p][0][j0 + 3];
             const double P11 = sv.col[p][1][j0 + 1], P21 = sv.col[p][1][j0 + 2], P31 = sv.col[p][1][j0 + 3];
             const double P22 = sv.col[p][2][j0 + 2], P32 = sv.col[p][2][j0 + 3], P33 = sv.col[p][3][j0 + 3];
-            if (!(P00 > 0.0) || !isfinite(P00)) { failed = true; break; }          // uniform: same values in every thread
+            bool ok = (P00 > 0.0) && isfinite(P00);                                 // (checked once per group: one uniform branch, not four)
             const double i0 = rsqrt_newton(P00);
             const double l10 = P10 * i0, l20 = P20 * i0, l30 = P30 * i0;
             const double d1 = fma(-l10, l10, P11);
-            if (!(d1 > 0.0) || !isfinite(d1)) { failed = true; break; }
+            ok = ok && (d1 > 0.0) && isfinite(d1);
             const double i1 = rsqrt_newton(d1);
             const double l21 = fma(-l20, l10, P21) * i1, l31 = fma(-l30, l10, P31) * i1;
             const double d2 = fma(-l21, l21, fma(-l20, l20, P22));
-            if (!(d2 > 0.0) || !isfinite(d2)) { failed = true; break; }
+            ok = ok && (d2 > 0.0) && isfinite(d2);
             const double i2 = rsqrt_newton(d2);
             const double l32 = fma(-l31, l21, fma(-l30, l20, P32)) * i2;
             const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, P33)));
-            if (!(d3 > 0.0) || !isfinite(d3)) { failed = true; break; }
+            ok = ok && (d3 > 0.0) && isfinite(d3);
             const double i3 = rsqrt_newton(d3);
+            if (!ok) { failed = true; break; }          // uniform: same values in every thread
             // M = Lp^-1 (lower triangular); this lane needs row lk of it
             const double M10 = -(l10 * i0) * i1;
             const double M20 = -fma(l21, M10, l20 * i0) * i2, M21 = -(l21 * i1) * i2;
@@ -570,7 +571,11 @@ __device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, doubl
 
 // (Measured, round 2, per 60-column block: register-tile VALU updates with 16 x 16 threads 19.4 us; the same with 32 x 32 threads
 // and 2 x 2 tiles 26.1 us; this MFMA form 18.7 us.  The step is bound by its dependent chain -- barrier, pivot loads, four pivots
-// of rsqrt + two Newton steps at ~15 clocks per dependent v_fma_f64 (tools/probes/f64_rates.hip) -- not by f64 issue.)
+// of rsqrt + two Newton steps at ~15 clocks per dependent v_fma_f64 (tools/probes/f64_rates.hip) -- not by f64 issue.
+// EIGHT columns per barrier (8 x 8 pivot block and its inverse replicated in every thread, two MFMA k-steps per update) was built
+// and is bit-compatible, but slower: 29 us per block against 22 -- the replicated pivot algebra grows with the cube of the group
+// width and outweighs the publish / barrier / operand rounds it saves.  Per 4-column group (tools/lba_step_timing.py): operands +
+// MFMA 1400-1700 cycles, pivot block + M 1000-1300, publish 475, barrier 290.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
                                                    double* __restrict__ Linv, double* __restrict__ scal)
 {

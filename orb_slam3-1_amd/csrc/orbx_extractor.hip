@@ -511,12 +511,6 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), nB), dim3(256), 0, bs, lvl0, pyr, in_place ? pyr : nullptr, blr, pyr_frame_bytes,
                                d_levels.p, d_tiles.p, (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
         };
-        if (blur_s) {
-            ORBX_HIP(hipEventRecord(ev_fork, s));
-            ORBX_HIP(hipStreamWaitEvent(blur_s, ev_fork, 0));
-            launch_blur(blur_s);
-            ORBX_HIP(hipEventRecord(ev_join, blur_s));
-        }
         // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
         // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
         // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
@@ -530,6 +524,14 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         // (keys in LDS: one launch, the buffers are sized for the largest level anyway)
         const bool two_launches = !oct_nodes_hbm && o_keys == 0 && oct_split > 0 && oct_stream && blur_s;
         const int lv_lo = two_launches ? oct_split : nlevels;
+        // With a side stream the throughput-bound blur stays on the launch stream (it starts the moment FAST ends) and the
+        // latency-bound octree + index go beside it: octree of the lower levels and the index on `blur_s`, the upper levels'
+        // octree on `oct_stream`.  Without one (profiling) everything is serial on `s`.
+        hipStream_t os = blur_s ? blur_s : s;
+        if (blur_s) {
+            ORBX_HIP(hipEventRecord(ev_fork, s));
+            ORBX_HIP(hipStreamWaitEvent(blur_s, ev_fork, 0));
+        }
         if (two_launches) {
             ORBX_HIP(hipStreamWaitEvent(oct_stream, ev_fork, 0));
             hipLaunchKernelGGL(oct_kernel, dim3(nlevels - oct_split, nB), dim3(64), oct_lds_hi, oct_stream, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
@@ -537,18 +539,19 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                                sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0, (uint8_t*)nullptr, (size_t)0, oct_split);
             ORBX_HIP(hipEventRecord(ev_oct_join, oct_stream));
         }
-        hipLaunchKernelGGL(oct_kernel, dim3(lv_lo, nB), dim3(64), o_lds, s, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
+        hipLaunchKernelGGL(oct_kernel, dim3(lv_lo, nB), dim3(64), o_lds, os, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
                            cell_cnt, n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
                            sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0,
                            d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride, 0);
-        if (two_launches) ORBX_HIP(hipStreamWaitEvent(s, ev_oct_join, 0));
+        if (blur_s) launch_blur(s);
+        if (two_launches) ORBX_HIP(hipStreamWaitEvent(os, ev_oct_join, 0));
         ORBX_LAUNCHED("k_octree / k_blur");
         if (marks) mark();
-        hipLaunchKernelGGL(k_index, dim3(nB), dim3(64), 0, s, d_levels.p, nlevels, sel, sel_frame_entries, sel_cnt,
+        hipLaunchKernelGGL(k_index, dim3(nB), dim3(64), 0, os, d_levels.p, nlevels, sel, sel_frame_entries, sel_cnt,
                            lap0, lap1, cap, kp_dst, sel_frame_entries, o_n + f0, o_mono + f0, o_status + f0);
         ORBX_LAUNCHED("k_index");
         if (marks) mark();
-        if (blur_s) ORBX_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        if (blur_s) { ORBX_HIP(hipEventRecord(ev_join, blur_s)); ORBX_HIP(hipStreamWaitEvent(s, ev_join, 0)); }
         else launch_blur(s);
         if (marks) mark();
         hipLaunchKernelGGL(k_orient_desc, dim3((unsigned)(((long long)quads * nB + 7) / 8 * 8)), dim3(256), 0, s, pyr, blr, pyr_frame_bytes,
