@@ -154,6 +154,7 @@ struct orbx_extractor {
     size_t oct_lds_hi = 0;
     // streams for the ranges a large batch is cut into (enqueue)
     int split_parts = 1;                 // ORBX_SPLIT (measurement knob, see enqueue)
+    int resize_tail_first = 4;           // first pyramid level of the fused resize tail (ORBX_RESIZE_TAIL; 0: a launch per level)
     std::vector<hipStream_t> aux_streams;
     hipEvent_t ev_parts_fork = nullptr;
     std::vector<hipEvent_t> ev_parts_join;
@@ -488,7 +489,9 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             ORBX_LAUNCHED("k_copy_level0");
         }
         if (marks) mark();
-        for (int l = 1; l < nlevels; l++) {
+        // (resize_tail_first: the levels from there on are one launch, a workgroup per frame -- k_resize_tail)
+        const int l_tail = (resize_tail_first >= 2 && resize_tail_first < nlevels) ? resize_tail_first : nlevels;
+        for (int l = 1; l < l_tail; l++) {
             const LevelDesc& D = levels[l];
             dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + kResizeRows - 1) / kResizeRows)), nB);
             const LevelDesc& P = levels[l - 1];
@@ -498,6 +501,13 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             hipLaunchKernelGGL(k_resize, g, dim3(256), 0, s, src, pyr, pyr_frame_bytes, D,
                                d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
             ORBX_LAUNCHED("k_resize");
+        }
+        if (l_tail < nlevels) {
+            ResizeTables T;
+            std::memset(&T, 0, sizeof(T));
+            for (int l = l_tail; l < nlevels; l++) { T.q_sx0[l] = d_qsx0[l].p; T.q_sel[l] = d_qsel[l].p; T.q_alpha[l] = d_qalpha[l].p; T.yofs[l] = d_yofs[l].p; T.ibeta[l] = d_ibeta[l].p; }
+            hipLaunchKernelGGL(k_resize_tail, dim3(nB), dim3(1024), 0, s, pyr, pyr_frame_bytes, d_levels.p, T, l_tail, nlevels);
+            ORBX_LAUNCHED("k_resize_tail");
         }
         if (marks) mark();
         uint32_t* cand = d_cand.p + (size_t)f0 * cand_frame_entries;
@@ -648,6 +658,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
         hipStreamCreateWithFlags(&e->oct_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_oct_join, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
     if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
+    if (const char* env = getenv("ORBX_RESIZE_TAIL")) e->resize_tail_first = atoi(env);
     for (int i = 0; i + 1 < e->split_parts; i++) {
         hipStream_t s = nullptr; hipEvent_t ev = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
@@ -977,6 +988,15 @@ int orbx_stereo_matches(orbx_extractor* left, orbx_extractor* right, int frame,
 float orbx_debug_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 void orbx_debug_sincos(float a, float* c, float* s) { sincos_f32(a, c, s); }
 
+#ifdef ORBX_FAST_TIMING
+int orbx_debug_fast_prof(unsigned long long* out16)
+{
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(d_fast_prof), sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_fast_prof), z, sizeof(z)) != hipSuccess) return ORBX_ERR_HIP;
+    return ORBX_OK;
+}
+#endif
 #ifdef ORBX_OCT_TIMING
 int orbx_debug_oct_prof(unsigned long long* out10)
 {

@@ -48,19 +48,15 @@ struct SrcImage {
 struct __attribute__((aligned(4))) Dwords3 { uint32_t x, y, z; };     // 12 bytes at dword alignment: one global_load_dwordx3
 constexpr int kResizeRows = 32;      // output rows per workgroup (8 per wave): few, fat workgroups -- the dispatcher starts only ~2 workgroups per ns
 
-__global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc dst,
-                                                const int* __restrict__ q_sx0, const uint4* __restrict__ q_sel, const uint4* __restrict__ q_alpha,
-                                                const int* __restrict__ yofs, const short* __restrict__ ibeta)
+// one tile of 256 x 32 outputs of level `dst` of frame `frame` by 4 waves (`wave` 0..3, 8 rows each)
+__device__ __forceinline__ void resize_tile(const SrcImage& src, uint8_t* __restrict__ pyr, size_t frame_stride, const LevelDesc& dst,
+                                            const int* __restrict__ q_sx0, const uint4* __restrict__ q_sel, const uint4* __restrict__ q_alpha,
+                                            const int* __restrict__ yofs, const short* __restrict__ ibeta, int tile, int frame, int lane, int wave)
 {
-    // tiles of 256 x 32 outputs are numbered row-major and handed to the XCDs in contiguous bands (xcd_remap), so the source
-    // rows a band of destination rows needs are fetched by one L2 only
-    const int tiles_x = (dst.w + 255) >> 8, tiles_y = (dst.h + kResizeRows - 1) / kResizeRows;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x, blockIdx.y);
-    if (tile >= tiles_x * tiles_y) return;
+    const int tiles_x = (dst.w + 255) >> 8;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int q = tx * 64 + (threadIdx.x & 63);
+    const int q = tx * 64 + lane;
     if (4 * q >= dst.w) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sx0 = q_sx0[q];
     const uint4 sel = q_sel[q], al = q_alpha[q];
     const uint32_t sels[4] = {sel.x, sel.y, sel.z, sel.w}, als[4] = {al.x, al.y, al.z, al.w};
@@ -68,8 +64,8 @@ __global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restric
     const uint32_t sh = (uint32_t)(sx0 & 3);
     const int last = src.stride - 4;                            // last dword of a row: bytes past the row's pixels only meet coefficient 0
     const int o0 = a, o1 = min(a + 4, last), o2 = min(a + 8, last);
-    const uint8_t* S = src.base + (size_t)blockIdx.y * src.frame_stride;
-    uint8_t* D = pyr + (size_t)blockIdx.y * frame_stride + dst.off + 4 * q;
+    const uint8_t* S = src.base + (size_t)frame * src.frame_stride;
+    uint8_t* D = pyr + (size_t)frame * frame_stride + dst.off + 4 * q;
     const int dy0 = ty * kResizeRows + wave * (kResizeRows / 4);
     constexpr int NR = kResizeRows / 4;
     // all the loads of the wave's rows are issued before the first result is stored (the compiler cannot move a load above a
@@ -111,6 +107,43 @@ __global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restric
         }
         // columns past dst.w: coefficients 0 -> 0; the row padding absorbs the tail of the last dword
         *(uint32_t*)(D + (size_t)dy * dst.stride) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc dst,
+                                                const int* __restrict__ q_sx0, const uint4* __restrict__ q_sel, const uint4* __restrict__ q_alpha,
+                                                const int* __restrict__ yofs, const short* __restrict__ ibeta)
+{
+    // tiles of 256 x 32 outputs are numbered row-major and handed to the XCDs in contiguous bands (xcd_remap), so the source
+    // rows a band of destination rows needs are fetched by one L2 only
+    const int tiles_x = (dst.w + 255) >> 8, tiles_y = (dst.h + kResizeRows - 1) / kResizeRows;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x, blockIdx.y);
+    if (tile >= tiles_x * tiles_y) return;
+    resize_tile(src, pyr, frame_stride, dst, q_sx0, q_sel, q_alpha, yofs, ibeta, tile, blockIdx.y, threadIdx.x & 63,
+                __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
+// The upper pyramid levels are small and each depends on the one below: as launches of their own they are a chain of short,
+// launch-latency-bound kernels.  Here ONE 1024-thread workgroup per frame walks the levels l_first .. n_levels-1 in turn (four
+// tiles at a time, a workgroup barrier between levels: the level just written is read back by the same CU).
+struct ResizeTables {
+    const int* q_sx0[kMaxLevels]; const uint4* q_sel[kMaxLevels]; const uint4* q_alpha[kMaxLevels];
+    const int* yofs[kMaxLevels]; const short* ibeta[kMaxLevels];
+};
+__global__ __launch_bounds__(1024) void k_resize_tail(uint8_t* __restrict__ pyr, size_t frame_stride, const LevelDesc* __restrict__ levels,
+                                                      ResizeTables T, int l_first, int n_levels)
+{
+    const int frame = blockIdx.x;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+    const int lane = threadIdx.x & 63;
+    for (int l = l_first; l < n_levels; l++) {
+        const LevelDesc D = levels[l], P = levels[l - 1];
+        SrcImage src;
+        src.base = pyr + P.off; src.frame_stride = frame_stride; src.stride = P.stride; src.w = P.w; src.h = P.h;
+        const int tiles = ((D.w + 255) >> 8) * ((D.h + kResizeRows - 1) / kResizeRows);
+        for (int t = sub; t < tiles; t += 4)
+            resize_tile(src, pyr, frame_stride, D, T.q_sx0[l], T.q_sel[l], T.q_alpha[l], T.yofs[l], T.ibeta[l], t, frame, lane, wave);
+        __syncthreads();            // the level is complete (and visible to this CU) before it becomes the next one's source
     }
 }
 
