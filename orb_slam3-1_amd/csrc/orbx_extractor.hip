@@ -490,7 +490,8 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         }
         if (marks) mark();
         // (resize_tail_first: the levels from there on are one launch, a workgroup per frame -- k_resize_tail)
-        const int l_tail = (resize_tail_first >= 2 && resize_tail_first < nlevels) ? resize_tail_first : nlevels;
+        // (only with many frames: a single workgroup walks a small batch's levels slower than one wide launch per level does)
+        const int l_tail = (nB >= 64 && resize_tail_first >= 2 && resize_tail_first < nlevels) ? resize_tail_first : nlevels;
         for (int l = 1; l < l_tail; l++) {
             const LevelDesc& D = levels[l];
             dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + kResizeRows - 1) / kResizeRows)), nB);
@@ -580,7 +581,8 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     if (!profile && split_parts > 1 && B >= 32 * split_parts) parts = std::min(split_parts, 1 + (int)aux_streams.size());
     int r;
     if (parts == 1) {
-        if ((r = run_range(0, B, st, (!profile && side_stream) ? side_stream : nullptr, true))) return r;
+        // (small batches: the blur is a few microseconds, less than the fork / join across streams costs)
+        if ((r = run_range(0, B, st, (!profile && side_stream && B >= 32) ? side_stream : nullptr, true))) return r;
     } else {
         ORBX_HIP(hipEventRecord(ev_parts_fork, st));
         for (int p = 0; p < parts; p++) {

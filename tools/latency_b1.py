@@ -12,7 +12,7 @@ pkg = importlib.import_module("orb_slam3-1_amd")
 synth = importlib.import_module("orb_slam3-1_amd.synth")
 dev = torch.device("cuda", 0)
 host = synth.make_frames(8, seed0=0)
-for B in (1, 4, 16, 64):
+for B in (64, 1, 4, 16, 1):       # (the first configuration also brings the clocks up: a cold GPU runs the latency-bound stages at half speed)
     imgs = np.concatenate([host] * ((B + 7) // 8))[:B]
     d = torch.from_numpy(imgs.copy()).to(dev)
     ex = pkg.Extractor()
