@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) of
-`bench.py --no-cpu --no-lba` into profiles/pmc_traffic.json: HBM bytes per launch of every extractor kernel.
+`bench.py --no-cpu --no-lba` into profiles/pmc_traffic.json: HBM bytes per step (= per launch, summed over the launches of kernels that run more than once per step) of every extractor kernel.
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports exactly 1/2 of the bytes of a wide coalesced read (factor 2), WRITE_SIZE reads the bytes exactly for wide stores.
@@ -49,9 +49,15 @@ def main():
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         out["_raw_kib"][k] = {"FETCH_SIZE": f, "WRITE_SIZE": w, "dispatches": nf.get(k, 0)}
         out[k[2:]] = f * 1024.0 * cal_f + w * 1024.0 * cal_w
-    # k_resize is launched once per level: report the sum over the 7 levels as one "resize" stage
-    if "resize" in out:
-        out["resize"] = out["resize"] * 7
+    # kernels launched several times per step (k_resize once per lower level, k_octree twice): report bytes per STEP
+    steps = max(nf.get("k_fast_strips", 1), 1)
+    for k in list(out):
+        if k.startswith("_"):
+            continue
+        per_step = nf.get("k_" + k, steps) / float(steps)
+        if per_step > 1.01:
+            out[k] = out[k] * per_step
+            out["_raw_kib"]["k_" + k]["launches_per_step"] = per_step
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -9,6 +9,7 @@ timeout -k 10 420 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out: stopping"; exit 1; fi
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
+cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_prof.json 2> $OUT/bench_prof.err || { echo "rocprof stats failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu --no-lba > /dev/null 2> $OUT/pmc_fetch.err || { echo "pmc fetch failed"; exit 1; }
@@ -19,7 +20,9 @@ timeout -k 10 200 python bench.py --streams 4 --no-cpu --no-lba > $OUT/bench_str
 # per-kernel times of the two BA solvers alone (profiles/<tag>_lba_kernel_stats.csv, <tag>_inertial_ba_kernel_stats.csv)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lbaprof -- python tools/lba_prof.py 5 > $OUT/lbaprof.log 2>&1 || echo "lba profile failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/libaprof -- python tools/liba_prof.py 5 > $OUT/libaprof.log 2>&1 || echo "inertial ba profile failed"
-cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
+# single-call latencies (what Tracking / LocalMapping make): extract for small batches, per-frame inertial optimisation, LocalInertialBA
+timeout -k 10 200 python tools/latency_b1.py > $OUT/latency_b1.log 2>&1 || echo "latency_b1 failed"
+timeout -k 10 200 python tools/pi_latency.py > $OUT/pi_latency.log 2>&1 || echo "pi_latency failed"
 bash tools/pmc_lba.sh $TAG/lba_pmc > $OUT/lba_pmc.log 2>&1 || echo "lba mfma counter pass failed"
 python - <<PY
 import json
@@ -31,4 +34,9 @@ print("lba iters/s %.0f  x%.1f vs cpu  ms/iteration %.3f ms/trial %.3f  roofline
 t = json.load(open("$OUT/pmc_traffic.json"))
 print("traffic MB/launch", {k: round(v / 1e6, 1) for k, v in t.items() if not k.startswith("_")})
 print("line length", len(open("$OUT/bench.json").read()))
+for f in ("latency_b1.log", "pi_latency.log"):
+    try:
+        print("".join(l for l in open("$OUT/" + f) if ("ms per" in l or "liba_solve" in l)).rstrip())
+    except OSError:
+        pass
 PY
