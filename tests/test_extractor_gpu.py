@@ -210,3 +210,25 @@ def test_wave_sort_is_std_sort(pkg, oracle, n):
         oracle.lib.orb_oracle_sort_nodes(c1.ctypes.data, u1.ctypes.data, t1.ctypes.data, n)
         assert pkg.lib.orbx_debug_wave_sort(c2.ctypes.data, u2.ctypes.data, t2.ctypes.data, n) == 0
         np.testing.assert_array_equal(c2, c1); np.testing.assert_array_equal(u2, u1); np.testing.assert_array_equal(t2, t1)
+
+
+@pytest.mark.parametrize("B", [40, 72])
+def test_large_batch_launch_paths(pkg, oracle, synth, B):
+    """batches of >= 32 frames run the blur on the launch stream beside the octree -- whose upper levels are a launch of their
+    own with a smaller node pool -- and from 64 frames on the upper pyramid levels come from the fused resize tail: the same key
+    points and descriptors as the oracle, frame by frame"""
+    distinct = [synth.make_frame(900 + i) for i in range(6)]
+    oex = oracle.extractor(1000, 1.2, 8, 20, 7)
+    ref = [oex.extract(im, (0, 1000)) for im in distinct]
+    imgs = np.stack([distinct[i % 6] for i in range(B)])
+    ex = pkg.Extractor(1000, 1.2, 8, 20, 7)
+    try:
+        for rep in range(2):            # twice: the second call reuses every buffer and stream
+            mono, n, kps, desc = ex.extract_batch(imgs)
+            for b in range(B):
+                r0, k0, d0 = ref[b % 6]
+                assert mono[b] == r0 and n[b] == len(k0)
+                _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
+                np.testing.assert_array_equal(desc[b, :n[b]], d0)
+    finally:
+        ex.close()
