@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void k_lin_all(Dev d, const double* __restrict
 // host reads them by polling that word instead of a device-to-host copy plus a stream synchronisation per LM trial.
 __global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode, double* __restrict__ hmap, unsigned long long seq)
 {
-    __shared__ double s_a[1024], s_b[1024], s_c[1024];
+    // fixed tree: a strided partial per thread, a butterfly inside each wave, the 16 wave results by wave 0 -- one barrier instead
+    // of ten (the kernel is a single workgroup on the critical path of every Levenberg trial)
+    __shared__ double s_a[16], s_b[16], s_c[16];
     const int tid = threadIdx.x;
     double a = 0, b = 0, c = 0;
     for (int e = tid; e < d.nE; e += 1024) a += d.rho0[e];
@@ -314,15 +316,18 @@ __global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode, double* __rest
         for (int i = tid; i < d.nP; i += 1024) b += d.part[d.nL + i];
         for (int i = tid; i < d.nL; i += 1024) c += d.part[i];
     }
-    s_a[tid] = a; s_b[tid] = b; s_c[tid] = c;
+    auto combine = [&](int o, int width) {
+        const double a2 = __shfl_xor(a, o, width), b2 = __shfl_xor(b, o, width), c2 = __shfl_xor(c, o, width);
+        a += a2;
+        if (mode == 0) { b = fmax(b, b2); c = fmax(c, c2); } else { b += b2; c += c2; }
+    };
+    for (int o = 32; o > 0; o >>= 1) combine(o, 64);
+    if ((tid & 63) == 0) { s_a[tid >> 6] = a; s_b[tid >> 6] = b; s_c[tid >> 6] = c; }
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) {
-            s_a[tid] += s_a[tid + o];
-            if (mode == 0) { s_b[tid] = fmax(s_b[tid], s_b[tid + o]); s_c[tid] = fmax(s_c[tid], s_c[tid + o]); }
-            else { s_b[tid] += s_b[tid + o]; s_c[tid] += s_c[tid + o]; }
-        }
-        __syncthreads();
+    if (tid < 64) {
+        a = tid < 16 ? s_a[tid] : 0.0; b = tid < 16 ? s_b[tid] : 0.0; c = tid < 16 ? s_c[tid] : 0.0;
+        for (int o = 8; o > 0; o >>= 1) combine(o, 16);
+        if (tid == 0) { s_a[0] = a; s_b[0] = b; s_c[0] = c; }
     }
     if (tid == 0) {
         d.scal[0] = s_a[0];
