@@ -218,7 +218,7 @@ int orbx_extractor::setup_geometry(int w, int h)
         L.scale = scale[l];
         L.patch_size = (int)(kPatch * scale[l]);
         L.sel_off = sel_off; L.sel_cap = nfeat[l] + 3;
-        sel_off += L.sel_cap;
+        sel_off += (L.sel_cap + 1) & ~1;        // even: the two key points of a wave of k_orient_desc share a level
         max_nfeat = std::max(max_nfeat, nfeat[l]);
         // FAST cells (ComputeKeyPointsOctTree :787-822)
         L.cell_begin = (int)cells.size();
@@ -471,7 +471,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     // copied first (k_copy_level0), as it is when the host-pointer entry points have uploaded it into the pyramid themselves.
     const bool in_place = !level0_ready && ((uintptr_t)d_imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
     const int n_cells = (int)cells.size();
-    const int quads = (sel_frame_entries + 3) / 4;
+    const int quads = (sel_frame_entries + 7) / 8;       // workgroups of k_orient_desc per frame: 8 key points each (two per wave)
 
     // One range of frames [f0, f0 + nB) through the whole pipeline on stream `s`; the blur either on `blur_s` beside the octree
     // (a single range: the octree is one wave per frame and level and leaves most of the chip idle) or on `s` itself.

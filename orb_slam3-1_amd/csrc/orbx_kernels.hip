@@ -46,6 +46,7 @@ struct SrcImage {
 };
 
 struct __attribute__((aligned(4))) Dwords3 { uint32_t x, y, z; };     // 12 bytes at dword alignment: one global_load_dwordx3
+struct __attribute__((aligned(4))) Dwords4 { uint32_t x, y, z, w; };  // 16 bytes at dword alignment: one global_load_dwordx4
 constexpr int kResizeRows = 32;      // output rows per workgroup (8 per wave): few, fat workgroups -- the dispatcher starts only ~2 workgroups per ns
 
 // one tile of 256 x 32 outputs of level `dst` of frame `frame` by 4 waves (`wave` 0..3, 8 rows each)
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(256) void k_blur(SrcImage lvl0, const uint8_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// E5 + E7 + E8: one wave per keypoint.  IC_Angle on the unblurred level, steered BRIEF on the blurred
+// E5 + E7 + E8: half a wave per keypoint.  IC_Angle on the unblurred level, steered BRIEF on the blurred
 // level, then the cv::KeyPoint record and the 32-byte descriptor are written to their output row.
 // ------------------------------------------------------------------------------------------------
 // mask of the radius-15 disc (umax, :453-468) per patch row, as byte masks of the 8 dwords that hold columns u = -15 .. 16
@@ -772,100 +773,110 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
                                                      OrbxKeyPoint* __restrict__ lvl_kps /* optional: per-level keypoints, level coords */,
                                                      int quads_per_frame, int batch)
 {
-    // Both patches a keypoint needs -- the 31x31 disc of the unblurred level (IC_Angle) and the 37x37 window of the blurred
-    // level that the rotated pattern can reach (|coordinate| <= 18 < EDGE_THRESHOLD) -- are fetched up front as aligned 16-byte
-    // chunks into a wave-private LDS window (the address unit takes 16 clocks per wave-wide load whatever its width: 5 wide
-    // loads per lane instead of 11 dword loads), so a wave sees two dependent memory round trips (selection record, patches).
-    constexpr int kBR = 18, kBP = 64, kPR = 15, kPP = 48;       // blur: 37 rows x 4 chunks; pyr: 31 rows x 3 chunks
-    constexpr int kBBytes = (2 * kBR + 1) * kBP, kPBytes = (2 * kPR + 1) * kPP;
-    __shared__ __align__(16) uint8_t s_patch[4][kBBytes + kPBytes];
-    // 1-D grid of quads_per_frame * batch workgroups.  Workgroup w runs on XCD w % 8: giving XCD k the contiguous range
-    // [k * total / 8, (k + 1) * total / 8) of (frame, quad) pairs keeps all the patches of a frame in ONE L2 (2.4 MB of
-    // pyramid + blur per frame against 4 MB of L2) instead of fetching every frame into all eight.
+    // TWO keypoints per wave, one per half: the intensity-centroid rows (31 lanes each), the angle, its sine and cosine and
+    // the bookkeeping are the same instructions for both halves, and a lane steers 8 of its keypoint's 256 pairs instead of 4 --
+    // a third fewer wave instructions per keypoint than one keypoint per wave.
+    // Everything a keypoint needs -- the 31x31 disc of the unblurred level (IC_Angle) and the 37x37 window of the blurred level
+    // that the rotated pattern can reach (|coordinate| <= 18 < EDGE_THRESHOLD) -- is fetched up front with wide loads (the address
+    // unit takes 16 clocks per wave-wide load whatever its width), so a wave sees two dependent memory round trips (selection
+    // record, patches).
+    constexpr int kBR = 18, kBP = 64, kPR = 15;                 // blur: 37 rows x 4 chunks
+    constexpr int kBBytes = (2 * kBR + 1) * kBP;
+    __shared__ __align__(16) uint8_t s_patch[8][kBBytes];
+    // 1-D grid of octets_per_frame * batch workgroups (8 keypoints each).  Workgroup w runs on XCD w % 8: giving XCD k the
+    // contiguous range [k * total / 8, (k + 1) * total / 8) of (frame, octet) pairs keeps all the patches of a frame in ONE L2
+    // (2.4 MB of pyramid + blur per frame against 4 MB of L2) instead of fetching every frame into all eight.
     const int total_wg = gridDim.x, per_xcd = total_wg >> 3;            // the host pads the grid to a multiple of 8
     const int v_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     const int frame = v_id / quads_per_frame, quad = v_id - frame * quads_per_frame;
     if (frame >= batch) return;                                         // grid padding (uniform for the workgroup)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // the selection slots of all levels are one flat range [0, sel_frame_stride): a wave takes slot s and finds its level
-    // from the level offsets (scalar loads), so no workgroup is launched for slots a level does not have
-    const int s_flat = quad * 4 + wave;
+    const int half = lane >> 5, hl = lane & 31;
+    // the selection slots of all levels are one flat range [0, sel_frame_stride): a half-wave takes slot s and finds its level
+    // from the level offsets, so no workgroup is launched for slots a level does not have
+    // (the levels' slot ranges start at even offsets, so both halves of a wave are in the same level: scalar table loads)
+    const int s_pair = quad * 8 + wave * 2, s_flat = s_pair + half;
     int level = 0;
-    for (int l = 1; l < n_levels; l++) level = (s_flat >= levels[l].sel_off) ? l : level;
+    for (int l = 1; l < n_levels; l++) level = (s_pair >= levels[l].sel_off) ? l : level;
     const LevelDesc L = levels[level];
     const int k = s_flat - L.sel_off;
     const bool live = s_flat < sel_frame_stride && k < L.sel_cap && k < sel_count[(size_t)frame * n_levels + level];
     const int slot = L.sel_off + (live ? k : 0);
     const uint32_t e = live ? sel[(size_t)frame * sel_frame_stride + slot] : 0u;
     const int row = live ? kp_dst[(size_t)frame * kp_frame_stride + slot] : -1;
-    uint32_t pw[4];
+    uint32_t pw[8];
 #pragma unroll
-    for (int q = 0; q < 4; q++) pw[q] = ((const uint32_t*)d_pattern)[lane + 64 * q];       // one dword = (x0, y0, x1, y1) as int8
+    for (int q = 0; q < 8; q++) pw[q] = ((const uint32_t*)d_pattern)[hl + 32 * q];       // one dword = (x0, y0, x1, y1) as int8
     const int px = (int)key_x(e) + 16, py = (int)key_y(e) + 16;     // level coordinates (:885-886)
-    uint8_t* sb = s_patch[wave];
-    uint8_t* sp = sb + kBBytes;
-    const int xb = (px - kBR) & ~15, xp = (px - kPR) & ~15;         // 16-byte aligned window starts (rows are 64-B aligned)
+    uint8_t* sb = s_patch[wave * 2 + half];
+    const int xb = (px - kBR) & ~15;                                // 16-byte aligned window start (rows are 64-B aligned)
+    // The time of this kernel is the number of keypoints a CU holds in flight over their two memory round trips (measured: it
+    // scales with the LDS a workgroup is given), so LDS only holds what is addressed at random -- the blurred window.  The
+    // intensity-centroid rows go straight into the registers of the lanes that own them: row r of the 31 x 31 patch = the 9 dwords
+    // from the dword that holds column u = -15 on (dword-aligned wide loads).
+    uint32_t icw[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) icw[j] = 0u;
     if (live) {
         const uint8_t* bbase = blur + (size_t)frame * frame_stride + L.off + (size_t)(py - kBR) * L.stride + xb;
-        const uint8_t* pbase = pyr + (size_t)frame * frame_stride + L.off + (size_t)(py - kPR) * L.stride + xp;
-        for (int i = lane; i < (2 * kBR + 1) * 4; i += 64) {
+        for (int i = hl; i < (2 * kBR + 1) * 4; i += 32) {
             const int r = i >> 2, c = i & 3;
             *(uint4*)(sb + r * kBP + 16 * c) = *(const uint4*)(bbase + (size_t)r * L.stride + 16 * c);
         }
-        for (int i = lane; i < (2 * kPR + 1) * 3; i += 64) {
-            const int r = (i * 43) >> 7, c = i - 3 * r;              // i / 3 for i < 128
-            *(uint4*)(sp + r * kPP + 16 * c) = *(const uint4*)(pbase + (size_t)r * L.stride + 16 * c);
+        if (hl < 2 * kPR + 1) {
+            const uint8_t* rp = pyr + (size_t)frame * frame_stride + L.off + (size_t)(py - kPR + hl) * L.stride + ((px - kPR) & ~3);
+            const Dwords4 q0 = *(const Dwords4*)rp, q1 = *(const Dwords4*)(rp + 16);
+            icw[0] = q0.x; icw[1] = q0.y; icw[2] = q0.z; icw[3] = q0.w; icw[4] = q1.x; icw[5] = q1.y; icw[6] = q1.z; icw[7] = q1.w;
+            icw[8] = *(const uint32_t*)(rp + 32);
         }
     }
-    // the LDS window is private to the wave: its own writes are ordered before its own reads by the LDS queue; only the
+    // the LDS window is private to the (half-)wave: its own writes are ordered before its own reads by the LDS queue; only the
     // compiler has to be kept from reordering them -- no workgroup barrier, so a wave never waits for its three neighbours
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (!live) return;
+    if (__ballot(live) == 0ull) return;
 
-    // ---- IC_Angle (:76-103): lane r < 31 owns patch row v = r - 15: its 31 bytes as 8 byte-aligned dwords, masked to the disc;
-    // the row sums  a = sum I  and  b = sum (u + 15) I  are byte dot products, m10 += b - 15 a, m01 += v a ----
+    // ---- IC_Angle (:76-103): lane r < 31 of a half owns patch row v = r - 15: its 31 bytes as 8 byte-aligned dwords, masked to
+    // the disc; the row sums  a = sum I  and  b = sum (u + 15) I  are byte dot products, m10 += b - 15 a, m01 += v a ----
     int m10 = 0, m01 = 0;
-    if (lane < 2 * kPR + 1) {
-        const int c0 = px - kPR - xp;                                 // byte of column u = -15 inside the window row (wave-uniform)
-        const uint32_t* rw = (const uint32_t*)(sp + lane * kPP + (c0 & ~3));
-        const uint32_t sh = (uint32_t)(c0 & 3);
-        uint32_t w[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) w[j] = rw[j];
-        const uint4 ma = *(const uint4*)&d_ic_mask.m[lane][0], mb = *(const uint4*)&d_ic_mask.m[lane][4];
+    if (live && hl < 2 * kPR + 1) {
+        const uint32_t sh = (uint32_t)((px - kPR) & 3);
+        const uint4 ma = *(const uint4*)&d_ic_mask.m[hl][0], mb = *(const uint4*)&d_ic_mask.m[hl][4];
         const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
         uint32_t a = 0u, b = 0u;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const uint32_t d = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh) & mk[j];
+            const uint32_t d = __builtin_amdgcn_alignbyte(icw[j + 1], icw[j], sh) & mk[j];
             a = __builtin_amdgcn_udot4(d, 0x01010101u, a, false);
             b = __builtin_amdgcn_udot4(d, 0x03020100u + 0x04040404u * (uint32_t)j, b, false);
         }
         m10 = (int)b - 15 * (int)a;
-        m01 = (lane - kPR) * (int)a;
+        m01 = (hl - kPR) * (int)a;
     }
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    for (int o = 16; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }     // (inside the half)
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- steered BRIEF: lane handles pairs lane, lane+64, lane+128, lane+192; ballot k = descriptor bytes 8k..8k+7
+    // ---- steered BRIEF: a lane handles the pairs hl, hl + 32, ..., hl + 224 of its keypoint; ballot q = the descriptor's 32-bit
+    // word q of the lower-half keypoint in its low half, of the upper-half keypoint in its high half
     const float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
     float a, b;
     sincos_f32(angle * factorPI, &a, &b);
     const uint8_t* bimg = sb + kBR * kBP + (px - xb);
-    unsigned long long w[4];
-    int t0s[4], t1s[4];
+    unsigned long long w[8];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 8; q++) {
         const float x0 = (float)(signed char)(pw[q] & 0xFF), y0 = (float)(signed char)((pw[q] >> 8) & 0xFF);
         const float x1 = (float)(signed char)((pw[q] >> 16) & 0xFF), y1 = (float)(signed char)(pw[q] >> 24);
-        t0s[q] = bimg[cv_round_f(x0 * b + y0 * a) * kBP + cv_round_f(x0 * a - y0 * b)];
-        t1s[q] = bimg[cv_round_f(x1 * b + y1 * a) * kBP + cv_round_f(x1 * a - y1 * b)];
+        int t0 = 0, t1 = 0;
+        if (live) {
+            t0 = bimg[cv_round_f(x0 * b + y0 * a) * kBP + cv_round_f(x0 * a - y0 * b)];
+            t1 = bimg[cv_round_f(x1 * b + y1 * a) * kBP + cv_round_f(x1 * a - y1 * b)];
+        }
+        w[q] = __ballot(t0 < t1);
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) w[q] = __ballot(t0s[q] < t1s[q]);
-    if (lane == 0) {
+    if (!live) return;
+    if (hl == 0) {
         OrbxKeyPoint kp;
         kp.x = (float)px; kp.y = (float)py;
         kp.size = (float)L.patch_size; kp.angle = angle; kp.response = (float)key_resp(e);
@@ -874,9 +885,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t* __restrict__
         if (level != 0) { kp.x = kp.x * L.scale; kp.y = kp.y * L.scale; }      // :1149-1151
         if (row >= 0 && row < cap) kps[(size_t)frame * cap + row] = kp;
     }
-    if (lane < 4 && row >= 0 && row < cap) {
-        const unsigned long long mine = lane == 0 ? w[0] : lane == 1 ? w[1] : lane == 2 ? w[2] : w[3];
-        ((unsigned long long*)(desc + ((size_t)frame * cap + row) * 32))[lane] = mine;
+    if (hl < 8 && row >= 0 && row < cap) {
+        unsigned long long mine = w[0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) mine = (hl == q) ? w[q] : mine;
+        ((uint32_t*)(desc + ((size_t)frame * cap + row) * 32))[hl] = (uint32_t)(mine >> (32 * half));
     }
 }
 
