@@ -675,13 +675,20 @@ __global__ __launch_bounds__(256) void k_blur(SrcImage lvl0, const uint8_t* __re
     for (int i = tid; i < SR * (SP / 16); i += 256) {
         const int r = i / (SP / 16), q = i - r * (SP / 16);
         const int sy = reflect101(y0 + r - 3, L.h), cx = x0 - 16 + 16 * q;
-        uint4 v;
-        if (cx >= 0 && cx + 16 <= L.w) v = *(const uint4*)(img + (size_t)sy * istride + cx);
-        else {
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            for (int b = 0; b < 16; b++) {
-                const int col = cx + b;
-                if (col >= x0 - 3 && col <= x0 + kBlurTW + 2) w[b >> 2] |= (uint32_t)img[(size_t)sy * istride + reflect101(col, L.w)] << (8 * (b & 3));
+        // A chunk that starts inside the row is one aligned load (its bytes past the last column are row padding: they only reach
+        // outputs that are not stored).  Only the three columns left of column 0 and the three right of column w - 1 can be read by
+        // stored outputs without being pixels: they are patched in with BORDER_REFLECT_101 (six byte tests per border chunk --
+        // a byte-by-byte assembly of such chunks cost more than the whole filter of an inner tile).
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const uint8_t* rowp = img + (size_t)sy * istride;
+        if (cx >= 0 && cx < L.w) v = *(const uint4*)(rowp + cx);
+        if (cx < 0 || cx + 16 > L.w) {
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 1; k <= 3; k++) {
+                const int bl = -k - cx, br = L.w - 1 + k - cx;              // byte positions of columns -k and w - 1 + k in this chunk
+                if (bl >= 0 && bl < 16) { const uint32_t px = rowp[reflect101(-k, L.w)]; w[bl >> 2] = (w[bl >> 2] & ~(0xFFu << (8 * (bl & 3)))) | (px << (8 * (bl & 3))); }
+                if (br >= 0 && br < 16) { const uint32_t px = rowp[reflect101(L.w - 1 + k, L.w)]; w[br >> 2] = (w[br >> 2] & ~(0xFFu << (8 * (br & 3)))) | (px << (8 * (br & 3))); }
             }
             v = make_uint4(w[0], w[1], w[2], w[3]);
         }
