@@ -157,6 +157,88 @@ __device__ void bow_node_group(const BowPairDev& P, int k, int f, float nnratio,
     }
 }
 
+// The common case -- a node with at most 32 Frame features -- without a memory access inside the loop over the KF features:
+// the lanes hold their (at most two) candidates' descriptors, indices and angles in registers, the KF features of the node are
+// loaded 16 at a time (lane i holds feature i) and handed round by 16-lane shuffles.  The generic form above walks four
+// dependent global round trips per KF feature (index, descriptor, candidate index, candidate descriptor), which made the kernel
+// a chain of memory latencies.
+__device__ __forceinline__ unsigned long long shfl16_u64(unsigned long long v, int src)
+{
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src, kBowGroup), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src, kBowGroup);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <bool KFKF>
+__device__ void bow_node_group32(const BowPairDev& P, int k, int f, float nnratio, int check_ori, int* s_hist, int sub)
+{
+    const int b2 = P.off2[f], n2 = P.off2[f + 1] - b2;         // n2 <= 32
+    int idx2[2] = {0, 0};
+    bool ok2[2];
+    unsigned long long db[2][4];
+    float ang2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; j++) { const int c = sub + kBowGroup * j; ok2[j] = c < n2; if (ok2[j]) idx2[j] = (int)P.feat2[b2 + c]; }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) db[j][q] = 0ull;
+        if (ok2[j]) {
+            if (KFKF && !P.v2[idx2[j]]) ok2[j] = false;
+            const unsigned long long* dp = (const unsigned long long*)(P.d2 + (size_t)idx2[j] * 32);
+#pragma unroll
+            for (int q = 0; q < 4; q++) db[j][q] = dp[q];
+            if (check_ori) ang2[j] = P.a2[(size_t)idx2[j] * P.a2_stride];
+        }
+    }
+    unsigned taken = 0;                                         // bit j: this lane's candidate j is consumed
+    const int b1 = P.off1[k], n1 = P.off1[k + 1] - b1;
+    for (int i0 = 0; i0 < n1; i0 += kBowGroup) {
+        const int ii = i0 + sub;
+        int idx1m = 0, valid = 0;
+        unsigned long long A[4] = {0ull, 0ull, 0ull, 0ull};
+        float ang1 = 0.f;
+        if (ii < n1) {
+            idx1m = (int)P.feat1[b1 + ii];
+            valid = (!P.v1 || P.v1[idx1m]) ? 1 : 0;              // !pMP || pMP->isBad()
+            const unsigned long long* da = (const unsigned long long*)(P.d1 + (size_t)idx1m * 32);
+#pragma unroll
+            for (int q = 0; q < 4; q++) A[q] = da[q];
+            if (check_ori) ang1 = P.a1[(size_t)idx1m * P.a1_stride];
+        }
+        const int cnt = min(kBowGroup, n1 - i0);
+        for (int i = 0; i < cnt; i++) {
+            if (!__shfl(valid, i, kBowGroup)) continue;         // uniform over the group
+            const unsigned long long a0 = shfl16_u64(A[0], i), a1 = shfl16_u64(A[1], i), a2 = shfl16_u64(A[2], i), a3 = shfl16_u64(A[3], i);
+            const int idx1 = __shfl(idx1m, i, kBowGroup);
+            const float an1 = __shfl(ang1, i, kBowGroup);
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (!ok2[j] || ((taken >> j) & 1u)) continue;
+                const unsigned key = ((unsigned)(__popcll(a0 ^ db[j][0]) + __popcll(a1 ^ db[j][1]) + __popcll(a2 ^ db[j][2]) + __popcll(a3 ^ db[j][3])) << 16) | (unsigned)(sub + kBowGroup * j);
+                if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+            }
+            for (int o = kBowGroup / 2; o > 0; o >>= 1) {
+                const unsigned o1 = (unsigned)__shfl_xor((int)k1, o), o2 = (unsigned)__shfl_xor((int)k2, o);
+                if (o1 < k1) { k2 = min(k1, o2); k1 = o1; } else k2 = min(k2, o1);
+            }
+            if (k1 == 0xFFFFFFFFu) continue;
+            const int best1 = (int)(k1 >> 16), best2 = (k2 == 0xFFFFFFFFu) ? 256 : (int)(k2 >> 16), cbest = (int)(k1 & 0xFFFFu);
+            const bool low = KFKF ? (best1 < TH_LOW) : (best1 <= TH_LOW);       // :848 is strict, :327 is not
+            if (low && (float)best1 < nnratio * (float)best2) {
+                const int jb = cbest / kBowGroup, lb = cbest & (kBowGroup - 1);
+                const int bestIdx = __shfl(jb ? idx2[1] : idx2[0], lb, kBowGroup);
+                const float an2 = __shfl(jb ? ang2[1] : ang2[0], lb, kBowGroup);
+                if (lb == sub) taken |= 1u << jb;
+                if (sub == 0) {
+                    if (KFKF) { P.match[idx1] = bestIdx; P.matched2[bestIdx] = 1; }
+                    else P.match[bestIdx] = idx1;
+                    if (check_ori) atomicAdd(&s_hist[rot_bin(an1, an2)], 1);
+                }
+            }
+        }
+    }
+}
+
 template <bool KFKF>
 __global__ __launch_bounds__(kBowThreads) void k_bow(const BowPairDev* __restrict__ pairs, float nnratio, int check_ori)
 {
@@ -193,7 +275,9 @@ __global__ __launch_bounds__(kBowThreads) void k_bow(const BowPairDev* __restric
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.node2[mid] < key) lo = mid + 1; else hi = mid; }
             if (lo < P.nn2 && P.node2[lo] == key) {
                 // a node with more than 512 Frame features does not fit the per-lane bitmask: one lane walks it
-                if (P.off2[lo + 1] - P.off2[lo] > 32 * kBowGroup) { if (sub == 0) bow_node<KFKF>(P, k, lo, nnratio, check_ori, s_hist); }
+                const int n2 = P.off2[lo + 1] - P.off2[lo];
+                if (n2 > 32 * kBowGroup) { if (sub == 0) bow_node<KFKF>(P, k, lo, nnratio, check_ori, s_hist); }
+                else if (n2 <= 2 * kBowGroup) bow_node_group32<KFKF>(P, k, lo, nnratio, check_ori, s_hist, sub);
                 else bow_node_group<KFKF>(P, k, lo, nnratio, check_ori, s_hist, sub);
             }
         }
