@@ -494,7 +494,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         const int l_tail = (nB >= 64 && resize_tail_first >= 2 && resize_tail_first < nlevels) ? resize_tail_first : nlevels;
         for (int l = 1; l < l_tail; l++) {
             const LevelDesc& D = levels[l];
-            dim3 g(xcd_grid(((D.w + 255) / 256) * ((D.h + kResizeRows - 1) / kResizeRows)), nB);
+            dim3 g(xcd_grid(((D.w + kResizeTW - 1) / kResizeTW) * ((D.h + kResizeRows - 1) / kResizeRows)), nB);
             const LevelDesc& P = levels[l - 1];
             SrcImage src;
             src.base = pyr + P.off; src.frame_stride = pyr_frame_bytes; src.stride = P.stride; src.w = P.w; src.h = P.h;

@@ -47,16 +47,18 @@ struct SrcImage {
 
 struct __attribute__((aligned(4))) Dwords3 { uint32_t x, y, z; };     // 12 bytes at dword alignment: one global_load_dwordx3
 struct __attribute__((aligned(4))) Dwords4 { uint32_t x, y, z, w; };  // 16 bytes at dword alignment: one global_load_dwordx4
-constexpr int kResizeRows = 32;      // output rows per workgroup (8 per wave): few, fat workgroups -- the dispatcher starts only ~2 workgroups per ns
+constexpr int kResizeRows = 64, kResizeTW = 64;      // output tile of a workgroup: 64 x 64 (16 rows per wave, 64-pixel segments of four rows per wave step)
 
-// one tile of 256 x 32 outputs of level `dst` of frame `frame` by 4 waves (`wave` 0..3, 8 rows each)
+// one tile of 64 x 64 outputs of level `dst` of frame `frame` by 4 waves (`wave` 0..3, 16 rows each).  A wave covers 16 quads
+// (64 pixels) of FOUR rows at a time: levels are 179..533 pixels wide, and whole waves per row (256 pixels) left a third of the
+// lanes idle on average (533 px = 2.08 waves); with 64-pixel segments the idle share is a few percent.
 __device__ __forceinline__ void resize_tile(const SrcImage& src, uint8_t* __restrict__ pyr, size_t frame_stride, const LevelDesc& dst,
                                             const int* __restrict__ q_sx0, const uint4* __restrict__ q_sel, const uint4* __restrict__ q_alpha,
                                             const int* __restrict__ yofs, const short* __restrict__ ibeta, int tile, int frame, int lane, int wave)
 {
-    const int tiles_x = (dst.w + 255) >> 8;
+    const int tiles_x = (dst.w + kResizeTW - 1) / kResizeTW;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int q = tx * 64 + lane;
+    const int q = tx * (kResizeTW / 4) + (lane & 15), rsel = lane >> 4;
     if (4 * q >= dst.w) return;
     const int sx0 = q_sx0[q];
     const uint4 sel = q_sel[q], al = q_alpha[q];
@@ -67,17 +69,17 @@ __device__ __forceinline__ void resize_tile(const SrcImage& src, uint8_t* __rest
     const int o0 = a, o1 = min(a + 4, last), o2 = min(a + 8, last);
     const uint8_t* S = src.base + (size_t)frame * src.frame_stride;
     uint8_t* D = pyr + (size_t)frame * frame_stride + dst.off + 4 * q;
-    const int dy0 = ty * kResizeRows + wave * (kResizeRows / 4);
-    constexpr int NR = kResizeRows / 4;
+    constexpr int NR = kResizeRows / 16;                        // row groups of 4 per wave
+    const int dy0 = ty * kResizeRows + wave * (kResizeRows / 4) + rsel;
     // all the loads of the wave's rows are issued before the first result is stored (the compiler cannot move a load above a
-    // store through pointers it cannot tell apart): 48 dwords in flight per thread instead of 6
+    // store through pointers it cannot tell apart)
     uint32_t u[NR][3], v[NR][3], bb[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const int dy = __builtin_amdgcn_readfirstlane(min(dy0 + r, dst.h - 1));       // wave-uniform: scalar table loads
+        const int dy = min(dy0 + 4 * r, dst.h - 1);
         const int sy = yofs[dy];
         const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
-        bb[r] = ((const uint32_t*)ibeta)[dy];                      // (ibeta0, ibeta1) as one scalar dword
+        bb[r] = ((const uint32_t*)ibeta)[dy];                      // (ibeta0, ibeta1) as one dword
         const uint8_t* r0p = S + (size_t)sy0 * src.stride;
         const uint8_t* r1p = S + (size_t)sy1 * src.stride;
         if (a + 8 <= last) {        // one 12-byte load per row: the address unit handles 4 lanes per clock whatever the width
@@ -91,8 +93,8 @@ __device__ __forceinline__ void resize_tile(const SrcImage& src, uint8_t* __rest
     }
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const int dy = dy0 + r;
-        if (dy >= dst.h) break;
+        const int dy = dy0 + 4 * r;
+        if (dy >= dst.h) continue;
         const uint32_t b0 = bb[r] & 0xFFFFu, b1 = bb[r] >> 16;
         // the 8 source bytes from column sx0 on, per row
         const uint32_t ulo = __builtin_amdgcn_alignbyte(u[r][1], u[r][0], sh), uhi = __builtin_amdgcn_alignbyte(u[r][2], u[r][1], sh);
@@ -115,9 +117,9 @@ __global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restric
                                                 const int* __restrict__ q_sx0, const uint4* __restrict__ q_sel, const uint4* __restrict__ q_alpha,
                                                 const int* __restrict__ yofs, const short* __restrict__ ibeta)
 {
-    // tiles of 256 x 32 outputs are numbered row-major and handed to the XCDs in contiguous bands (xcd_remap), so the source
+    // tiles of 64 x 64 outputs are numbered row-major and handed to the XCDs in contiguous bands (xcd_remap), so the source
     // rows a band of destination rows needs are fetched by one L2 only
-    const int tiles_x = (dst.w + 255) >> 8, tiles_y = (dst.h + kResizeRows - 1) / kResizeRows;
+    const int tiles_x = (dst.w + kResizeTW - 1) / kResizeTW, tiles_y = (dst.h + kResizeRows - 1) / kResizeRows;
     const int tile = xcd_remap(blockIdx.x, gridDim.x, blockIdx.y);
     if (tile >= tiles_x * tiles_y) return;
     resize_tile(src, pyr, frame_stride, dst, q_sx0, q_sel, q_alpha, yofs, ibeta, tile, blockIdx.y, threadIdx.x & 63,
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(1024) void k_resize_tail(uint8_t* __restrict__ pyr,
         const LevelDesc D = levels[l], P = levels[l - 1];
         SrcImage src;
         src.base = pyr + P.off; src.frame_stride = frame_stride; src.stride = P.stride; src.w = P.w; src.h = P.h;
-        const int tiles = ((D.w + 255) >> 8) * ((D.h + kResizeRows - 1) / kResizeRows);
+        const int tiles = ((D.w + kResizeTW - 1) / kResizeTW) * ((D.h + kResizeRows - 1) / kResizeRows);
         for (int t = sub; t < tiles; t += 4)
             resize_tile(src, pyr, frame_stride, D, T.q_sx0[l], T.q_sel[l], T.q_alpha[l], T.yofs[l], T.ibeta[l], t, frame, lane, wave);
         __syncthreads();            // the level is complete (and visible to this CU) before it becomes the next one's source
