@@ -921,17 +921,34 @@ __global__ __launch_bounds__(64) void k_backsub_update(Dev d, double lambda, con
     if (g < d.nL) {
         const int l = g;
         double c[3] = {d.bl[3 * (size_t)l], d.bl[3 * (size_t)l + 1], d.bl[3 * (size_t)l + 2]};
-        for (int k = d.l_off[l]; k < d.l_off[l + 1]; k++) {
-            const int e = d.l_edge[k];
-            const int col = d.pose_col[d.e_pose[e]];
-            if (col < 0) continue;
-            const double* W = d.W + 18 * (size_t)e;
-            const double* xp = d.x + 6 * (size_t)col;
-            for (int q = 0; q < 3; q++) {
-                double s = 0;
-                for (int r = 0; r < 6; r++) s += W[r * 3 + q] * xp[r];
-                c[q] -= s;
+        // four edges at a time: their index chains (edge -> pose -> column -> W, x) are independent, only the subtraction is
+        // kept in edge order (a thread walking one edge after the other paid four dependent memory round trips per edge)
+        const int k1 = d.l_off[l + 1];
+        for (int k = d.l_off[l]; k < k1; k += 4) {
+            int e[4], col[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = (k + u < k1) ? d.l_edge[k + u] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) col[u] = (e[u] >= 0) ? d.pose_col[d.e_pose[e[u]]] : -1;
+            double sv[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                sv[u][0] = 0; sv[u][1] = 0; sv[u][2] = 0;
+                if (col[u] >= 0) {
+                    const double* W = d.W + 18 * (size_t)e[u];
+                    const double* xp = d.x + 6 * (size_t)col[u];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        double s2 = 0;
+#pragma unroll
+                        for (int r = 0; r < 6; r++) s2 += W[r * 3 + q] * xp[r];
+                        sv[u][q] = s2;
+                    }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (col[u] >= 0) { c[0] -= sv[u][0]; c[1] -= sv[u][1]; c[2] -= sv[u][2]; }
         }
         const double* Di = d.Dinv + 9 * (size_t)l;
         double sc = 0;
