@@ -503,19 +503,40 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                                d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
             ORBX_LAUNCHED("k_resize");
         }
+        uint32_t* cand = d_cand.p + (size_t)f0 * cand_frame_entries;
+        int* cell_cnt = d_cell_count.p + (size_t)f0 * std::max<size_t>(cells.size(), 1);
+        auto launch_fast = [&](hipStream_t fs, int s0, int s1) {
+            if (s1 > s0)
+                hipLaunchKernelGGL(k_fast_strips, dim3(xcd_grid(s1 - s0), nB), dim3(256), fast_lds, fs, lvl0, pyr, pyr_frame_bytes, d_levels.p, d_cells.p,
+                                   d_strips.p + s0, s1 - s0, n_cells, ini_th, min_th, fast_layout, cand, (size_t)cand_frame_entries, cell_cnt);
+        };
+        // first strip of the levels the resize tail produces (the strips are in level order)
+        int tail_strip = (int)strips.size();
+        for (int si = (int)strips.size() - 1; si >= 0 && strips[si].level >= l_tail; si--) tail_strip = si;
         if (l_tail < nlevels) {
             ResizeTables T;
             std::memset(&T, 0, sizeof(T));
             for (int l = l_tail; l < nlevels; l++) { T.q_sx0[l] = d_qsx0[l].p; T.q_sel[l] = d_qsel[l].p; T.q_alpha[l] = d_qalpha[l].p; T.yofs[l] = d_yofs[l].p; T.ibeta[l] = d_ibeta[l].p; }
-            hipLaunchKernelGGL(k_resize_tail, dim3(nB), dim3(1024), 0, s, pyr, pyr_frame_bytes, d_levels.p, T, l_tail, nlevels);
+            // With side streams the tail -- one latency-bound workgroup per frame -- and FAST on its levels run BESIDE FAST on the
+            // lower levels (which only need the levels before the tail) instead of in front of it.
+            const bool beside = blur_s && oct_stream && n_cells > 0 && tail_strip > 0;
+            hipStream_t ts = beside ? oct_stream : s;
+            if (beside) { ORBX_HIP(hipEventRecord(ev_fork, s)); ORBX_HIP(hipStreamWaitEvent(ts, ev_fork, 0)); }
+            hipLaunchKernelGGL(k_resize_tail, dim3(nB), dim3(1024), 0, ts, pyr, pyr_frame_bytes, d_levels.p, T, l_tail, nlevels);
             ORBX_LAUNCHED("k_resize_tail");
+            if (beside) {
+                launch_fast(ts, tail_strip, (int)strips.size());
+                ORBX_HIP(hipEventRecord(ev_oct_join, ts));
+                launch_fast(s, 0, tail_strip);
+                ORBX_HIP(hipStreamWaitEvent(s, ev_oct_join, 0));
+            } else {
+                if (marks) mark();
+                if (n_cells > 0) launch_fast(s, 0, (int)strips.size());
+            }
+        } else {
+            if (marks) mark();
+            if (n_cells > 0) launch_fast(s, 0, (int)strips.size());
         }
-        if (marks) mark();
-        uint32_t* cand = d_cand.p + (size_t)f0 * cand_frame_entries;
-        int* cell_cnt = d_cell_count.p + (size_t)f0 * std::max<size_t>(cells.size(), 1);
-        if (n_cells > 0)
-            hipLaunchKernelGGL(k_fast_strips, dim3(xcd_grid((int)strips.size()), nB), dim3(256), fast_lds, s, lvl0, pyr, pyr_frame_bytes, d_levels.p, d_cells.p,
-                               d_strips.p, (int)strips.size(), n_cells, ini_th, min_th, fast_layout, cand, (size_t)cand_frame_entries, cell_cnt);
         ORBX_LAUNCHED("k_fast_strips");
         if (marks) mark();
         auto launch_blur = [&](hipStream_t bs) {
