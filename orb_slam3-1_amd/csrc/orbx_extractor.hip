@@ -149,7 +149,7 @@ struct orbx_extractor {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // second stream for the octree of the upper pyramid levels (their node pools are small: own launch, own LDS size)
     hipStream_t oct_stream = nullptr;
-    hipEvent_t ev_oct_join = nullptr;
+    hipEvent_t ev_oct_join = nullptr, ev_fast0 = nullptr;
     int oct_split = 0, oct_pool_hi = 0;  // levels [oct_split, nlevels) go to the second launch with a pool of oct_pool_hi nodes (0: one launch)
     size_t oct_lds_hi = 0;
     // streams for the ranges a large batch is cut into (enqueue)
@@ -503,6 +503,27 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                                d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
             ORBX_LAUNCHED("k_resize");
         }
+        // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
+        // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
+        // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
+        const bool small_batch = !oct_keys_forced && oct_small_keys > 0 && (long long)B * nlevels <= 512;
+        const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
+        const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
+        uint32_t* sel = d_sel.p + (size_t)f0 * sel_frame_entries;
+        int* sel_cnt = d_sel_count.p + (size_t)f0 * nlevels;
+        int* kp_dst = d_kp_dst.p + (size_t)f0 * sel_frame_entries;
+        auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>);
+        // (keys in LDS: one launch, the buffers are sized for the largest level anyway)
+        const bool two_launches = !oct_nodes_hbm && o_keys == 0 && oct_split > 0 && oct_stream && blur_s;
+        const int lv_lo = two_launches ? oct_split : nlevels;
+        auto launch_octree = [&](hipStream_t qs, int lv0, int lv1, size_t lds, int pool, int keys) {
+            if (lv1 > lv0)
+                hipLaunchKernelGGL(oct_kernel, dim3(lv1 - lv0, nB), dim3(64), lds, qs, d_levels.p, d_cells.p, d_cand.p + (size_t)f0 * cand_frame_entries, (size_t)cand_frame_entries,
+                                   d_cell_count.p + (size_t)f0 * std::max<size_t>(cells.size(), 1), n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, pool, keys,
+                                   sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0,
+                                   d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride, lv0);
+        };
+        bool oct0_early = false;            // level 0's octree already runs beside FAST on the levels above it (below)
         uint32_t* cand = d_cand.p + (size_t)f0 * cand_frame_entries;
         int* cell_cnt = d_cell_count.p + (size_t)f0 * std::max<size_t>(cells.size(), 1);
         auto launch_fast = [&](hipStream_t fs, int s0, int s1) {
@@ -527,7 +548,20 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             if (beside) {
                 launch_fast(ts, tail_strip, (int)strips.size());
                 ORBX_HIP(hipEventRecord(ev_oct_join, ts));
-                launch_fast(s, 0, tail_strip);
+                // FAST on level 0 first; its octree -- the longest chain of the stage -- then runs beside FAST on levels 1..
+                // (a launch per level with every level's octree started early was measured too: the extra launch tails cost
+                // FAST 40 us, more than the octrees gain)
+                int l1_strip = tail_strip;
+                for (int si = tail_strip - 1; si >= 0 && strips[si].level >= 1; si--) l1_strip = si;
+                if (two_launches && oct_split > 1 && l1_strip > 0 && l1_strip < tail_strip) {
+                    launch_fast(s, 0, l1_strip);
+                    ORBX_HIP(hipEventRecord(ev_fast0, s));
+                    ORBX_HIP(hipStreamWaitEvent(blur_s, ev_fast0, 0));
+                    launch_octree(blur_s, 0, 1, o_lds, oct_pool, o_keys);
+                    oct0_early = true;
+                    launch_fast(s, l1_strip, tail_strip);
+                } else
+                    launch_fast(s, 0, tail_strip);
                 ORBX_HIP(hipStreamWaitEvent(s, ev_oct_join, 0));
             } else {
                 if (marks) mark();
@@ -543,19 +577,6 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), nB), dim3(256), 0, bs, lvl0, pyr, in_place ? pyr : nullptr, blr, pyr_frame_bytes,
                                d_levels.p, d_tiles.p, (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
         };
-        // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
-        // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
-        // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
-        const bool small_batch = !oct_keys_forced && oct_small_keys > 0 && (long long)B * nlevels <= 512;
-        const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
-        const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
-        uint32_t* sel = d_sel.p + (size_t)f0 * sel_frame_entries;
-        int* sel_cnt = d_sel_count.p + (size_t)f0 * nlevels;
-        int* kp_dst = d_kp_dst.p + (size_t)f0 * sel_frame_entries;
-        auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>);
-        // (keys in LDS: one launch, the buffers are sized for the largest level anyway)
-        const bool two_launches = !oct_nodes_hbm && o_keys == 0 && oct_split > 0 && oct_stream && blur_s;
-        const int lv_lo = two_launches ? oct_split : nlevels;
         // With a side stream the throughput-bound blur stays on the launch stream (it starts the moment FAST ends) and the
         // latency-bound octree + index go beside it: octree of the lower levels and the index on `blur_s`, the upper levels'
         // octree on `oct_stream`.  Without one (profiling) everything is serial on `s`.
@@ -566,15 +587,10 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         }
         if (two_launches) {
             ORBX_HIP(hipStreamWaitEvent(oct_stream, ev_fork, 0));
-            hipLaunchKernelGGL(oct_kernel, dim3(nlevels - oct_split, nB), dim3(64), oct_lds_hi, oct_stream, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
-                               cell_cnt, n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, oct_pool_hi, 0,
-                               sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0, (uint8_t*)nullptr, (size_t)0, oct_split);
+            launch_octree(oct_stream, oct_split, nlevels, oct_lds_hi, oct_pool_hi, 0);
             ORBX_HIP(hipEventRecord(ev_oct_join, oct_stream));
         }
-        hipLaunchKernelGGL(oct_kernel, dim3(lv_lo, nB), dim3(64), o_lds, os, d_levels.p, d_cells.p, cand, (size_t)cand_frame_entries,
-                           cell_cnt, n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, oct_pool, o_keys,
-                           sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0,
-                           d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride, 0);
+        launch_octree(os, oct0_early ? 1 : 0, lv_lo, o_lds, oct_pool, o_keys);
         if (blur_s) launch_blur(s);
         if (two_launches) ORBX_HIP(hipStreamWaitEvent(os, ev_oct_join, 0));
         ORBX_LAUNCHED("k_octree / k_blur");
@@ -679,7 +695,8 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
         hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_parts_fork, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&e->oct_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_oct_join, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
+        hipEventCreateWithFlags(&e->ev_oct_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
     if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
     if (const char* env = getenv("ORBX_RESIZE_TAIL")) e->resize_tail_first = atoi(env);
     for (int i = 0; i + 1 < e->split_parts; i++) {
@@ -702,6 +719,7 @@ void orbx_destroy(orbx_extractor* e)
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
     if (e->oct_stream) { (void)hipStreamSynchronize(e->oct_stream); (void)hipStreamDestroy(e->oct_stream); }
     if (e->ev_oct_join) (void)hipEventDestroy(e->ev_oct_join);
+    if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (hipStream_t s : e->aux_streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
