@@ -154,6 +154,7 @@ struct orbx_extractor {
     size_t oct_lds_hi = 0;
     // streams for the ranges a large batch is cut into (enqueue)
     int split_parts = 1;                 // ORBX_SPLIT (measurement knob, see enqueue)
+    bool serial_schedule = false;        // ORBX_SERIAL=1: every kernel of a batch on the launch stream, one launch per stage (per-kernel profiles)
     int resize_tail_first = 4;           // first pyramid level of the fused resize tail (ORBX_RESIZE_TAIL; 0: a launch per level)
     std::vector<hipStream_t> aux_streams;
     hipEvent_t ev_parts_fork = nullptr;
@@ -619,7 +620,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
     int r;
     if (parts == 1) {
         // (small batches: the blur is a few microseconds, less than the fork / join across streams costs)
-        if ((r = run_range(0, B, st, (!profile && side_stream && B >= 32) ? side_stream : nullptr, true))) return r;
+        if ((r = run_range(0, B, st, (!profile && !serial_schedule && side_stream && B >= 32) ? side_stream : nullptr, true))) return r;
     } else {
         ORBX_HIP(hipEventRecord(ev_parts_fork, st));
         for (int p = 0; p < parts; p++) {
@@ -697,6 +698,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
         hipStreamCreateWithFlags(&e->oct_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_oct_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
+    if (const char* env = getenv("ORBX_SERIAL")) e->serial_schedule = atoi(env) != 0;
     if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
     if (const char* env = getenv("ORBX_RESIZE_TAIL")) e->resize_tail_first = atoi(env);
     for (int i = 0; i + 1 < e->split_parts; i++) {

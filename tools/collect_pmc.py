@@ -49,8 +49,9 @@ def main():
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         out["_raw_kib"][k] = {"FETCH_SIZE": f, "WRITE_SIZE": w, "dispatches": nf.get(k, 0)}
         out[k[2:]] = f * 1024.0 * cal_f + w * 1024.0 * cal_w
-    # kernels launched several times per step (k_resize once per lower level, k_octree twice): report bytes per STEP
-    steps = max(nf.get("k_fast_strips", 1), 1)
+    # kernels launched several times per step (k_resize once per lower level, k_octree and k_fast_strips two or three times in the
+    # large-batch schedule): report bytes per STEP
+    steps = max(nf.get("k_orient_desc", nf.get("k_blur", 1)), 1)      # kernels that are one launch per step in every schedule
     for k in list(out):
         if k.startswith("_"):
             continue

@@ -16,6 +16,11 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fet
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu --no-lba > /dev/null 2> $OUT/pmc_write.err || { echo "pmc write failed"; exit 1; }
 python tools/collect_pmc.py $OUT/pmc_fetch $OUT/pmc_write 256 > $OUT/pmc_traffic.log && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 cp $(ls $OUT/prof/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+# the same command with the serial schedule (ORBX_SERIAL=1: one launch per stage on one stream): per-kernel averages that can be
+# compared with the HIP-event stage times of the bench line (in the production schedule FAST and the octree are several
+# launches that run beside other kernels)
+ORBX_SERIAL=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -- python bench.py --steps 5 --warmup 1 --no-cpu --no-lba > $OUT/bench_prof_serial.json 2> $OUT/bench_prof_serial.err || echo "serial rocprof stats failed"
+cp $(ls $OUT/prof_serial/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_serial.csv 2>/dev/null
 timeout -k 10 200 python bench.py --streams 4 --no-cpu --no-lba > $OUT/bench_streams4.json 2> $OUT/bench_streams4.err || echo "streams-4 bench failed"
 # per-kernel times of the two BA solvers alone (profiles/<tag>_lba_kernel_stats.csv, <tag>_inertial_ba_kernel_stats.csv)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lbaprof -- python tools/lba_prof.py 5 > $OUT/lbaprof.log 2>&1 || echo "lba profile failed"
