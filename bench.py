@@ -58,7 +58,7 @@ def compact_line(out):
     line = {k: out[k] for k in keep if k in out}
     if "roofline" in out:
         r = out["roofline"]
-        line["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms",
+        line["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms", "launch_ms_from",
                                                "pipeline_frac", "stage_ms") if k in r}
         if "stage_ms" in line["roofline"]:
             line["roofline"]["stage_ms"] = {k: round(v, 3) for k, v in line["roofline"]["stage_ms"].items()}
@@ -266,7 +266,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                            "pipeline_frac": ALGO_BYTES_PER_FRAME * value / 1e9 / HBM_PEAK_GBS,
-                           "launch_ms": acc[dom], "algorithmic_bytes_per_launch": sb[dom] * B,
+                           "launch_ms": acc[dom], "launch_ms_from": "HIP events, serial schedule (ORBX_SERIAL=1 rocprof agrees)",
+                           "algorithmic_bytes_per_launch": sb[dom] * B,
                            "stage_ms": acc, "stage_gbs": {k: sb[k] * B / (max(acc[k], 1e-6) * 1e-3) / 1e9 for k in acc}}
         # ---- extra leg: the batch cut over S independent streams (one Extractor handle + BoW plan per stream, like the
         # reference's one ORBextractor per camera thread).  Stages with different bottlenecks (FAST: VALU, octree /
