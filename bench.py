@@ -69,8 +69,11 @@ def compact_line(out):
         l = out["lba"]
         line["lba"] = {k: l[k] for k in ("metric", "value", "unit", "dtype", "ms_per_iteration", "ms_per_trial", "roofline", "cpu_baseline",
                                           "speedup_vs_cpu_1core", "workload") if k in l}
-    if "gba" in out:
-        line["gba"] = out["gba"]
+    if "gba" in out:        # the short form of the sharded global-BA leg (N > 1); the full record is in bench_detail.json
+        g = out["gba"]
+        line["gba"] = {k: g[k] for k in ("error", "iters_per_s", "iterations", "trials", "allreduce_bytes_per_trial") if k in g}
+        if "roofline" in g:
+            line["gba"]["roofline"] = {k: g["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in g["roofline"]}
     line["detail"] = "gpurun_out/bench_detail.json"
 
     def shorten(o):         # six significant digits are plenty for a headline line
@@ -228,8 +231,7 @@ def main():
         "metric": "tracking frames/s (ORB extract+match)", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "ORBextractor::operator() 640x480 mono, 8 levels, 1000 features (configs[1]) + "
-                               "ORBmatcher::SearchByBoW 1000x1000 per frame (configs[2])",
+        "config": {"workload": "ORBextractor 640x480, 8 levels, 1000 features (configs[1]) + SearchByBoW 1000x1000 per frame (configs[2])",
                    "batch_per_gpu": B, "frames_per_step": world * B, "keypoints_per_frame": n_kp,
                    "bow_matches_per_pair": float(np.mean([b[0] for b in bow])), "sharding": "frames, no collective"},
         "pipeline_gbs": ALGO_BYTES_PER_FRAME * value / 1e9,
@@ -260,13 +262,13 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(dom)
-                traffic_from = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)"
+                traffic_from = "profiles/pmc_traffic.json"
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                            "pipeline_frac": ALGO_BYTES_PER_FRAME * value / 1e9 / HBM_PEAK_GBS,
-                           "launch_ms": acc[dom], "launch_ms_from": "HIP events, serial schedule (ORBX_SERIAL=1 rocprof agrees)",
+                           "launch_ms": acc[dom], "launch_ms_from": "HIP events, serial schedule",
                            "algorithmic_bytes_per_launch": sb[dom] * B,
                            "stage_ms": acc, "stage_gbs": {k: sb[k] * B / (max(acc[k], 1e-6) * 1e-3) / 1e9 for k in acc}}
         # ---- extra leg: the batch cut over S independent streams (one Extractor handle + BoW plan per stream, like the
