@@ -362,15 +362,18 @@ __global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
 // all-reduces partial systems first and adds lambda afterwards).
 // Workgroups [nBlocks, nBlocks + nP): b_schur = b_p - sum_e W_e db_l(e) (block_solver.hpp:413,436-439), plus copies of
 // b_p and diag(Hpp) for the reduce buffer (additive over shards).
-__global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict__ S, double lambda_diag,
+constexpr int kSchurThreads = 1024, kSchurGroups = 28;     // 28 groups x 36 entries walk a block's pair list (the diagonal blocks
+                                                            // hold a pose's ~400 edges: with 7 groups their chains of dependent loads
+                                                            // were the kernel's time)
+__global__ __launch_bounds__(kSchurThreads) void k_schur_blocks(Dev d, double* __restrict__ S, double lambda_diag,
                                                       double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out)
 {
-    __shared__ double s_part[7][36];
+    __shared__ double s_part[kSchurGroups][36];
     const int blk = blockIdx.x, tid = threadIdx.x;
     if (blk >= d.nBlocks) {
         const int i = blk - d.nBlocks, lane = tid & 63, wave = tid >> 6;
         double acc[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = d.p_off[i] + tid; k < d.p_off[i + 1]; k += 256) {
+        for (int k = d.p_off[i] + tid; k < d.p_off[i + 1]; k += kSchurThreads) {
             const int e = d.p_edge[k];
             const double* W = d.W + 18 * (size_t)e;
             const double* db = d.db + 3 * (size_t)d.e_point[e];
@@ -381,7 +384,8 @@ __global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict_
         if (lane == 0) for (int r = 0; r < 6; r++) s_part[wave][r] = acc[r];
         __syncthreads();
         if (tid < 6) {
-            const double a = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
+            double a = 0;
+            for (int w = 0; w < kSchurThreads / 64; w++) a += s_part[w][tid];
             bs[6 * i + tid] = d.bp[6 * (size_t)i + tid] - a;
             bp_out[6 * i + tid] = d.bp[6 * (size_t)i + tid];
             diag_out[6 * i + tid] = d.Hpp[36 * (size_t)i + tid * 7];
@@ -391,11 +395,11 @@ __global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict_
     const int i = d.b_i[blk], j = d.b_j[blk];
     const int n = d.n;
     const int g = tid / 36, ent = tid - g * 36;
-    if (g < 7) {
+    if (g < kSchurGroups) {
         const int r = ent / 6, c = ent - r * 6;
         double acc = 0.0;
 #pragma unroll 4
-        for (int k = d.b_off[blk] + g; k < d.b_off[blk + 1]; k += 7) {
+        for (int k = d.b_off[blk] + g; k < d.b_off[blk + 1]; k += kSchurGroups) {
             const int2 pr = d.b_pair[k];
             const double* Z = d.Z + 18 * (size_t)pr.x + r * 3;
             const double* W = d.W + 18 * (size_t)pr.y + c * 3;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void k_schur_blocks(Dev d, double* __restrict_
     if (tid < 36) {
         const int r = tid / 6, c = tid - r * 6;
         double sum = s_part[0][tid];
-        for (int q = 1; q < 7; q++) sum += s_part[q][tid];
+        for (int q = 1; q < kSchurGroups; q++) sum += s_part[q][tid];
         double v = ((i == j) ? d.Hpp[36 * (size_t)i + tid] : 0.0) - sum;
         if (i == j && r == c) v += lambda_diag;
         S[(size_t)(6 * i + r) * n + 6 * j + c] = v;
@@ -1487,7 +1491,7 @@ int lba_shard_reduce(lba_shard* s, double lambda)
         hipLaunchKernelGGL(lba::k_schur_landmarks, dim3((d.nL + 7) / 8), dim3(64), 0, s->stream, d, lambda);
     s->schur_lambda = -1.0;                 // W / Dinv / Z now belong to this lambda only until the next trial changes it
     if (d.nBlocks + d.nP > 0)
-        hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks + d.nP), dim3(256), 0, s->stream, d, s->S(),
+        hipLaunchKernelGGL(lba::k_schur_blocks, dim3(d.nBlocks + d.nP), dim3(lba::kSchurThreads), 0, s->stream, d, s->S(),
                            s->lambda_in_reduce ? lambda : 0.0, s->bs(), s->bpf(), s->diag());
     s->lambda_added = s->lambda_in_reduce;
     s->mark(lba::kStageIdle);
