@@ -1,14 +1,14 @@
 // orbx_kernels.hip -- gfx950 kernels of the ORB extractor (reference src/ORBextractor.cc).
 //
 // Pipeline per batch of B frames (all launches cover the whole batch; blockIdx.y / .z = frame):
-//   k_resize        level l-1 -> l, fixed-point bilinear            (E1, ComputePyramid :1170-1195)
+//   k_resize        level l-1 -> l, fixed-point bilinear; k_resize_tail: the upper levels in one launch (E1, ComputePyramid :1170-1195)
 //   k_fast_strips   FAST-9/16 score + per-cell NMS / threshold fallback / ordered compaction, a workgroup per strip of cells
 //                                                                    (E2, ComputeKeyPointsOctTree :787-872)
-//   k_octree        quadtree keypoint selection, one wave per (frame, level)
+//   k_octree        quadtree keypoint selection, one wave per (frame, level), a lane per node within a pass
 //                                                                    (E3, DistributeOctTree :555-779)
 //   k_index         output slot of every keypoint (lapping-area split) (E8, operator() :1140-1167)
 //   k_blur          7x7 sigma-2 Gaussian, Q8.8 fixed point             (E6, :1132-1133)
-//   k_orient_desc   intensity-centroid angle + steered BRIEF-256       (E5 :76-103, E7 :107-146)
+//   k_orient_desc   intensity-centroid angle + steered BRIEF-256, half a wave per keypoint (E5 :76-103, E7 :107-146)
 //
 // Integer stages are exact by construction; float stages use orbx_math.h (no FMA, no libm).
 // HBM layout: one pyramid buffer per frame, levels back to back, row stride rounded up to 64 B so that
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(1024) void k_resize_tail(uint8_t* __restrict__ pyr,
 // ------------------------------------------------------------------------------------------------
 // E3: DistributeOctTree.  One wave per (frame, level).  The std::list of nodes is an index-linked list
 // in LDS; a node's keys are a contiguous, order-preserving segment of a ping-pong key array (LDS when
-// the level's candidates fit, HBM scratch otherwise).  Node bookkeeping is wave-uniform scalar work;
-// the stable 4-way key partition of DivideNode is wave-parallel (ballot + prefix popcount).
+// the level's candidates fit, HBM scratch otherwise).  A pass of the reference's loops is a batch of up to 64
+// DivideNode calls, a lane per node (see k_octree); std::sort is wave-parallel (orbx_introsort.h).
 // ------------------------------------------------------------------------------------------------
 #ifdef ORBX_OCT_TIMING      // cycle split of the (level 0, frame 0) wave (tools/oct_timing.py); never defined in the product build
 __device__ unsigned long long d_oct_prof[10];
