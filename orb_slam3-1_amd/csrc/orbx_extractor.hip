@@ -563,7 +563,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                     launch_fast(s, l1_strip, tail_strip);
                 } else
                     launch_fast(s, 0, tail_strip);
-                ORBX_HIP(hipStreamWaitEvent(s, ev_oct_join, 0));
+                ORBX_HIP(hipStreamWaitEvent(blur_s, ev_oct_join, 0));
             } else {
                 if (marks) mark();
                 if (n_cells > 0) launch_fast(s, 0, (int)strips.size());
