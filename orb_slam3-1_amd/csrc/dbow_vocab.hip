@@ -39,6 +39,10 @@ struct VocabDev {
     const uint4* desc;          // 2 x uint4 per node
     const double* weight;
     const int32_t* word_id;
+    // per CHILD SLOT (position in child_id): the child's centroid and its own child range, so that a tree level is ONE round trip
+    // (slot -> id -> centroid and id -> range were three dependent ones)
+    const uint4* slot_desc;     // 2 x uint4 per slot
+    const int2* slot_range;     // (child_off[id], child_off[id + 1]) of the slot's child
 };
 
 // ---- per-feature descent (TemplatedVocabulary.h:1216-1259) ----
@@ -62,26 +66,40 @@ __global__ __launch_bounds__(256) void k_vocab_descend(VocabDev V, const uint8_t
     bool nid_set = nid_level <= 0;
     int level = 0;
     bool going = live;
-    // all 16 lanes of a group hold the same (final_id, going); groups of one wave leave the loop together via the ballot
+    // all 16 lanes of a group hold the same (final_id, c0, c1, going); groups of one wave leave the loop together via the ballot
+    int c0 = V.child_off[0], c1 = V.child_off[1];          // the root's children
     while (__ballot(going) != 0ull) {
         uint32_t key = 0xFFFFFFFFu;
-        int c0 = 0, c1 = 0;
+        uint32_t my_id = 0;
+        int2 my_range = make_int2(0, 0);
         if (going) {
-            c0 = V.child_off[final_id]; c1 = V.child_off[final_id + 1];
-            for (int c = c0 + sub; c < c1; c += 16) {
-                const uint32_t id = V.child_id[c];
-                const uint4 a = V.desc[2 * (size_t)id], b = V.desc[2 * (size_t)id + 1];
+            const int c = c0 + sub;                             // the first 16 children: one load round for id, range and centroid
+            if (c < c1) {
+                my_id = V.child_id[c];
+                my_range = V.slot_range[c];
+                const uint4 a = V.slot_desc[2 * (size_t)c], b = V.slot_desc[2 * (size_t)c + 1];
                 const int dist = __popc(a.x ^ d0.x) + __popc(a.y ^ d0.y) + __popc(a.z ^ d0.z) + __popc(a.w ^ d0.w) +
                                  __popc(b.x ^ d1.x) + __popc(b.y ^ d1.y) + __popc(b.z ^ d1.z) + __popc(b.w ^ d1.w);
-                key = min(key, ((uint32_t)dist << 20) | (uint32_t)(c - c0));       // first minimum in children order
+                key = ((uint32_t)dist << 20) | (uint32_t)sub;          // first minimum in children order
+            }
+            for (int cc = c + 16; cc < c1; cc += 16) {          // (nodes with more than 16 children)
+                const uint4 a = V.slot_desc[2 * (size_t)cc], b = V.slot_desc[2 * (size_t)cc + 1];
+                const int dist = __popc(a.x ^ d0.x) + __popc(a.y ^ d0.y) + __popc(a.z ^ d0.z) + __popc(a.w ^ d0.w) +
+                                 __popc(b.x ^ d1.x) + __popc(b.y ^ d1.y) + __popc(b.z ^ d1.z) + __popc(b.w ^ d1.w);
+                key = min(key, ((uint32_t)dist << 20) | (uint32_t)(cc - c0));
             }
         }
         for (int o = 8; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o));
+        const int best = (int)(key & 0xFFFFFu);
+        // the winner's id and child range: from the lane that holds it (slots below 16), else one more load
+        const uint32_t w_id = (uint32_t)__shfl((int)my_id, best & 15, 16);
+        const int w_c0 = __shfl(my_range.x, best & 15, 16), w_c1 = __shfl(my_range.y, best & 15, 16);
         if (going) {
-            final_id = V.child_id[c0 + (int)(key & 0xFFFFFu)];
+            if (best < 16) { final_id = w_id; c0 = w_c0; c1 = w_c1; }
+            else { final_id = V.child_id[c0 + best]; const int2 r = V.slot_range[c0 + best]; c0 = r.x; c1 = r.y; }
             level++;
             if (level == nid_level) { nid = final_id; nid_set = true; }
-            going = V.child_off[final_id + 1] > V.child_off[final_id] && level < 64;     // !isLeaf(); the bound ends a malformed (cyclic) tree
+            going = c1 > c0 && level < 64;                      // !isLeaf(); the bound ends a malformed (cyclic) tree
         }
     }
     if (live && sub == 0) {
@@ -284,7 +302,17 @@ int orbv_create(int device, const OrbvVocabulary* voc, orbv_vocab** out)
     orbv_vocab* v = new orbv_vocab();
     v->device = device;
     const size_t o_off = 0, o_cid = al(o_off + sizeof(int32_t) * ((size_t)nn + 1)), o_desc = al(o_cid + sizeof(uint32_t) * (size_t)std::max(n_child, 1)),
-                 o_w = al(o_desc + (size_t)nn * 32), o_word = al(o_w + sizeof(double) * (size_t)nn), total = al(o_word + sizeof(int32_t) * (size_t)nn);
+                 o_w = al(o_desc + (size_t)nn * 32), o_word = al(o_w + sizeof(double) * (size_t)nn),
+                 o_sdesc = al(o_word + sizeof(int32_t) * (size_t)nn), o_srange = al(o_sdesc + 32 * (size_t)std::max(n_child, 1)),
+                 total = al(o_srange + sizeof(int2) * (size_t)std::max(n_child, 1));
+    // per child slot: centroid and child range of the slot's child (the descent then needs one round trip per level)
+    std::vector<uint8_t> sdesc(32 * (size_t)std::max(n_child, 1));
+    std::vector<int2> srange((size_t)std::max(n_child, 1));
+    for (int c = 0; c < n_child; c++) {
+        const uint32_t id = voc->child_id[c];
+        std::memcpy(&sdesc[32 * (size_t)c], (const uint8_t*)voc->desc + 32 * (size_t)id, 32);
+        srange[c] = make_int2(voc->child_off[id], voc->child_off[id + 1]);
+    }
     if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&v->d_tree, total) != hipSuccess) {
         orbv_destroy(v);
         return fail(ORBX_ERR_HIP, "vocabulary allocation of %zu bytes failed", total);
@@ -293,7 +321,9 @@ int orbv_create(int device, const OrbvVocabulary* voc, orbv_vocab** out)
               hipMemcpy(v->d_tree + o_cid, voc->child_id, sizeof(uint32_t) * (size_t)n_child, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(v->d_tree + o_desc, voc->desc, (size_t)nn * 32, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(v->d_tree + o_w, voc->weight, sizeof(double) * (size_t)nn, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(v->d_tree + o_word, voc->word_id, sizeof(int32_t) * (size_t)nn, hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(v->d_tree + o_word, voc->word_id, sizeof(int32_t) * (size_t)nn, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(v->d_tree + o_sdesc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(v->d_tree + o_srange, srange.data(), sizeof(int2) * srange.size(), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { orbv_destroy(v); return fail(ORBX_ERR_HIP, "vocabulary upload failed"); }
     if (hipFuncSetAttribute((const void*)orbv::k_vocab_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8) != hipSuccess) {
         orbv_destroy(v);
@@ -302,6 +332,7 @@ int orbv_create(int device, const OrbvVocabulary* voc, orbv_vocab** out)
     v->V.n_nodes = nn; v->V.L = voc->L;
     v->V.child_off = (const int32_t*)(v->d_tree + o_off); v->V.child_id = (const uint32_t*)(v->d_tree + o_cid);
     v->V.desc = (const uint4*)(v->d_tree + o_desc); v->V.weight = (const double*)(v->d_tree + o_w); v->V.word_id = (const int32_t*)(v->d_tree + o_word);
+    v->V.slot_desc = (const uint4*)(v->d_tree + o_sdesc); v->V.slot_range = (const int2*)(v->d_tree + o_srange);
     *out = v;
     return ORBX_OK;
 }
