@@ -232,3 +232,23 @@ def test_large_batch_launch_paths(pkg, oracle, synth, B):
                 np.testing.assert_array_equal(desc[b, :n[b]], d0)
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("args,size", [((500, 1.5, 5, 20, 7), (376, 240)), ((1500, 1.2, 10, 12, 5), (752, 480)), ((300, 2.0, 3, 20, 7), (320, 240))])
+def test_large_batch_other_geometries(pkg, oracle, synth, args, size):
+    """the large-batch schedule (resize tail, split FAST / octree launches, side streams) on pyramids with other level counts"""
+    B = 64
+    distinct = [synth.make_frame(950 + i, *size) for i in range(4)]
+    oex = oracle.extractor(*args)
+    ref = [oex.extract(im, (0, 1000)) for im in distinct]
+    imgs = np.stack([distinct[i % 4] for i in range(B)])
+    ex = pkg.Extractor(*args)
+    try:
+        mono, n, kps, desc = ex.extract_batch(imgs)
+        for b in range(B):
+            r0, k0, d0 = ref[b % 4]
+            assert mono[b] == r0 and n[b] == len(k0)
+            _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
+            np.testing.assert_array_equal(desc[b, :n[b]], d0)
+    finally:
+        ex.close()
