@@ -252,3 +252,35 @@ def test_large_batch_other_geometries(pkg, oracle, synth, args, size):
             np.testing.assert_array_equal(desc[b, :n[b]], d0)
     finally:
         ex.close()
+
+
+def test_large_batch_device_api_in_place(pkg, oracle, synth):
+    """the bench's path: 64 device-resident frames read in place (level 0 = the caller's buffer, copied into the pyramid by the
+    blur), the large-batch schedule, results left on the device -- twice on the same handle, against the oracle frame by frame"""
+    import torch
+    B = 64
+    distinct = [synth.make_frame(970 + i) for i in range(4)]
+    oex = oracle.extractor(1000, 1.2, 8, 20, 7)
+    ref = [oex.extract(im, (0, 1000)) for im in distinct]
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(np.stack([distinct[i % 4] for i in range(B)])).to(dev)
+    ex = pkg.Extractor(1000, 1.2, 8, 20, 7)
+    try:
+        cap = ex.max_keypoints
+        d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev); d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(B, dtype=torch.int32, device=dev); d_mono = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        for rep in range(2):
+            ex.extract_batch_device(d_img.data_ptr(), B, 640, 480, 640, 640 * 480, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                    d_n.data_ptr(), d_mono.data_ptr(), d_st.data_ptr(), (0, 1000), st)
+            torch.cuda.synchronize()
+            assert int(d_st.abs().sum().item()) == 0
+            n = d_n.cpu().numpy(); mono = d_mono.cpu().numpy()
+            kps = d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap); desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+            for b in range(B):
+                r0, k0, d0 = ref[b % 4]
+                assert mono[b] == r0 and n[b] == len(k0)
+                _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
+                np.testing.assert_array_equal(desc[b, :n[b]], d0)
+    finally:
+        ex.close()
