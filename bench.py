@@ -62,7 +62,7 @@ def compact_line(out):
                                                "pipeline_frac", "stage_ms") if k in r}
         if "stage_ms" in line["roofline"]:
             line["roofline"]["stage_ms"] = {k: round(v, 3) for k, v in line["roofline"]["stage_ms"].items()}
-    for k in ("cpu_baseline", "speedup_vs_cpu_1core"):
+    for k in ("cpu_baseline", "speedup_vs_cpu_1core", "self_check"):
         if k in out:
             line[k] = out[k]
     if "lba" in out:
@@ -131,6 +131,29 @@ def cpu_baseline(synth, imgs, match_sets, budget_s=12.0):
                "sample": "%d frames 640x480 (extract 1000 features + SearchByBoW 1000x1000), single thread, %.1f s" % (n, dt)}
 
 
+def check_against_oracle(pkg, ex, B, cap, d_kps, d_desc, d_n, d_mono, host_imgs, n_distinct, bow, match_sets, n_sets, n_check=8):
+    """Untimed checker leg: n_check frames spread over the batch the TIMED loop left on the device (B device-resident frames read in
+    place, the large-batch schedule) are compared with the CPU oracle -- mono index, key points, descriptor bytes -- and so are the
+    SearchByBoW results of the same batch slots.  Raises SystemExit on any difference."""
+    from oracle_api import Oracle
+    o = Oracle()
+    oex = o.extractor(1000, 1.2, 8, 20, 7)
+    sched = ex.debug_last_schedule()
+    nk = d_n.cpu().numpy(); mono = d_mono.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+    picks = sorted(set(int(round(i * (B - 1) / max(n_check - 1, 1))) for i in range(n_check)))
+    for b in picks:
+        r0, k0, d0 = oex.extract(host_imgs[b % n_distinct], (0, 1000))
+        if mono[b] != r0 or nk[b] != len(k0) or any(not np.array_equal(kps[b, :nk[b]][f], k0[f]) for f in k0.dtype.names) or not np.array_equal(desc[b, :nk[b]], d0):
+            raise SystemExit("SELF-CHECK FAILED: extractor output of batch frame %d differs from the oracle" % b)
+        ms = match_sets[b % n_sets]
+        n0, m0 = o.search_by_bow(ms["dKF"], ms["validKF"], ms["angKF"], ms["fvKF"], ms["dF"], ms["angF"], ms["fvF"], 0.7, True)
+        if bow[b][0] != n0 or not np.array_equal(bow[b][1], m0):
+            raise SystemExit("SELF-CHECK FAILED: SearchByBoW result of batch slot %d differs from the oracle" % b)
+    return {"frames_checked": picks, "against": "CPU oracle (key points, descriptors, BoW matches bit-exact)", "schedule_bits": sched, "ok": True}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ORBX_BENCH_BATCH", "256")))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lba", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the untimed comparison of the timed path's results with the CPU oracle")
     ap.add_argument("--extra", action="store_true",
                     help="also time the SURVEY 8(f) legs (PoseOptimization, projection search, vocabulary transform, packets, inertial BA ...); "
                          "they go to bench_detail.json, never into the headline line")
@@ -175,7 +199,7 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     Hh, Ww = 480, 640
     # ---- synthetic inputs, resident in HBM before the timed region ----
-    n_distinct = 8
+    n_distinct = min(64, B)         # 64 different frames (octree and FAST fallback are data-dependent: a real stream has a slow-frame tail)
     host_imgs = synth.make_frames(n_distinct, seed0=100 * rank)
     reps = (B + n_distinct - 1) // n_distinct
     d_imgs = torch.from_numpy(np.concatenate([host_imgs] * reps)[:B].copy()).to(dev)
@@ -186,9 +210,10 @@ def main():
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
     d_mono = torch.zeros(B, dtype=torch.int32, device=dev)
     d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    match_sets = [synth.make_match_set(50 + i) for i in range(4)]
+    n_sets = 16
+    match_sets = [synth.make_match_set(50 + i) for i in range(n_sets)]
     matcher = pkg.Matcher(0.7, True, device=local_rank)
-    plan = matcher.bow_plan([match_sets[i % 4] for i in range(B)])
+    plan = matcher.bow_plan([match_sets[i % n_sets] for i in range(B)])
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -226,6 +251,11 @@ def main():
         raise SystemExit("extractor reported device status %r" % st[st != 0][:4])
     bow = plan.fetch(stream)
     n_kp = float(nk.mean())
+    # self-check of the timed path (untimed): 8 frames of the batch the timed loop produced -- key points, descriptors and the BoW
+    # matches of their pairs -- against the CPU oracle; a mismatch fails the run
+    self_check = None
+    if rank == 0 and not args.no_check:
+        self_check = check_against_oracle(pkg, ex, B, cap, d_kps, d_desc, d_n, d_mono, host_imgs, n_distinct, bow, match_sets, n_sets)
 
     out = {
         "metric": "tracking frames/s (ORB extract+match)", "value": value, "unit": "frames/s",
@@ -236,6 +266,10 @@ def main():
                    "bow_matches_per_pair": float(np.mean([b[0] for b in bow])), "sharding": "frames, no collective"},
         "pipeline_gbs": ALGO_BYTES_PER_FRAME * value / 1e9,
     }
+    if self_check is not None:
+        out["config"]["distinct_frames"] = n_distinct
+        out["config"]["distinct_match_sets"] = n_sets
+        out["self_check"] = self_check
 
     if rank == 0:
         # ---- roofline leg: per-stage device time with HIP events on the launch stream ----
@@ -280,7 +314,7 @@ def main():
             b = B // S
             exs = [pkg.Extractor(1000, 1.2, 8, 20, 7, device=local_rank) for _ in range(S)]
             sts = [torch.cuda.Stream(device=dev) for _ in range(S)]
-            plans = [matcher.bow_plan([match_sets[i % 4] for i in range(b)]) for _ in range(S)]
+            plans = [matcher.bow_plan([match_sets[i % n_sets] for i in range(b)]) for _ in range(S)]
 
             def step_s():
                 for i in range(S):

@@ -119,6 +119,13 @@ int orbx_debug_level_keypoints(orbx_extractor* h, int frame, int level, OrbxKeyP
  * through the kernel's overflow path (every pixel of a wave's rows goes through non-maximum suppression and emission), which
  * otherwise only pathological images reach; results must not change. */
 int orbx_debug_set_fast_corner_cap(orbx_extractor* h, int cap);
+/* Test hook: a spin kernel of `microseconds` in front of the fused resize of the upper pyramid levels (which runs on a side
+ * stream for batches >= 64 frames), so that a missing cross-stream dependency on those levels shows up as wrong results. */
+int orbx_debug_set_tail_delay(orbx_extractor* h, int microseconds);
+/* Test hook: the schedule the LAST extract call used -- bits 0-1 octree instantiation (0 node pool in HBM, 1 keys + nodes in
+ * LDS, 2 keys in the L2-resident scratch), 4 two octree launches, 8 level-0 octree started early, 16 level 0 read in place,
+ * 32 resize tail on the side stream. */
+int orbx_debug_last_schedule(orbx_extractor* h);
 
 /* ------------------------------------------------------------------------------------------------
  * Matcher -- replaces ORB_SLAM3::ORBmatcher (include/ORBmatcher.h:40-106)

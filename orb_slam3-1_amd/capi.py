@@ -81,6 +81,8 @@ lib.orbx_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_vo
 lib.orbx_debug_blurred_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
 lib.orbx_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
 lib.orbx_debug_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+lib.orbx_debug_set_tail_delay.argtypes = [C.c_void_p, C.c_int]
+lib.orbx_debug_last_schedule.argtypes = [C.c_void_p]
 lib.orbx_debug_introsort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 lib.orbx_debug_wave_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 lib.orbx_debug_fast_atan2.restype = C.c_float
@@ -239,6 +241,14 @@ class Extractor:
         """test hook: shrink the FAST kernel's per-wave corner lists so that its overflow path runs"""
         lib.orbx_debug_set_fast_corner_cap.argtypes = [C.c_void_p, C.c_int]
         _check(lib.orbx_debug_set_fast_corner_cap(self._h, int(cap)))
+
+    def debug_set_tail_delay(self, microseconds):
+        _check(lib.orbx_debug_set_tail_delay(self.h, int(microseconds)))
+
+    def debug_last_schedule(self):
+        """bits: 0-1 octree instantiation (0 node pool in HBM, 1 keys + nodes in LDS, 2 keys in the scratch), 4 two octree launches,
+        8 level-0 octree early, 16 level 0 read in place, 32 resize tail on the side stream"""
+        return int(lib.orbx_debug_last_schedule(self.h))
 
     def candidates(self, level, frame=0, cap=200000):
         out = np.zeros(cap, KP_DTYPE)

@@ -150,6 +150,9 @@ struct orbx_extractor {
     // second stream for the octree of the upper pyramid levels (their node pools are small: own launch, own LDS size)
     hipStream_t oct_stream = nullptr;
     hipEvent_t ev_oct_join = nullptr, ev_fast0 = nullptr;
+    hipEvent_t ev_tail = nullptr;        // the resize tail's levels are written (the blur on the launch stream reads them)
+    int dbg_tail_delay_us = 0;           // tests: a spin kernel in front of the resize tail (orbx_debug_set_tail_delay)
+    int last_octree_variant = 0;         // which k_octree instantiation / schedule the last enqueue used (orbx_debug_last_schedule)
     int oct_split = 0, oct_pool_hi = 0;  // levels [oct_split, nlevels) go to the second launch with a pool of oct_pool_hi nodes (0: one launch)
     size_t oct_lds_hi = 0;
     // streams for the ranges a large batch is cut into (enqueue)
@@ -441,6 +444,12 @@ int orbx_extractor::ensure_batch(int batch)
 }
 
 namespace orbx {
+// test aid: keeps a stream busy for `ticks` of the 100 MHz wall clock (orbx_debug_set_tail_delay)
+__global__ void k_debug_spin(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 // copies B frames of arbitrary row stride into pyramid level 0 (dword stores, byte loads)
 __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__ src, int row_stride, size_t src_frame_stride,
                                                      uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc L)
@@ -525,6 +534,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                                    d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride, lv0);
         };
         bool oct0_early = false;            // level 0's octree already runs beside FAST on the levels above it (below)
+        bool tail_beside = false;           // the resize tail ran on oct_stream: ev_tail orders its levels before the blur
         uint32_t* cand = d_cand.p + (size_t)f0 * cand_frame_entries;
         int* cell_cnt = d_cell_count.p + (size_t)f0 * std::max<size_t>(cells.size(), 1);
         auto launch_fast = [&](hipStream_t fs, int s0, int s1) {
@@ -544,9 +554,13 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             const bool beside = blur_s && oct_stream && n_cells > 0 && tail_strip > 0;
             hipStream_t ts = beside ? oct_stream : s;
             if (beside) { ORBX_HIP(hipEventRecord(ev_fork, s)); ORBX_HIP(hipStreamWaitEvent(ts, ev_fork, 0)); }
+            if (dbg_tail_delay_us > 0) hipLaunchKernelGGL(k_debug_spin, dim3(1), dim3(64), 0, ts, (long long)dbg_tail_delay_us * 100);
             hipLaunchKernelGGL(k_resize_tail, dim3(nB), dim3(1024), 0, ts, pyr, pyr_frame_bytes, d_levels.p, T, l_tail, nlevels);
             ORBX_LAUNCHED("k_resize_tail");
             if (beside) {
+                // the blur runs on `s` and reads EVERY level: it has to wait for the tail's levels (FAST on them may still run)
+                ORBX_HIP(hipEventRecord(ev_tail, ts));
+                tail_beside = true;
                 launch_fast(ts, tail_strip, (int)strips.size());
                 ORBX_HIP(hipEventRecord(ev_oct_join, ts));
                 // FAST on level 0 first; its octree -- the longest chain of the stage -- then runs beside FAST on levels 1..
@@ -592,7 +606,11 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             ORBX_HIP(hipEventRecord(ev_oct_join, oct_stream));
         }
         launch_octree(os, oct0_early ? 1 : 0, lv_lo, o_lds, oct_pool, o_keys);
-        if (blur_s) launch_blur(s);
+        if (blur_s) {
+            if (tail_beside) ORBX_HIP(hipStreamWaitEvent(s, ev_tail, 0));
+            launch_blur(s);
+        }
+        last_octree_variant = (oct_nodes_hbm ? 0 : (o_keys > 0 ? 1 : 2)) | (two_launches ? 4 : 0) | (oct0_early ? 8 : 0) | (in_place ? 16 : 0) | (tail_beside ? 32 : 0);
         if (two_launches) ORBX_HIP(hipStreamWaitEvent(os, ev_oct_join, 0));
         ORBX_LAUNCHED("k_octree / k_blur");
         if (marks) mark();
@@ -697,6 +715,7 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
         hipEventCreateWithFlags(&e->ev_parts_fork, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&e->oct_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_oct_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
     if (const char* env = getenv("ORBX_SERIAL")) e->serial_schedule = atoi(env) != 0;
     if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
@@ -722,6 +741,7 @@ void orbx_destroy(orbx_extractor* e)
     if (e->oct_stream) { (void)hipStreamSynchronize(e->oct_stream); (void)hipStreamDestroy(e->oct_stream); }
     if (e->ev_oct_join) (void)hipEventDestroy(e->ev_oct_join);
     if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
+    if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     for (hipStream_t s : e->aux_streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -910,6 +930,19 @@ int orbx_debug_level_keypoints(orbx_extractor* e, int frame, int level, OrbxKeyP
 
 // Test hook: shrinks the per-wave corner list of the FAST kernel so that ordinary images take its overflow path (every pixel of
 // the wave's rows goes through nms / emission).  cap <= 0 restores the default.  Takes effect at the next geometry setup.
+int orbx_debug_set_tail_delay(orbx_extractor* e, int microseconds)
+{
+    if (!e || microseconds < 0 || microseconds > 20000) return fail(ORBX_ERR_ARG, "bad tail delay");
+    e->dbg_tail_delay_us = microseconds;
+    return ORBX_OK;
+}
+
+int orbx_debug_last_schedule(orbx_extractor* e)
+{
+    if (!e) return fail(ORBX_ERR_ARG, "NULL handle");
+    return e->last_octree_variant;
+}
+
 int orbx_debug_set_fast_corner_cap(orbx_extractor* e, int cap)
 {
     if (!e) return fail(ORBX_ERR_ARG, "NULL handle");

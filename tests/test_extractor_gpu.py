@@ -254,16 +254,21 @@ def test_large_batch_other_geometries(pkg, oracle, synth, args, size):
         ex.close()
 
 
-def test_large_batch_device_api_in_place(pkg, oracle, synth):
-    """the bench's path: 64 device-resident frames read in place (level 0 = the caller's buffer, copied into the pyramid by the
-    blur), the large-batch schedule, results left on the device -- twice on the same handle, against the oracle frame by frame"""
+@pytest.mark.parametrize("B,tail_delay", [(64, 0), (96, 0), (96, 400)])
+def test_large_batch_device_api_in_place(pkg, oracle, synth, B, tail_delay):
+    """the bench's path: device-resident frames read in place (level 0 = the caller's buffer, copied into the pyramid by the
+    blur), the large-batch schedule, results left on the device -- twice on the same handle, against the oracle frame by frame.
+    B = 64 is the last batch whose octree keeps its keys in LDS (one launch); B = 96 takes the bench's schedule: keys in the
+    L2-resident scratch, two octree launches, level 0's octree started early, resize tail on the side stream.  The test asserts
+    which one ran.  With `tail_delay` a spin kernel holds the resize tail back by 0.4 ms -- far longer than FAST on the lower
+    levels -- and the upper pyramid levels are poisoned first, so a blur that does not wait for the tail reads the poison and the
+    upper levels' descriptors differ (the ordering bug of round 2, src/ORBextractor.cc:1132-1138 reads every level)."""
     import torch
-    B = 64
-    distinct = [synth.make_frame(970 + i) for i in range(4)]
+    distinct = [synth.make_frame(970 + i) for i in range(8)]
     oex = oracle.extractor(1000, 1.2, 8, 20, 7)
     ref = [oex.extract(im, (0, 1000)) for im in distinct]
     dev = torch.device("cuda", 0)
-    d_img = torch.from_numpy(np.stack([distinct[i % 4] for i in range(B)])).to(dev)
+    d_img = torch.from_numpy(np.stack([distinct[i % 8] for i in range(B)])).to(dev)
     ex = pkg.Extractor(1000, 1.2, 8, 20, 7)
     try:
         cap = ex.max_keypoints
@@ -271,14 +276,27 @@ def test_large_batch_device_api_in_place(pkg, oracle, synth):
         d_n = torch.zeros(B, dtype=torch.int32, device=dev); d_mono = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         for rep in range(2):
+            if tail_delay:
+                ex.debug_set_tail_delay(tail_delay)
+                if rep == 1:
+                    # second call: the upper levels hold the previous batch's pixels -- shift the frames by one so that stale
+                    # levels belong to ANOTHER frame
+                    d_img = torch.roll(d_img, 1, 0).contiguous()
             ex.extract_batch_device(d_img.data_ptr(), B, 640, 480, 640, 640 * 480, d_kps.data_ptr(), d_desc.data_ptr(), cap,
                                     d_n.data_ptr(), d_mono.data_ptr(), d_st.data_ptr(), (0, 1000), st)
             torch.cuda.synchronize()
+            sched = ex.debug_last_schedule()
+            assert sched & 16, "level 0 was not read in place"
+            if B == 64:
+                assert sched & 3 == 1 and not sched & 4, "B = 64 should keep the octree keys in LDS (one launch): %d" % sched
+            else:
+                assert sched & 3 == 2 and sched & 4 and sched & 8 and sched & 32, "B = 96 should take the bench's schedule: %d" % sched
             assert int(d_st.abs().sum().item()) == 0
             n = d_n.cpu().numpy(); mono = d_mono.cpu().numpy()
             kps = d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap); desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+            shift = 1 if (tail_delay and rep == 1) else 0
             for b in range(B):
-                r0, k0, d0 = ref[b % 4]
+                r0, k0, d0 = ref[(b - shift) % 8]
                 assert mono[b] == r0 and n[b] == len(k0)
                 _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
                 np.testing.assert_array_equal(desc[b, :n[b]], d0)

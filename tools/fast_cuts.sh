@@ -3,6 +3,8 @@
 # stage time of each variant tells what the stages cost in the full kernel.  Results of the cut variants are wrong by construction.
 # usage (GPU box, repo root, after `make -C orb_slam3-1_amd/csrc`):  bash tools/fast_cuts.sh
 cp orb_slam3-1_amd/liborbslam3_hip.so /tmp/lib_full.so
+# whatever happens (a failed build, a timeout, an interrupt): the full library comes back
+trap 'cp /tmp/lib_full.so orb_slam3-1_amd/liborbslam3_hip.so' EXIT
 for v in 0 1 2 3; do
   (cd orb_slam3-1_amd/csrc && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -DORBX_FAST_CUT=$v -c -o /tmp/ex_cut.o orbx_extractor.hip &&
    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../liborbslam3_hip.so dbow_vocab.o edge_packet.o lba_solver.o orbm_matcher.o /tmp/ex_cut.o pose_solver.o) || exit 1
@@ -23,4 +25,3 @@ except Exception as e:
 print("cut $v:", ex.profile_read())
 PY
 done
-cp /tmp/lib_full.so orb_slam3-1_amd/liborbslam3_hip.so
