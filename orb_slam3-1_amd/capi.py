@@ -243,12 +243,12 @@ class Extractor:
         _check(lib.orbx_debug_set_fast_corner_cap(self._h, int(cap)))
 
     def debug_set_tail_delay(self, microseconds):
-        _check(lib.orbx_debug_set_tail_delay(self.h, int(microseconds)))
+        _check(lib.orbx_debug_set_tail_delay(self._h, int(microseconds)))
 
     def debug_last_schedule(self):
         """bits: 0-1 octree instantiation (0 node pool in HBM, 1 keys + nodes in LDS, 2 keys in the scratch), 4 two octree launches,
         8 level-0 octree early, 16 level 0 read in place, 32 resize tail on the side stream"""
-        return int(lib.orbx_debug_last_schedule(self.h))
+        return int(lib.orbx_debug_last_schedule(self._h))
 
     def candidates(self, level, frame=0, cap=200000):
         out = np.zeros(cap, KP_DTYPE)

@@ -258,9 +258,10 @@ def test_large_batch_other_geometries(pkg, oracle, synth, args, size):
 def test_large_batch_device_api_in_place(pkg, oracle, synth, B, tail_delay):
     """the bench's path: device-resident frames read in place (level 0 = the caller's buffer, copied into the pyramid by the
     blur), the large-batch schedule, results left on the device -- twice on the same handle, against the oracle frame by frame.
-    B = 64 is the last batch whose octree keeps its keys in LDS (one launch); B = 96 takes the bench's schedule: keys in the
-    L2-resident scratch, two octree launches, level 0's octree started early, resize tail on the side stream.  The test asserts
-    which one ran.  With `tail_delay` a spin kernel holds the resize tail back by 0.4 ms -- far longer than FAST on the lower
+    Both batch sizes must take the bench's schedule -- octree keys in the L2-resident scratch (at 640x480 a level's candidates
+    never fit LDS: the keys-in-LDS instantiation only exists for images below about 65 k pixels, see
+    test_small_images_keep_octree_keys_in_lds), two octree launches, level 0's octree started early, resize tail on the side
+    stream -- and the test asserts that it ran (orbx_debug_last_schedule).  With `tail_delay` a spin kernel holds the resize tail back by 0.4 ms -- far longer than FAST on the lower
     levels -- and the upper pyramid levels are poisoned first, so a blur that does not wait for the tail reads the poison and the
     upper levels' descriptors differ (the ordering bug of round 2, src/ORBextractor.cc:1132-1138 reads every level)."""
     import torch
@@ -287,10 +288,7 @@ def test_large_batch_device_api_in_place(pkg, oracle, synth, B, tail_delay):
             torch.cuda.synchronize()
             sched = ex.debug_last_schedule()
             assert sched & 16, "level 0 was not read in place"
-            if B == 64:
-                assert sched & 3 == 1 and not sched & 4, "B = 64 should keep the octree keys in LDS (one launch): %d" % sched
-            else:
-                assert sched & 3 == 2 and sched & 4 and sched & 8 and sched & 32, "B = 96 should take the bench's schedule: %d" % sched
+            assert sched == (2 | 4 | 8 | 16 | 32), "not the bench's schedule: %d" % sched
             assert int(d_st.abs().sum().item()) == 0
             n = d_n.cpu().numpy(); mono = d_mono.cpu().numpy()
             kps = d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap); desc = d_desc.cpu().numpy().reshape(B, cap, 32)
@@ -300,5 +298,23 @@ def test_large_batch_device_api_in_place(pkg, oracle, synth, B, tail_delay):
                 assert mono[b] == r0 and n[b] == len(k0)
                 _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
                 np.testing.assert_array_equal(desc[b, :n[b]], d0)
+    finally:
+        ex.close()
+
+
+def test_small_images_keep_octree_keys_in_lds(pkg, oracle, synth):
+    """the other octree instantiation (k_octree<true, true>: both key buffers of a level in LDS, one launch) serves small batches
+    of small images; asserted via the schedule getter, results against the oracle"""
+    imgs = np.stack([synth.make_frame(990 + i, 256, 192) for i in range(4)])
+    oex = oracle.extractor(400, 1.2, 5, 20, 7)
+    ex = pkg.Extractor(400, 1.2, 5, 20, 7)
+    try:
+        mono, n, kps, desc = ex.extract_batch(imgs)
+        assert ex.debug_last_schedule() & 3 == 1 and not ex.debug_last_schedule() & 4
+        for b in range(4):
+            r0, k0, d0 = oex.extract(imgs[b], (0, 1000))
+            assert mono[b] == r0 and n[b] == len(k0)
+            _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
+            np.testing.assert_array_equal(desc[b, :n[b]], d0)
     finally:
         ex.close()
