@@ -432,6 +432,21 @@ int lba_shard_reduce(lba_shard* s, double lambda);
 int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double* scale_poses, double* scale_landmarks_local);
 int lba_shard_accept(lba_shard* s, int accept);
 int lba_shard_reset(lba_shard* s);     /* back to the initial estimates (benchmarks re-run without re-uploading) */
+/* The Levenberg-Marquardt loop above as ONE call, for C / C++ hosts: optimizer.optimize(max_iters) of
+ * Optimizer::BundleAdjustment (src/Optimizer.cc:60-390, called by GlobalBundleAdjustemnt :52-58 from LoopClosing.cc:2288 and
+ * Tracking.cc:2722) over a landmark shard.  Every rank (one process or thread per GPU) calls it on its own shard with the same
+ * arguments; `allreduce` is called on every rank in the same order with a DEVICE buffer of `count` doubles that must be reduced
+ * in place over all ranks (op: LBA_REDUCE_SUM / LBA_REDUCE_MAX), enqueued on `hip_stream` (the shard's stream: kernels before
+ * and after are ordered by the stream, no host synchronisation is needed) -- with RCCL the whole callback is
+ *     return ncclAllReduce(buf, buf, count, ncclDouble, op == LBA_REDUCE_MAX ? ncclMax : ncclSum, comm, (hipStream_t)hip_stream);
+ * It returns 0 on success.  Per LM trial there is one call on the reduce buffer ([S | b_schur | b_p | diag Hpp], n*n + 3n
+ * doubles) and two on packs of <= 3 scalars (chi2 / scale / solver-ok; the abort flag as a MAX so that all ranks stop together);
+ * the first iteration makes one more exchange for g2o's lambda initialisation.  allreduce == NULL / world_size == 1: no
+ * exchange (this is what lba_solve runs).  stop_flag, max_iters, lambda_init, stats: as lba_solve. */
+enum { LBA_REDUCE_SUM = 0, LBA_REDUCE_MAX = 1 };
+typedef int (*lba_allreduce_fn)(void* user, double* device_buffer, int64_t count, int op, void* hip_stream);
+int lba_shard_optimize(lba_shard* s, lba_allreduce_fn allreduce, void* user, int world_size, int max_iters, double lambda_init,
+                       const volatile uint8_t* stop_flag, LbaStats* stats);
 /* estimates of the accepted state; chi2_per_edge = e->chi2() of the last computed errors, depth_positive = isDepthPositive() */
 int lba_shard_download(lba_shard* s, double* pose_q, double* pose_t, double* points, double* chi2_per_edge, uint8_t* depth_positive);
 

@@ -16,6 +16,8 @@
 //   static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)            :40
 //   static void Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&, int&, int&, int&)     include/Optimizer.h:58
 //   static void Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&, int&, int&, int&, bool, bool)   include/Optimizer.h (src/Optimizer.cc:2383)
+//   static void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>&, const std::vector<MapPoint*>&, int, bool*, unsigned long, bool)   include/Optimizer.h:50-52
+//   static void Optimizer::GlobalBundleAdjustemnt(Map*, int, bool*, unsigned long, bool)             include/Optimizer.h:53-54
 #pragma once
 
 #include <cstdint>
@@ -674,9 +676,17 @@ inline bool LocalBundleAdjustmentGraph(KeyFrame* pKF, Map* pMap, LbaGraph& g)
 inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges)
 {
     if (!LbaWindowIsPinhole(pKF)) { Optimizer::LocalBundleAdjustment(pKF, pbStopFlag, pMap, num_fixedKF, num_OptKF, num_MPs, num_edges); return; }
-    (void)num_MPs;      // never assigned by the reference overload either (SURVEY.md B14)
     LbaGraph g;
     const bool ok = LocalBundleAdjustmentGraph(pKF, pMap, g);
+    // the fixed cameras -- key frames outside the covisibility list that see local map points -- only turn up in the walk: one
+    // of them with a second camera or a non-pinhole model would need EdgeSE3ProjectXYZToBody edges (:1366-1396) the device does
+    // not build.  The walk has only stamped mnBALocalForKF / mnBAFixedForKF, which the reference rewrites anyway.
+    for (KeyFrame* pKFi : g.kfs)
+        if (pKFi->mpCamera2 || !pKFi->mpCamera || pKFi->mpCamera->GetType() != GeometricCamera::CAM_PINHOLE) {
+            Optimizer::LocalBundleAdjustment(pKF, pbStopFlag, pMap, num_fixedKF, num_OptKF, num_MPs, num_edges);
+            return;
+        }
+    (void)num_MPs;      // never assigned by the reference overload either (SURVEY.md B14)
     num_fixedKF = g.num_fixedKF;
     if (!ok) return;                                                                // :1182-1186: the other counters keep the caller's values
     num_OptKF = g.num_OptKF; num_edges = g.num_edges;
@@ -716,6 +726,177 @@ inline void LocalBundleAdjustmentHIP(KeyFrame* pKF, bool* pbStopFlag, Map* pMap,
         pMP->UpdateNormalAndDepth();
     }
     pMap->IncreaseChangeIndex();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Drop-in for Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) (include/Optimizer.h:50-52,
+// src/Optimizer.cc:60-390) and Optimizer::GlobalBundleAdjustemnt(pMap, ...) (:52-58; callers src/LoopClosing.cc:2288 with
+// bRobust = false and src/Tracking.cc:2722 with 20 iterations).  Differences from the local window: EVERY non-bad key frame
+// of vpKFs is a free pose except the map's initial one (:125), Huber deltas sqrt(5.99) / sqrt(7.815) (:130-131) or no robust
+// kernel at all, a map point without a usable observation drops out (vbNotIncludedMP, :63, :269-277), and the results go to
+// mTcwGBA / mPosGBA / mnBAGlobalForKF unless nLoopKF is the origin key frame (:297-303, :376-388).
+// This is also the multi-GPU entry of the path: with a GbaSharding every rank -- one host thread per GPU of
+// the process that owns the map -- walks the same graph, keeps the map points [lo, hi) of its rank with all their edges,
+// and the reduced camera system is summed by ONE all-reduce per Levenberg trial (lba_shard_optimize).
+// ---------------------------------------------------------------------------------------------------------------
+struct GbaSharding {
+    int rank = 0, world = 1;        // this thread's share of the map points; world == 1: everything on `device`
+    int device = 0;
+    lba_allreduce_fn allreduce = nullptr;   // e.g. ncclAllReduce on the stream it is given
+    void* user = nullptr;
+};
+
+struct GbaGraph {
+    std::vector<KeyFrame*> kfs;             // pose vertices: the non-bad key frames of vpKFs, ascending mnId (g2o's active-vertex order)
+    std::vector<MapPoint*> mps;             // point vertices that kept an edge, ascending mnId (vertex id = mnId + maxKFid + 1, :142)
+    std::vector<bool> vbNotIncludedMP;      // indexed like vpMP (:63)
+    std::map<KeyFrame*, int> kfIndex;
+    std::map<MapPoint*, int> mpIndex;
+    std::vector<double> q, t, X;
+    std::vector<uint8_t> fixed;
+    std::vector<int32_t> ePoint, ePose;     // edges in addEdge order: vpMP order, observations in map order (:148-265)
+    std::vector<double> eObs, eW;
+    std::vector<uint8_t> eStereo;
+    double fx = 0, fy = 0, cx = 0, cy = 0, bf = 0;
+    unsigned long maxKFid = 0;
+    bool accelerated = true;                // false: an EdgeSE3ProjectXYZToBody / non-pinhole edge would be needed -> the reference
+};
+
+// src/Optimizer.cc:62-279
+inline void BundleAdjustmentGraph(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, GbaGraph& g)
+{
+    g.vbNotIncludedMP.assign(vpMP.size(), false);
+    Map* pMap = vpKFs[0]->GetMap();
+    std::map<unsigned long, KeyFrame*> vertexOfId;                                  // optimizer.vertex(pKF->mnId)
+    for (KeyFrame* pKF : vpKFs) {                                                   // :116-129
+        if (pKF->isBad()) continue;
+        vertexOfId[pKF->mnId] = pKF;
+        if (pKF->mnId > g.maxKFid) g.maxKFid = pKF->mnId;
+        if (pKF->mpCamera2 || !pKF->mpCamera || pKF->mpCamera->GetType() != GeometricCamera::CAM_PINHOLE) g.accelerated = false;
+    }
+    for (auto& kv : vertexOfId) { g.kfIndex[kv.second] = (int)g.kfs.size(); g.kfs.push_back(kv.second); }
+    g.q.resize(g.kfs.size() * 4); g.t.resize(g.kfs.size() * 3); g.fixed.resize(g.kfs.size());
+    for (size_t i = 0; i < g.kfs.size(); i++) {
+        const Sophus::SE3<float> Tcw = g.kfs[i]->GetPose();
+        const Eigen::Quaterniond qd = Tcw.unit_quaternion().cast<double>();
+        const Eigen::Vector3d td = Tcw.translation().cast<double>();
+        g.q[4 * i] = qd.x(); g.q[4 * i + 1] = qd.y(); g.q[4 * i + 2] = qd.z(); g.q[4 * i + 3] = qd.w();
+        g.t[3 * i] = td.x(); g.t[3 * i + 1] = td.y(); g.t[3 * i + 2] = td.z();
+        g.fixed[i] = g.kfs[i]->mnId == pMap->GetInitKFid();                         // :125
+    }
+    // first pass: which map points keep an edge (their vertex order is by id, their edges are in vpMP order)
+    struct Obs { KeyFrame* kf; int leftIndex; };
+    std::vector<std::vector<Obs> > usable(vpMP.size());
+    std::vector<MapPoint*> included;
+    for (size_t i = 0; i < vpMP.size(); i++) {
+        MapPoint* pMP = vpMP[i];
+        if (pMP->isBad()) continue;                                                 // :137-138 (vbNotIncludedMP stays false)
+        for (auto& obs : pMP->GetObservations()) {                                  // :151-265
+            KeyFrame* pKF = obs.first;
+            if (pKF->isBad() || pKF->mnId > g.maxKFid) continue;
+            auto it = vertexOfId.find(pKF->mnId);
+            if (it == vertexOfId.end()) continue;                                   // optimizer.vertex(pKF->mnId) == NULL
+            const int leftIndex = std::get<0>(obs.second);
+            if (leftIndex == -1) { g.accelerated = false; continue; }               // a right-camera-only observation (:231-263)
+            usable[i].push_back(Obs{it->second, leftIndex});
+        }
+        if (usable[i].empty()) g.vbNotIncludedMP[i] = true;                         // :269-273 optimizer.removeVertex(vPoint)
+        else included.push_back(pMP);
+    }
+    g.mps = included;
+    std::sort(g.mps.begin(), g.mps.end(), [](MapPoint* a, MapPoint* b) { return a->mnId < b->mnId; });
+    g.X.resize(g.mps.size() * 3);
+    for (size_t i = 0; i < g.mps.size(); i++) {
+        g.mpIndex[g.mps[i]] = (int)i;
+        const Eigen::Vector3d Xd = g.mps[i]->GetWorldPos().cast<double>();
+        g.X[3 * i] = Xd.x(); g.X[3 * i + 1] = Xd.y(); g.X[3 * i + 2] = Xd.z();
+    }
+    for (size_t i = 0; i < vpMP.size(); i++)
+        for (const Obs& o : usable[i]) {
+            KeyFrame* pKF = o.kf;
+            const cv::KeyPoint& kpUn = pKF->mvKeysUn[o.leftIndex];
+            const float ur = pKF->mvuRight[o.leftIndex];
+            g.ePoint.push_back(g.mpIndex.at(vpMP[i])); g.ePose.push_back(g.kfIndex.at(pKF));
+            g.eObs.push_back(kpUn.pt.x); g.eObs.push_back(kpUn.pt.y); g.eObs.push_back(ur >= 0 ? (double)ur : -1.0);
+            g.eW.push_back((double)pKF->mvInvLevelSigma2[kpUn.octave]);
+            g.eStereo.push_back(ur >= 0);                                           // :160 mono iff mvuRight < 0, :196 stereo
+            g.fx = pKF->fx; g.fy = pKF->fy; g.cx = pKF->cx; g.cy = pKF->cy; g.bf = pKF->mbf;
+        }
+}
+
+inline void BundleAdjustmentHIP(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations = 5, bool* pbStopFlag = NULL,
+                                const unsigned long nLoopKF = 0, const bool bRobust = true, const GbaSharding* shard = nullptr)
+{
+    GbaGraph g;
+    BundleAdjustmentGraph(vpKFs, vpMP, g);
+    if (!g.accelerated) { Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust); return; }
+    Map* pMap = vpKFs[0]->GetMap();
+    const int rank = shard ? shard->rank : 0, world = shard ? shard->world : 1;
+
+    // this rank's map points [lo, hi) of the vertex order, with all their edges (poses are replicated)
+    const int nMP = (int)g.mps.size();
+    const int base = nMP / world, rem = nMP % world;
+    const int lo = rank * base + std::min(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
+    std::vector<int32_t> ePoint, ePose;
+    std::vector<double> eObs, eW;
+    std::vector<uint8_t> eStereo;
+    for (size_t e = 0; e < g.ePoint.size(); e++)
+        if (g.ePoint[e] >= lo && g.ePoint[e] < hi) {
+            ePoint.push_back(g.ePoint[e] - lo); ePose.push_back(g.ePose[e]);
+            eObs.insert(eObs.end(), g.eObs.begin() + 3 * e, g.eObs.begin() + 3 * e + 3);
+            eW.push_back(g.eW[e]); eStereo.push_back(g.eStereo[e]);
+        }
+    LbaProblem pr;
+    pr.n_poses = (int)g.kfs.size(); pr.pose_q = g.q.data(); pr.pose_t = g.t.data(); pr.pose_fixed = g.fixed.data();
+    pr.n_points = hi - lo; pr.points = g.X.data() + 3 * (size_t)lo;
+    pr.n_edges = (int)ePoint.size(); pr.edge_point = ePoint.data(); pr.edge_pose = ePose.data(); pr.edge_obs = eObs.data();
+    pr.edge_inv_sigma2 = eW.data(); pr.edge_stereo = eStereo.data();
+    pr.fx = g.fx; pr.fy = g.fy; pr.cx = g.cx; pr.cy = g.cy; pr.bf = g.bf;
+    const float thHuber2D = sqrt(5.99), thHuber3D = sqrt(7.815);                    // :130-131 (through float; 5.99, not 5.991)
+    pr.huber_mono = bRobust ? (double)thHuber2D : 0.0; pr.huber_stereo = bRobust ? (double)thHuber3D : 0.0;
+
+    lba_shard* sh = nullptr;
+    orbslam3_hip::check(lba_shard_create(shard ? shard->device : 0, &pr, &sh));
+    std::vector<double> qo(g.q.size()), to(g.t.size()), Xo(3 * (size_t)(hi - lo));
+    LbaStats st;
+    int rc = lba_shard_optimize(sh, world > 1 ? shard->allreduce : nullptr, shard ? shard->user : nullptr, world, nIterations, 0.0,
+                                (const volatile uint8_t*)pbStopFlag, &st);           // :281-283 optimize(nIterations)
+    if (rc == ORBX_OK) rc = lba_shard_download(sh, qo.data(), to.data(), Xo.data(), nullptr, nullptr);
+    lba_shard_destroy(sh);
+    orbslam3_hip::check(rc);
+
+    const bool toMap = nLoopKF == pMap->GetOriginKF()->mnId;
+    if (rank == 0)                                                                  // key frames: identical on every rank, written once (:287-371)
+        for (KeyFrame* pKF : vpKFs) {
+            if (pKF->isBad()) continue;
+            const int i = g.kfIndex.at(pKF);
+            const Eigen::Quaterniond qd(qo[4 * i + 3], qo[4 * i], qo[4 * i + 1], qo[4 * i + 2]);
+            const Eigen::Vector3d td(to[3 * i], to[3 * i + 1], to[3 * i + 2]);
+            if (toMap) pKF->SetPose(Sophus::SE3f(qd.cast<float>(), td.cast<float>()));
+            else {
+                pKF->mTcwGBA = Sophus::SE3d(qd, td).cast<float>();
+                pKF->mnBAGlobalForKF = nLoopKF;
+                // (:304-369 count edges of key frames that moved by more than 1 m into local variables nothing reads: no effect)
+            }
+        }
+    for (size_t i = 0; i < vpMP.size(); i++) {                                      // :374-389, every rank its own map points
+        if (g.vbNotIncludedMP[i]) continue;
+        MapPoint* pMP = vpMP[i];
+        if (pMP->isBad()) continue;
+        const int j = g.mpIndex.at(pMP);
+        if (j < lo || j >= hi) continue;
+        const Eigen::Vector3d Xd(Xo[3 * (size_t)(j - lo)], Xo[3 * (size_t)(j - lo) + 1], Xo[3 * (size_t)(j - lo) + 2]);
+        if (toMap) { pMP->SetWorldPos(Xd.cast<float>()); pMP->UpdateNormalAndDepth(); }
+        else { pMP->mPosGBA = Xd.cast<float>(); pMP->mnBAGlobalForKF = nLoopKF; }
+    }
+}
+
+inline void GlobalBundleAdjustemntHIP(Map* pMap, int nIterations = 5, bool* pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true,
+                                      const GbaSharding* shard = nullptr)
+{
+    const std::vector<KeyFrame*> vpKFs = pMap->GetAllKeyFrames();                   // :54-56
+    const std::vector<MapPoint*> vpMP = pMap->GetAllMapPoints();
+    BundleAdjustmentHIP(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust, shard);
 }
 
 // void Optimizer::LocalInertialBA(KeyFrame*, bool* pbStopFlag, Map*, int&, int&, int&, int&, bool bLarge, bool bRecInit)

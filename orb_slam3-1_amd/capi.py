@@ -706,6 +706,29 @@ class LbaShard:
         lib.lba_shard_reset.argtypes = [C.c_void_p]
         _check(lib.lba_shard_reset(self._h))
 
+    ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+
+    def optimize(self, allreduce=None, world=1, max_iters=10, lambda_init=0.0, stop_flag=None):
+        """lba_shard_optimize: the whole Levenberg loop in the library.  `allreduce(device_ptr, count, op, hip_stream) -> int` is
+        called for every exchange (op 0 = sum, 1 = max; reduce `count` doubles at `device_ptr` in place over all ranks, ordered on
+        `hip_stream`); None = world size 1.  Returns the stats dict."""
+        lib.lba_shard_optimize.argtypes = [C.c_void_p, self.ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(LbaStats)]
+        err = []
+
+        def tramp(user, buf, count, op, stream):
+            try:
+                return int(allreduce(buf, int(count), int(op), stream) or 0)
+            except Exception as e:  # noqa: BLE001  (an exception must not cross the C frame)
+                err.append(e)
+                return 1
+        cb = self.ALLREDUCE_FN(tramp) if allreduce is not None else C.cast(None, self.ALLREDUCE_FN)
+        st = LbaStats()
+        rc = lib.lba_shard_optimize(self._h, cb, None, int(world), int(max_iters), float(lambda_init), _p(stop_flag), C.byref(st))
+        if err:
+            raise err[0]
+        _check(rc)
+        return _stats_dict(st)
+
     def download(self):
         k = self._pr._keep
         q = np.zeros_like(k["pose_q"]); t = np.zeros_like(k["pose_t"]); pts = np.zeros_like(k["points"])

@@ -1045,6 +1045,8 @@ struct lba_shard {
     std::vector<int> prof_stage;
     int prof_n = 0;
     hipEvent_t ev_fence = nullptr;      // stream hand-over to / from the collective's stream (lba_shard_fence_*)
+    double* d_coll = nullptr;           // lba_shard_optimize: device scratch of the scalar all-reduces (chi2 / scale / flags) ...
+    double* h_coll = nullptr;           // ... and its pinned host mirror
     void mark(int stage)
     {
         if (!profile || prof_n >= kProfMarks) return;
@@ -1324,6 +1326,7 @@ void lba_shard_destroy(lba_shard* s)
     if (s->h_scal && s->owns_hscal) (void)hipHostFree(s->h_scal);
     for (hipEvent_t e : s->prof_ev) (void)hipEventDestroy(e);
     if (s->ev_fence) (void)hipEventDestroy(s->ev_fence);
+    if (s->h_coll) (void)hipHostFree(s->h_coll);
     delete s;
 }
 
@@ -1591,6 +1594,133 @@ int lba_shard_download(lba_shard* s, double* pose_q, double* pose_t, double* poi
     return ORBX_OK;
 }
 
+// ---- Levenberg-Marquardt driver over a shard: SparseOptimizer::optimize (sparse_optimizer.cpp:354-419) driving
+// OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-169).  With an all-reduce callback this is the
+// landmark-sharded global BA of SURVEY.md 8(e) for a C / C++ host: every rank calls it on its own shard and the callback is
+// one ncclAllReduce on the stream it is given; every decision input is all-reduced, so all ranks
+// walk the same path.  Without a callback (world size 1) it is lba_solve's loop. ----
+int lba_shard_optimize(lba_shard* s, lba_allreduce_fn allreduce, void* user, int world_size, int max_iters, double lambda_init,
+                       const volatile uint8_t* stop_flag, LbaStats* stats_out)
+{
+    if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
+    if (world_size < 1 || (world_size > 1 && !allreduce)) return fail(ORBX_ERR_ARG, "world size %d needs an all-reduce callback", world_size);
+    LBA_HIP(hipSetDevice(s->device));
+    const bool dist = allreduce != nullptr && world_size > 1;
+    if (dist) {
+        // the all-reduce sits between reduce() and finish() on the shard's own stream: lambda is added afterwards, no host wait
+        s->lambda_in_reduce = false;
+        s->sync_after_reduce = false;
+        if (!s->d_coll) {
+            int r0 = s->dalloc(&s->d_coll, 16);
+            if (r0) return r0;
+            if (hipHostMalloc((void**)&s->h_coll, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess) return fail(ORBX_ERR_HIP, "hipHostMalloc failed");
+        }
+    } else {
+        s->lambda_in_reduce = true;
+        s->sync_after_reduce = false;
+    }
+    int r = ORBX_OK;
+    // scalar pack through the caller's collective: host -> device scratch -> all-reduce on the shard's stream -> host
+    auto reduce_scalars = [&](double* v, int n, int op) -> int {
+        if (!dist) return ORBX_OK;
+        for (int i = 0; i < n; i++) s->h_coll[i] = v[i];
+        LBA_HIP(hipMemcpyAsync(s->d_coll, s->h_coll, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        if (allreduce(user, s->d_coll, n, op, (void*)s->stream)) return fail(ORBX_ERR_INTERNAL, "the all-reduce callback failed");
+        LBA_HIP(hipMemcpyAsync(s->h_coll, s->d_coll, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        LBA_HIP(hipStreamSynchronize(s->stream));
+        for (int i = 0; i < n; i++) v[i] = s->h_coll[i];
+        return ORBX_OK;
+    };
+    auto reduce_system = [&]() -> int {
+        if (!dist) return ORBX_OK;
+        if (allreduce(user, s->reduce, s->reduce_len, LBA_REDUCE_SUM, (void*)s->stream)) return fail(ORBX_ERR_INTERNAL, "the all-reduce callback failed");
+        return ORBX_OK;
+    };
+    // every rank must take the same decision: the flag is MAX-reduced
+    auto terminate = [&](bool* stop) -> int {
+        double f = (stop_flag && *stop_flag) ? 1.0 : 0.0;
+        const int rr = reduce_scalars(&f, 1, LBA_REDUCE_MAX);
+        *stop = f > 0.0;
+        return rr;
+    };
+    LbaStats st;
+    std::memset(&st, 0, sizeof(st));
+    double lambda = -1, ni = 2;
+    int nBad = 0;
+    for (int it = 0; it < max_iters; it++) {
+        bool stop = false;
+        if ((r = terminate(&stop))) break;
+        if (stop) { st.stop_reason = 3; break; }
+        double currentChi = 0, mdp = 0, mdl = 0;
+        if (it > 0) lba_shard_hint_lambda(s, lambda);
+        else if (lambda_init > 0) lba_shard_hint_lambda(s, lambda_init);
+        if ((r = lba_shard_linearize(s, &currentChi, &mdp, &mdl))) break;
+        if ((r = reduce_scalars(&currentChi, 1, LBA_REDUCE_SUM))) break;
+        const double iniChi = currentChi;
+        if (it == 0) {
+            st.chi2_initial = currentChi;
+            if (lambda_init > 0) lambda = lambda_init;
+            else {
+                if (dist) {
+                    // the pose diagonals are partial sums over the shards: one lambda-free exchange, then the maximum of the summed
+                    // diagonal section; the landmark maximum is MAX-reduced (computeLambdaInit, levenberg.cpp:171-185)
+                    if ((r = lba_shard_reduce(s, 0.0)) || (r = reduce_system())) break;
+                    std::vector<double> dg((size_t)std::max(s->d.n, 1), 0.0);
+                    if (s->d.n > 0) LBA_HIP(hipMemcpyAsync(dg.data(), s->diag(), (size_t)s->d.n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                    LBA_HIP(hipStreamSynchronize(s->stream));
+                    mdp = 0;
+                    for (int k = 0; k < s->d.n; k++) mdp = std::max(mdp, std::fabs(dg[k]));
+                    if ((r = reduce_scalars(&mdl, 1, LBA_REDUCE_MAX))) break;
+                }
+                lambda = 1e-5 * std::max(mdp, mdl);
+            }
+            ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        bool stopped = false;
+        do {
+            if ((r = lba_shard_reduce(s, lambda)) || (r = reduce_system())) break;
+            double tempChi = 0, sp = 0, sl = 0;
+            const int ok2 = lba_shard_finish(s, lambda, &tempChi, &sp, &sl);
+            if (ok2 < 0) { r = ok2; break; }
+            double pack[3] = {tempChi, sl, (double)ok2};
+            if ((r = reduce_scalars(pack, 3, LBA_REDUCE_SUM))) break;
+            tempChi = pack[0]; sl = pack[1];
+            if (pack[2] < (dist ? world_size : 1) - 0.5) tempChi = std::numeric_limits<double>::max();
+            rho = currentChi - tempChi;
+            double scale = sp + sl;
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                lba_shard_accept(s, 1);
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                lba_shard_accept(s, 0);
+            }
+            qmax++;
+            st.trials++;
+            if ((r = terminate(&stopped))) break;
+        } while (rho < 0 && qmax < 10 && !stopped);
+        if (r) break;
+        st.iterations++;
+        if (it < 16) st.chi2_trace[it] = currentChi;
+        st.chi2_final = currentChi;
+        if (qmax == 10 || rho == 0) { st.stop_reason = 1; break; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) { st.stop_reason = 2; break; }
+    }
+    st.lambda = lambda;
+    if (stats_out) *stats_out = st;
+    return r;
+}
+
 // ---- single-GPU driver: optimizer.initializeOptimization(); optimizer.optimize(max_iters) ----
 int lba_create(int device, lba_solver** out)
 {
@@ -1637,61 +1767,7 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
     s->lambda_in_reduce = true;
     const size_t wanted = s->bytes_wanted, wanted_stage = s->upload_bytes;
     LbaStats st;
-    std::memset(&st, 0, sizeof(st));
-    double lambda = -1, ni = 2;
-    int nBad = 0;
-    auto terminate = [&]() { return stop_flag && *stop_flag; };
-    // SparseOptimizer::optimize (sparse_optimizer.cpp:354-419) driving OptimizationAlgorithmLevenberg::solve (:61-169)
-    for (int it = 0; it < max_iters; it++) {
-        if (terminate()) { st.stop_reason = 3; break; }
-        double currentChi = 0, mdp = 0, mdl = 0;
-        if (it > 0) lba_shard_hint_lambda(s, lambda);
-        else if (lambda_init > 0) lba_shard_hint_lambda(s, lambda_init);
-        if ((r = lba_shard_linearize(s, &currentChi, &mdp, &mdl))) break;
-        const double iniChi = currentChi;
-        if (it == 0) {
-            st.chi2_initial = currentChi;
-            lambda = lambda_init > 0 ? lambda_init : 1e-5 * std::max(mdp, mdl);     // computeLambdaInit (:171-185)
-            ni = 2; nBad = 0;
-        }
-        double rho = 0;
-        int qmax = 0;
-        bool stopped = false;
-        do {
-            if ((r = lba_shard_reduce(s, lambda))) break;
-            double tempChi = 0, sp = 0, sl = 0;
-            const int ok2 = lba_shard_finish(s, lambda, &tempChi, &sp, &sl);
-            if (ok2 < 0) { r = ok2; break; }
-            if (!ok2) tempChi = std::numeric_limits<double>::max();
-            rho = currentChi - tempChi;
-            double scale = sp + sl;
-            scale += 1e-3;
-            rho /= scale;
-            if (rho > 0 && std::isfinite(tempChi)) {
-                double alpha = 1. - std::pow((2 * rho - 1), 3);
-                alpha = std::min(alpha, 2. / 3.);
-                lambda *= std::max(1. / 3., alpha);
-                ni = 2;
-                currentChi = tempChi;
-                lba_shard_accept(s, 1);
-            } else {
-                lambda *= ni;
-                ni *= 2;
-                lba_shard_accept(s, 0);
-            }
-            qmax++;
-            st.trials++;
-            stopped = terminate();
-        } while (rho < 0 && qmax < 10 && !stopped);
-        if (r) break;
-        st.iterations++;
-        if (it < 16) st.chi2_trace[it] = currentChi;
-        st.chi2_final = currentChi;
-        if (qmax == 10 || rho == 0) { st.stop_reason = 1; break; }
-        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-        if (nBad >= 3) { st.stop_reason = 2; break; }
-    }
-    st.lambda = lambda;
+    r = lba_shard_optimize(s, nullptr, nullptr, 1, max_iters, lambda_init, stop_flag, &st);
     const auto t_solved = std::chrono::steady_clock::now();
     if (!r) r = lba_shard_download(s, pose_q_out, pose_t_out, points_out, chi2_per_edge, depth_positive);
     const auto t_down = std::chrono::steady_clock::now();

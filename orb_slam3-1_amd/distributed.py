@@ -61,7 +61,9 @@ class TorchDist:
         self.dist = dist
         self.device = device
         self.world = dist.get_world_size()
-        self._events = []           # (start, end) event pairs around the reduce-buffer all-reduces (device tensors only)
+        self.timing = True          # HIP events around the reduce-buffer all-reduces (device tensors only); off: no events at all
+        self._events = []           # (start, end) event pairs not yet folded into _ms
+        self._ms = 0.0
 
     def sum_(self, t, shard=None):
         """All-reduce of the reduce buffer.  RCCL enqueues it on torch's current stream while the shard's kernels run on the
@@ -70,28 +72,46 @@ class TorchDist:
         host synchronises the collective's stream."""
         cuda = getattr(t, "is_cuda", False)
         fences = cuda and shard is not None and hasattr(shard, "fence_out")
+        timed = cuda and self.timing
         if cuda:
             st = self.torch.cuda.current_stream(t.device)
-            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             if fences:
                 shard.fence_out(st.cuda_stream)          # the collective waits for the shard's partial sums
-            e0.record(st)
+            if timed:
+                e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+                e0.record(st)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         if cuda:
-            e1.record(st)
-            self._events.append((e0, e1))
+            if timed:
+                e1.record(st)
+                self._events.append((e0, e1))
+                self._fold(False)
             if fences:
                 shard.fence_in(st.cuda_stream)           # the shard's next kernels wait for the summed buffer
             else:
                 st.synchronize()
         return t
 
+    def _fold(self, wait):
+        """completed event pairs go into the running total and are dropped (a long-lived comm must not grow)"""
+        keep = []
+        for a, b in self._events:
+            if wait:
+                b.synchronize()
+            if b.query():
+                self._ms += a.elapsed_time(b)
+            else:
+                keep.append((a, b))
+        self._events = keep
+
     @property
     def allreduce_seconds(self):
-        """device time spent in the reduce-buffer all-reduces so far (HIP events on the collective's stream); None on CPU backends"""
-        if not self._events:
+        """device time spent in the reduce-buffer all-reduces so far (HIP events on the collective's stream); None on CPU backends
+        or when nothing was timed.  Waits for the last collective."""
+        if not self._events and self._ms == 0.0:
             return None
-        return 1e-3 * sum(a.elapsed_time(b) for a, b in self._events)
+        self._fold(True)
+        return 1e-3 * self._ms
 
     def sum_scalars(self, vals):
         t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.device)
@@ -241,3 +261,44 @@ class HipShard:
         if self.n == 0:
             return 0.0
         return float(self.tensor[self.n * self.n + 2 * self.n:].abs().max().item())
+
+
+def host_staged_allreduce(dist, torch):
+    """An all-reduce callback for capi.LbaShard.optimize() / lba_shard_optimize on a backend without device collectives (gloo
+    rehearsals with several ranks on ONE GPU): the buffer goes through host memory.  With RCCL the callback is a single
+    ncclAllReduce on the given stream instead."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    calls = {"n": 0, "doubles": 0}
+
+    def cb(dev_ptr, count, op, stream):
+        calls["n"] += 1; calls["doubles"] += count
+        if hip.hipStreamSynchronize(stream):
+            return 1
+        host = torch.empty(count, dtype=torch.float64)
+        if hip.hipMemcpy(host.data_ptr(), dev_ptr, 8 * count, 2):
+            return 1
+        dist.all_reduce(host, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        return 1 if hip.hipMemcpy(dev_ptr, host.data_ptr(), 8 * count, 1) else 0
+    cb.calls = calls
+    return cb
+
+
+def rccl_allreduce(dist, torch, device):
+    """The same callback on RCCL (backend "nccl"): the buffer is wrapped as a tensor and all-reduced on torch's current stream,
+    ordered against the shard's stream by events (the C++ form needs neither: ncclAllReduce takes the shard's stream itself)."""
+    import ctypes as C
+
+    def cb(dev_ptr, count, op, stream):
+        class _Arr:         # __cuda_array_interface__ view of the raw device pointer
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(dev_ptr), False), "version": 2}
+        t = torch.as_tensor(_Arr(), device=device)
+        ext = torch.cuda.ExternalStream(int(stream) if stream else 0, device=device)
+        cur = torch.cuda.current_stream(device)
+        cur.wait_stream(ext)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        ext.wait_stream(cur)
+        return 0
+    return cb

@@ -3,13 +3,19 @@
 //   graph <map.txt>   LocalBundleAdjustmentGraph only (no device needed): prints the counters and the flattened problem
 //   solve <map.txt>   LocalBundleAdjustmentHIP end to end (needs a HIP device): also prints the written-back map
 //   track <case.txt>  ORBmatcherHIP::SearchByProjection(Frame&, vpMapPoints, ...) and (CurrentFrame, LastFrame, th, bMono)
+//   gba_graph <map.txt>                              BundleAdjustmentGraph only (no device needed)
+//   gba <map.txt> <nLoopKF> <bRobust> <world> <its>  GlobalBundleAdjustemntHIP end to end; world > 1: one host thread per rank on
+//                                                    the same device, the all-reduce callback sums through host memory (a stand-in
+//                                                    for ncclAllReduce, which needs one GPU per rank)
 // The python tests write the inputs, parse the output and compare with what the C ABI gives for the same data.
 #define ORBSLAM3_HIP_WITH_REFERENCE
 #include "orbslam3_shim.hpp"
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <thread>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -27,6 +33,8 @@ int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, const float, cons
 int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, std::vector<std::pair<size_t, size_t> >&, const bool, const bool) { fallback("SearchForTriangulation"); return 0; }
 static bool g_reference_lba_called = false;
 void Optimizer::LocalBundleAdjustment(KeyFrame*, bool*, Map*, int&, int&, int&, int&) { g_reference_lba_called = true; }
+static bool g_reference_gba_called = false;
+void Optimizer::BundleAdjustment(const std::vector<KeyFrame*>&, const std::vector<MapPoint*>&, int, bool*, const unsigned long, const bool) { g_reference_gba_called = true; }
 void Optimizer::LocalInertialBA(KeyFrame*, bool*, Map*, int&, int&, int&, int&, bool, bool) { fallback("LocalInertialBA"); }
 int Optimizer::PoseOptimization(Frame*) { fallback("PoseOptimization"); return 0; }
 int Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*, bool) { fallback("PoseInertialOptimizationLastKeyFrame"); return 0; }
@@ -156,6 +164,138 @@ static int run_lba(const char* path, bool solve)
     return 0;
 }
 
+// ---- global BA on the toy map ----
+// the HIP runtime calls the stand-in collective needs (declared here so that the test needs no HIP headers; libamdhip64 is
+// already a dependency of liborbslam3_hip.so)
+extern "C" {
+int hipStreamSynchronize(void* stream);
+int hipMemcpy(void* dst, const void* src, size_t bytes, int kind);
+}
+
+struct HostAllReduce {          // all-reduce over `world` threads through host memory: D2H, barrier, sum / max, H2D
+    int world = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0, generation = 0;
+    std::vector<std::vector<double> > part;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const int gen = generation;
+        if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+struct RankCtx { HostAllReduce* ar; int rank; long calls = 0; long doubles = 0; };
+
+static int host_allreduce(void* user, double* dev, int64_t count, int op, void* stream)
+{
+    RankCtx* c = (RankCtx*)user;
+    HostAllReduce& A = *c->ar;
+    c->calls++; c->doubles += count;
+    if (hipStreamSynchronize(stream)) return 1;
+    A.part[c->rank].resize((size_t)count);
+    if (hipMemcpy(A.part[c->rank].data(), dev, (size_t)count * sizeof(double), 2 /* hipMemcpyDeviceToHost */)) return 1;
+    A.barrier();
+    std::vector<double> acc(A.part[0]);
+    for (int r = 1; r < A.world; r++)
+        for (int64_t i = 0; i < count; i++) acc[(size_t)i] = op == LBA_REDUCE_MAX ? std::max(acc[(size_t)i], A.part[r][(size_t)i]) : acc[(size_t)i] + A.part[r][(size_t)i];
+    A.barrier();                // everybody has read every part before anybody overwrites its own
+    return hipMemcpy(dev, acc.data(), (size_t)count * sizeof(double), 1 /* hipMemcpyHostToDevice */) ? 1 : 0;
+}
+
+static void gba_lists(ToyMap& T, std::vector<KeyFrame*>& vpKFs, std::vector<MapPoint*>& vpMP)
+{
+    // Map::GetAllKeyFrames / GetAllMapPoints: everything of THIS map, bad ones included (the optimiser skips them itself)
+    for (auto& k : T.kfs) if (k.mpMap == &T.map) vpKFs.push_back(&k);
+    for (auto& p : T.mps) if (p.mpMap == &T.map) vpMP.push_back(&p);
+    T.map.mvpAllKeyFrames = vpKFs; T.map.mvpAllMapPoints = vpMP;
+    T.map.mpOriginKF = &T.kfs[T.cur];
+}
+
+static void print_gba_graph(const ToyMap& T, const std::vector<MapPoint*>& vpMP, const GbaGraph& g)
+{
+    auto kfIdx = [&](KeyFrame* k) { for (size_t i = 0; i < T.kfs.size(); i++) if (&T.kfs[i] == k) return (int)i; return -1; };
+    auto mpIdx = [&](MapPoint* p) { for (size_t i = 0; i < T.mps.size(); i++) if (&T.mps[i] == p) return (int)i; return -1; };
+    std::printf("accelerated %d\n", (int)g.accelerated);
+    std::printf("addr_order"); { std::vector<const KeyFrame*> a; for (auto& k : T.kfs) a.push_back(&k); std::sort(a.begin(), a.end()); for (auto* k : a) std::printf(" %d", kfIdx(const_cast<KeyFrame*>(k))); } std::printf("\n");
+    std::printf("vpmp"); for (MapPoint* p : vpMP) std::printf(" %d", mpIdx(p)); std::printf("\n");
+    std::printf("not_included"); for (bool b : g.vbNotIncludedMP) std::printf(" %d", (int)b); std::printf("\n");
+    std::printf("kfs"); for (KeyFrame* k : g.kfs) std::printf(" %d", kfIdx(k)); std::printf("\n");
+    std::printf("mps"); for (MapPoint* p : g.mps) std::printf(" %d", mpIdx(p)); std::printf("\n");
+    std::printf("pose_fixed"); for (uint8_t f : g.fixed) std::printf(" %d", (int)f); std::printf("\n");
+    std::printf("pose_q"); for (double v : g.q) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("pose_t"); for (double v : g.t) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("points"); for (double v : g.X) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("edge_point"); for (int v : g.ePoint) std::printf(" %d", v); std::printf("\n");
+    std::printf("edge_pose"); for (int v : g.ePose) std::printf(" %d", v); std::printf("\n");
+    std::printf("edge_obs"); for (double v : g.eObs) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("edge_w"); for (double v : g.eW) std::printf(" %.17g", v); std::printf("\n");
+    std::printf("edge_stereo"); for (uint8_t v : g.eStereo) std::printf(" %d", (int)v); std::printf("\n");
+    std::printf("intrinsics %.17g %.17g %.17g %.17g %.17g\n", g.fx, g.fy, g.cx, g.cy, g.bf);
+    std::printf("max_kf_id %lu\n", g.maxKFid);
+}
+
+static int run_gba(const char* path, bool solve, unsigned long nLoopKF, bool bRobust, int world, int its)
+{
+    ToyMap T;
+    load_map(path, T);
+    std::vector<KeyFrame*> vpKFs;
+    std::vector<MapPoint*> vpMP;
+    gba_lists(T, vpKFs, vpMP);
+    {
+        GbaGraph g;
+        BundleAdjustmentGraph(vpKFs, vpMP, g);
+        print_gba_graph(T, vpMP, g);
+    }
+    if (!solve) {
+        // a key frame with a second camera sends the whole call to the reference
+        Pinhole second(1, 1, 0, 0);
+        T.kfs[T.cur].mpCamera2 = &second;
+        BundleAdjustmentHIP(vpKFs, vpMP, 5, nullptr, 0, true);
+        std::printf("camera2_fallback %d\n", (int)g_reference_gba_called);
+        return 0;
+    }
+    std::printf("origin_id %lu\n", T.map.GetOriginKF()->mnId);
+    bool stop = false;
+    int err = 0;
+    HostAllReduce ar;
+    ar.world = world; ar.part.resize((size_t)world);
+    std::vector<RankCtx> ctx((size_t)world);
+    auto body = [&](int rank) {
+        GbaSharding sh;
+        sh.rank = rank; sh.world = world; sh.device = 0; sh.allreduce = host_allreduce; sh.user = &ctx[(size_t)rank];
+        ctx[(size_t)rank].ar = &ar; ctx[(size_t)rank].rank = rank;
+        try { GlobalBundleAdjustemntHIP(&T.map, its, &stop, nLoopKF, bRobust, world > 1 ? &sh : nullptr); }
+        catch (const orbslam3_hip::Error& e) { std::printf("error %d %s\n", e.code, e.what()); err = e.code == ORBX_ERR_NO_DEVICE ? 3 : 4; }
+    };
+    if (world == 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < world; r++) th.emplace_back(body, r);
+        for (auto& t : th) t.join();
+        std::printf("allreduce_calls %ld doubles %ld\n", ctx[0].calls, ctx[0].doubles);
+    }
+    if (err) return err;
+    for (size_t i = 0; i < T.kfs.size(); i++) {
+        const KeyFrame& k = T.kfs[i];
+        std::printf("kf %zu %d %lu", i, k.nPoseWrites, k.mnBAGlobalForKF);
+        const Eigen::Matrix3f R = k.mTcw.rotationMatrix(), Rg = k.mTcwGBA.rotationMatrix();
+        const Eigen::Vector3f t = k.mTcw.translation(), tg = k.mTcwGBA.translation();
+        for (int j = 0; j < 9; j++) std::printf(" %.9g", R[j]);
+        for (int j = 0; j < 3; j++) std::printf(" %.9g", t[j]);
+        for (int j = 0; j < 9; j++) std::printf(" %.9g", Rg[j]);
+        for (int j = 0; j < 3; j++) std::printf(" %.9g", tg[j]);
+        std::printf("\n");
+    }
+    for (size_t i = 0; i < T.mps.size(); i++) {
+        const MapPoint& p = T.mps[i];
+        std::printf("mp %zu %d %lu %.9g %.9g %.9g %.9g %.9g %.9g\n", i, p.nNormalUpdates, p.mnBAGlobalForKF, p.mWorldPos[0], p.mWorldPos[1], p.mWorldPos[2],
+                    p.mPosGBA[0], p.mPosGBA[1], p.mPosGBA[2]);
+    }
+    return 0;
+}
+
 // track <case.txt>: one frame + one set of map points / last-frame points; prints nmatches and the frame's mvpMapPoints
 static int run_track(const char* path)
 {
@@ -231,5 +371,7 @@ int main(int argc, char** argv)
     if (mode == "graph") return run_lba(argv[2], false);
     if (mode == "solve") return run_lba(argv[2], true);
     if (mode == "track") return run_track(argv[2]);
+    if (mode == "gba_graph") return run_gba(argv[2], false, 0, true, 1, 5);
+    if (mode == "gba" && argc >= 7) return run_gba(argv[2], true, std::strtoul(argv[3], nullptr, 10), std::atoi(argv[4]) != 0, std::atoi(argv[5]), std::atoi(argv[6]));
     return 2;
 }

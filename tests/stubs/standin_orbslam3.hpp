@@ -118,6 +118,12 @@ public:
     bool IsInertial() { return mbIsInertial; }
     void IncreaseChangeIndex() { mnMapChange++; }
     long unsigned int KeyFramesInMap() { return nKeyFrames; }
+    KeyFrame* GetOriginKF() { return mpOriginKF; }
+    std::vector<KeyFrame*> GetAllKeyFrames() { return mvpAllKeyFrames; }
+    std::vector<MapPoint*> GetAllMapPoints() { return mvpAllMapPoints; }
+    KeyFrame* mpOriginKF = nullptr;
+    std::vector<KeyFrame*> mvpAllKeyFrames;
+    std::vector<MapPoint*> mvpAllMapPoints;
     std::mutex mMutexMapUpdate;
     long unsigned int mnInitKFid = 0, nKeyFrames = 0;
     bool mbIsInertial = false;
@@ -146,7 +152,8 @@ public:
     void Replace(MapPoint* p) { mpReplaced = p; mbBad = true; }
     void UpdateNormalAndDepth() { nNormalUpdates++; }
 
-    long unsigned int mnId = 0, mnBALocalForKF = 0;
+    long unsigned int mnId = 0, mnBALocalForKF = 0, mnBAGlobalForKF = 0;
+    Eigen::Vector3f mPosGBA;
     float mTrackProjX = 0, mTrackProjY = 0, mTrackDepth = 0, mTrackProjXR = 0, mTrackViewCos = 0;
     int mnTrackScaleLevel = 0;
     bool mbTrackInView = false, mbTrackInViewR = false;
@@ -223,7 +230,8 @@ public:
     Map* GetMap() { return mpMap; }
     bool IsInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
 
-    long unsigned int mnId = 0, mnBALocalForKF = 0, mnBAFixedForKF = 0;
+    long unsigned int mnId = 0, mnBALocalForKF = 0, mnBAFixedForKF = 0, mnBAGlobalForKF = 0;
+    Sophus::SE3f mTcwGBA;
     int N = 0, NLeft = -1, mnGridCols = FRAME_GRID_COLS, mnGridRows = FRAME_GRID_ROWS;
     float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
@@ -265,6 +273,8 @@ public:
 class Optimizer {
 public:
     static void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges);
+    static void BundleAdjustment(const std::vector<KeyFrame*>& vpKF, const std::vector<MapPoint*>& vpMP, int nIterations = 5, bool* pbStopFlag = NULL,
+                                 const unsigned long nLoopKF = 0, const bool bRobust = true);
     static void LocalInertialBA(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, int& num_fixedKF, int& num_OptKF, int& num_MPs, int& num_edges,
                                 bool bLarge = false, bool bRecInit = false);
     static int PoseOptimization(Frame* pFrame);

@@ -17,12 +17,14 @@ public:
     SE3 inverse() const { const Eigen::Matrix<T, 3, 3> Rt = R_.transpose(); return SE3(Rt, -(Rt * t_)); }
     Eigen::Matrix<T, 3, 1> operator*(const Eigen::Matrix<T, 3, 1>& p) const { return R_ * p + t_; }
     SE3 operator*(const SE3& o) const { return SE3(R_ * o.R_, R_ * o.t_ + t_); }
+    template <typename U> SE3<U> cast() const { return SE3<U>(R_.template cast<U>(), t_.template cast<U>()); }
 
 private:
     Eigen::Matrix<T, 3, 3> R_;
     Eigen::Matrix<T, 3, 1> t_;
 };
 typedef SE3<float> SE3f;
+typedef SE3<double> SE3d;
 
 struct SO3f {
     static Eigen::Matrix3f hat(const Eigen::Vector3f& v)

@@ -131,3 +131,24 @@ def test_lba_outlier_epilogue(pkg, oracle, synth):
     near = np.abs(r0["chi2"] - 5.991) < 1e-6
     np.testing.assert_array_equal(bad0[~near], bad1[~near])
     assert bad0.sum() > 0.03 * len(bad0)
+
+
+@pytest.mark.parametrize("robust", [True, False])
+def test_global_ba_at_config5_size(pkg, oracle, synth, robust):
+    """SURVEY.md 8(d) item 5 / BASELINE configs[4]: the global BA of 500 poses (490 free), 20 000 map points, 200 000 edges --
+    n = 2 940 reduced unknowns, i.e. the unfused factorisation path (k_chol_diag / k_chol_panel / k_chol_update per block
+    column; the fused k_chol_step path ends at 480 unknowns) -- against the oracle with Optimizer::BundleAdjustment's settings:
+    Huber sqrt(5.99) (src/Optimizer.cc:130-131, mono initialisation Tracking.cc:2722) and no robust kernel (loop closing,
+    LoopClosing.cc:2288).  Same LM path, updates within 1e-4 relative."""
+    w = synth.make_ba_window(3, n_opt=490, n_fixed=10, n_points=20000, obs_per_point=10)
+    assert len(w["edge_point"]) == 200000
+    w["huber_mono"] = float(np.float32(np.sqrt(5.99))) if robust else 0.0
+    w["huber_stereo"] = float(np.float32(np.sqrt(7.815))) if robust else 0.0
+    r0 = oracle.lba_solve(w, 4)
+    s = pkg.LbaSolver()
+    try:
+        r1 = s.solve(w, 4)
+    finally:
+        s.close()
+    assert r0["stats"]["iterations"] >= 3 and r0["stats"]["chi2_final"] < 0.5 * r0["stats"]["chi2_initial"]
+    _check(w, r0, r1)

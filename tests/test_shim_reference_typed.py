@@ -29,7 +29,8 @@ def test_reference_typed_shim_compiles(tmp_path):
 def toy(tmp_path_factory, pkg):
     exe = tmp_path_factory.mktemp("shim") / "shim_toy_map"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", STUBS, "-I", INC, os.path.join(STUBS, "shim_toy_map.cpp"),
-                           "-o", str(exe), "-L", LIBDIR, "-lorbslam3_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-o", str(exe), "-L", LIBDIR, "-lorbslam3_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"])       # libamdhip64: the host-memory all-reduce of the 2-rank global-BA mode
     return str(exe)
 
 
@@ -303,3 +304,147 @@ def test_tracking_search_adapter_last_frame(toy, tmp_path, pkg, sm, frac, b_mono
         m.close()
     assert int(d["nmatches"][0][0]) == n1 > 50
     np.testing.assert_array_equal(_ints(d["assign"][0]), a1)
+
+
+# ---- Optimizer::BundleAdjustment / GlobalBundleAdjustemnt (src/Optimizer.cc:52-390) ----
+def _gba_map(seed):
+    """the toy map of the local-BA tests plus what only the global walk meets: map points whose only observers are a bad key
+    frame or a key frame of another map (-> vbNotIncludedMP, :269-273), a bad map point, the initial key frame (fixed, :125)"""
+    m = _toy_map(seed, True)
+    w = m["w"]
+    rs = np.random.RandomState(100 + seed)
+    orphans = rs.choice(len(w["points"]), 3, replace=False)
+    for k, p in enumerate(orphans):
+        w["edge_pose"][w["edge_point"] == p] = 4 if k < 2 else 5          # key frame 4 is bad, 5 belongs to another map
+    m["mp_bad"][:] = 0; m["mp_other"][:] = 0
+    m["mp_bad"][[q for q in range(len(w["points"])) if q not in orphans][:2]] = 1
+    m["orphans"] = [int(p) for p in orphans]
+    return m
+
+
+def _expected_gba_graph(m, addr_order, vpmp):
+    """src/Optimizer.cc:62-279 restated on index arrays, independently of the shim"""
+    w = m["w"]
+    nkf = len(w["pose_q"])
+    kf_ok = [i for i in range(nkf) if not m["kf_bad"][i] and not m["kf_other"][i]]     # vpKFs holds this map's key frames; bad ones are skipped (:119)
+    kfs = sorted(kf_ok, key=lambda k: m["kf_id"][k])
+    max_id = max(m["kf_id"][k] for k in kf_ok)
+    rank = {k: r for r, k in enumerate(addr_order)}
+    obs = {}
+    for e in range(len(w["edge_point"])):
+        obs.setdefault(int(w["edge_point"][e]), {})[int(w["edge_pose"][e])] = e
+    not_included, included, edges = [], [], []
+    for p in vpmp:
+        if m["mp_bad"][p]:
+            not_included.append(0)
+            continue
+        mine = [(k, obs[p][k]) for k in sorted(obs.get(p, {}), key=lambda k: rank[k])
+                if not m["kf_bad"][k] and m["kf_id"][k] <= max_id and k in kf_ok]
+        not_included.append(int(len(mine) == 0))
+        if mine:
+            included.append(p)
+            edges += [(p, k, e) for k, e in mine]
+    mps = sorted(included, key=lambda p: m["mp_id"][p])
+    return dict(kfs=kfs, mps=mps, not_included=not_included, pose_fixed=[int(m["kf_id"][k] == m["init_id"]) for k in kfs],
+                edge_point=[mps.index(p) for p, _, _ in edges], edge_pose=[kfs.index(k) for _, k, _ in edges], edge_src=[e for _, _, e in edges],
+                max_kf_id=int(max_id))
+
+
+def _check_gba_graph(d, m):
+    x = _expected_gba_graph(m, _ints(d["addr_order"][0]), _ints(d["vpmp"][0]))
+    w = m["w"]
+    assert d["accelerated"][0] == ["1"] and int(d["max_kf_id"][0][0]) == x["max_kf_id"]
+    for k in ("kfs", "mps", "not_included", "pose_fixed", "edge_point", "edge_pose"):
+        assert _ints(d[k][0]) == x[k], k
+    src = x["edge_src"]
+    np.testing.assert_array_equal(np.array(d["edge_obs"][0], float).reshape(-1, 3), w["edge_obs"][src])
+    np.testing.assert_array_equal(np.array(d["edge_w"][0], float), w["edge_inv_sigma2"][src])
+    np.testing.assert_array_equal(_ints(d["edge_stereo"][0]), w["edge_stereo"][src])
+    np.testing.assert_array_equal(np.array(d["points"][0], float).reshape(-1, 3), w["points"][x["mps"]])
+    return x
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_gba_graph_walk_on_toy_map(toy, tmp_path, seed):
+    """the all-key-frame walk without a device: vertex order, the one fixed pose, vbNotIncludedMP, edge order"""
+    m = _gba_map(seed)
+    path = str(tmp_path / "map.txt")
+    _write_map(path, m)
+    r = subprocess.run([toy, "gba_graph", path], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _parse(r.stdout)
+    x = _check_gba_graph(d, m)
+    vpmp = _ints(d["vpmp"][0])
+    dropped = [p for p, ni in zip(vpmp, x["not_included"]) if ni]
+    assert sorted(dropped) == sorted(m["orphans"]) and sum(x["pose_fixed"]) == 1 and len(x["edge_point"]) > 200
+    assert d["camera2_fallback"][0] == ["1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loop_is_origin,robust,world", [(True, True, 1), (False, False, 1), (False, False, 2), (True, True, 2)])
+def test_gba_shim_solves_toy_map(toy, tmp_path, pkg, loop_is_origin, robust, world):
+    """GlobalBundleAdjustemntHIP end to end, on one GPU and as two landmark shards (two host threads, the all-reduce callback
+    summing through host memory): the problem it flattens, solved through the C ABI from python with the global deltas
+    (Huber sqrt(5.99) or none), gives what the shim wrote -- SetPose / SetWorldPos + UpdateNormalAndDepth when nLoopKF is the
+    origin key frame (src/Optimizer.cc:297-300, :381-385), mTcwGBA / mPosGBA / mnBAGlobalForKF otherwise (:302-303, :386-388);
+    map points without a usable observation and bad ones stay untouched"""
+    m = _gba_map(0)
+    path = str(tmp_path / "map.txt")
+    _write_map(path, m)
+    origin_id = int(m["kf_id"][m["cur"]])
+    n_loop = origin_id if loop_is_origin else origin_id + 1000
+    r = subprocess.run([toy, "gba", path, str(n_loop), str(int(robust)), str(world), "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _parse(r.stdout)
+    x = _check_gba_graph(d, m)
+    assert int(d["origin_id"][0][0]) == origin_id
+    w = m["w"]
+    prob = dict(w)
+    prob.update(pose_q=np.array(d["pose_q"][0], float).reshape(-1, 4), pose_t=np.array(d["pose_t"][0], float).reshape(-1, 3),
+                pose_fixed=np.array(_ints(d["pose_fixed"][0]), np.uint8), points=np.array(d["points"][0], float).reshape(-1, 3),
+                edge_point=np.array(_ints(d["edge_point"][0]), np.int32), edge_pose=np.array(_ints(d["edge_pose"][0]), np.int32),
+                edge_obs=np.array(d["edge_obs"][0], float).reshape(-1, 3), edge_inv_sigma2=np.array(d["edge_w"][0], float),
+                edge_stereo=np.array(_ints(d["edge_stereo"][0]), np.uint8),
+                huber_mono=float(np.float32(np.sqrt(5.99))) if robust else 0.0, huber_stereo=float(np.float32(np.sqrt(7.815))) if robust else 0.0)
+    s = pkg.LbaSolver()
+    try:
+        ref = s.solve(prob, 5)
+    finally:
+        s.close()
+    assert ref["stats"]["chi2_final"] < 0.7 * ref["stats"]["chi2_initial"]
+    if world > 1:
+        # one reduce-buffer exchange per trial (+ one for lambda initialisation) and the scalar packs
+        n = 6 * int((prob["pose_fixed"] == 0).sum())
+        calls, doubles = _ints(d["allreduce_calls"][0][:1])[0], int(d["allreduce_calls"][0][2])
+        big = ref["stats"]["trials"] + 1
+        assert doubles >= big * (n * n + 3 * n) and calls > big
+    atol = 3e-6
+    kf_rows = {int(v[0]): v for v in d["kf"]}
+    for j, k in enumerate(x["kfs"]):
+        row = kf_rows[k]
+        R = np.array(row[3:12], float).reshape(3, 3); t = np.array(row[12:15], float)
+        Rg = np.array(row[15:24], float).reshape(3, 3); tg = np.array(row[24:27], float)
+        if loop_is_origin:
+            assert int(row[1]) == 1 and int(row[2]) == 0
+            np.testing.assert_allclose(R, _rot(ref["pose_q"][j]), atol=atol); np.testing.assert_allclose(t, ref["pose_t"][j], atol=atol)
+        else:
+            assert int(row[1]) == 0 and int(row[2]) == n_loop
+            np.testing.assert_allclose(Rg, _rot(ref["pose_q"][j]), atol=atol); np.testing.assert_allclose(tg, ref["pose_t"][j], atol=atol)
+            np.testing.assert_allclose(t, w["pose_t"][k], atol=1e-6)               # the map's pose is left alone
+    for k in set(range(len(w["pose_q"]))) - set(x["kfs"]):                        # bad / other-map key frames
+        assert int(kf_rows[k][1]) == 0 and int(kf_rows[k][2]) == 0
+    mp_rows = {int(v[0]): v for v in d["mp"]}
+    for j, p in enumerate(x["mps"]):
+        row = mp_rows[p]
+        pos, gpos = np.array(row[3:6], float), np.array(row[6:9], float)
+        if loop_is_origin:
+            assert int(row[1]) == 1 and int(row[2]) == 0
+            np.testing.assert_allclose(pos, ref["points"][j].astype(np.float32), rtol=0, atol=atol)
+        else:
+            assert int(row[1]) == 0 and int(row[2]) == n_loop
+            np.testing.assert_allclose(gpos, ref["points"][j].astype(np.float32), rtol=0, atol=atol)
+            np.testing.assert_allclose(pos, w["points"][p].astype(np.float32), rtol=0, atol=1e-6)
+    for p in set(range(len(w["points"]))) - set(x["mps"]):                        # vbNotIncludedMP, bad and other-map points
+        assert int(mp_rows[p][1]) == 0 and int(mp_rows[p][2]) == 0
+        np.testing.assert_allclose(np.array(mp_rows[p][3:6], float), w["points"][p].astype(np.float32), rtol=0, atol=1e-6)
+    assert len(set(range(len(w["points"]))) - set(x["mps"])) >= 5
