@@ -58,20 +58,30 @@ def compact_line(out):
     line = {k: out[k] for k in keep if k in out}
     if "roofline" in out:
         r = out["roofline"]
-        line["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms", "launch_ms_from",
+        line["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms",
                                                "pipeline_frac", "stage_ms") if k in r}
         if "stage_ms" in line["roofline"]:
             line["roofline"]["stage_ms"] = {k: round(v, 3) for k, v in line["roofline"]["stage_ms"].items()}
-    for k in ("cpu_baseline", "speedup_vs_cpu_1core", "self_check"):
+    for k in ("cpu_baseline", "speedup_vs_cpu_1core"):
         if k in out:
             line[k] = out[k]
+    if "self_check" in out:
+        line["self_check"] = {"ok": out["self_check"]["ok"], "frames_vs_oracle": len(out["self_check"]["frames_checked"])}
+    if out.get("n_gpus", 1) > 1 and "roofline" in line:       # the N > 1 line carries two more legs: the per-stage times stay in the N = 1 line
+        line["roofline"].pop("stage_ms", None)
     if "lba" in out:
         l = out["lba"]
         line["lba"] = {k: l[k] for k in ("metric", "value", "unit", "dtype", "ms_per_iteration", "ms_per_trial", "roofline", "cpu_baseline",
                                           "speedup_vs_cpu_1core", "workload") if k in l}
+    if "stereo" in out:
+        line["stereo"] = {k: out["stereo"][k] for k in ("value", "unit", "ms_per_step", "stereo_matches_per_frame") if k in out["stereo"]}
     if "gba" in out:        # the short form of the sharded global-BA leg (N > 1); the full record is in bench_detail.json
         g = out["gba"]
         line["gba"] = {k: g[k] for k in ("error", "iters_per_s", "iterations", "trials", "allreduce_bytes_per_trial") if k in g}
+        if "workload" in g:
+            line["gba"]["workload"] = "500 KF / 20 k MP / 200 k edges"
+        if "c_abi_driver" in g:
+            line["gba"]["c_abi_driver"] = {k: g["c_abi_driver"][k] for k in ("iters_per_s", "same_path_as_python_driver", "skipped") if k in g["c_abi_driver"]}
         if "roofline" in g:
             line["gba"]["roofline"] = {k: g["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac") if k in g["roofline"]}
     line["detail"] = "gpurun_out/bench_detail.json"
@@ -128,7 +138,7 @@ def cpu_baseline(synth, imgs, match_sets, budget_s=12.0):
         one(i)
     dt = time.perf_counter() - t0
     return o, {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "%d frames 640x480 (extract 1000 features + SearchByBoW 1000x1000), single thread, %.1f s" % (n, dt)}
+               "sample": "%d frames (extract + SearchByBoW), 1 thread, %.1f s" % (n, dt)}
 
 
 def check_against_oracle(pkg, ex, B, cap, d_kps, d_desc, d_n, d_mono, host_imgs, n_distinct, bow, match_sets, n_sets, n_check=8):
@@ -187,6 +197,7 @@ def main():
         import torch.distributed as dist
         import datetime
         backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
+        backend_is_nccl = backend == "nccl"
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
@@ -695,6 +706,47 @@ def main():
                                                       "sample": "3 solves of the same window"}
                 out["inertial_ba"]["speedup_vs_cpu_1core"] = out["inertial_ba"]["value"] / (rc["stats"]["iterations"] / dtc)
 
+    # ---- stereo streams: two extractions per frame with vLappingArea = {0, 0} (src/Frame.cc:122-125, two
+    # ORBextractor instances) + Frame::ComputeStereoMatches, B/2 rectified pairs per GPU, sharded like the mono frames ----
+    if (world > 1 or args.extra) and not args.no_lba:
+        Bs = B // 2
+        exL = pkg.Extractor(1000, 1.2, 8, 20, 7, device=local_rank)
+        exR = pkg.Extractor(1000, 1.2, 8, 20, 7, device=local_rank)
+        d_left = d_imgs[:Bs]
+        d_right = torch.roll(d_left, -12, dims=2).contiguous()          # the same scene 12 px to the left: a constant disparity
+        so = []
+        for _ in range(2):
+            so.append(dict(kps=torch.zeros(Bs * cap * 28, dtype=torch.uint8, device=dev), desc=torch.zeros(Bs * cap * 32, dtype=torch.uint8, device=dev),
+                           n=torch.zeros(Bs, dtype=torch.int32, device=dev), mono=torch.zeros(Bs, dtype=torch.int32, device=dev),
+                           st=torch.zeros(Bs, dtype=torch.int32, device=dev)))
+        d_ur = torch.zeros(Bs * cap, dtype=torch.float32, device=dev); d_dp = torch.zeros(Bs * cap, dtype=torch.float32, device=dev)
+
+        def sstep():
+            for e_, im, o_ in ((exL, d_left, so[0]), (exR, d_right, so[1])):
+                e_.extract_batch_device(im.data_ptr(), Bs, Ww, Hh, Ww, Ww * Hh, o_["kps"].data_ptr(), o_["desc"].data_ptr(), cap,
+                                        o_["n"].data_ptr(), o_["mono"].data_ptr(), o_["st"].data_ptr(), (0, 0), stream)
+            exL.stereo_matches_device(exR, Bs, so[0]["kps"].data_ptr(), so[0]["desc"].data_ptr(), so[0]["n"].data_ptr(),
+                                      so[1]["kps"].data_ptr(), so[1]["desc"].data_ptr(), so[1]["n"].data_ptr(), cap, 0.11, 47.9,
+                                      d_ur.data_ptr(), d_dp.data_ptr(), stream)
+        for _ in range(2):
+            sstep()
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            sstep()
+        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dts], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt.item())
+        if rank == 0:
+            matched = float((d_ur.view(Bs, cap) >= 0).sum(1).float().mean().item())
+            out["stereo"] = {"metric": "stereo frames/s (2 x ORB extract with vLappingArea {0,0} + ComputeStereoMatches)", "value": world * Bs * 10 / dts,
+                             "unit": "stereo frames/s", "ms_per_step": 1e3 * dts / 10, "pairs_per_gpu_step": Bs, "n_gpus": world,
+                             "stereo_matches_per_frame": matched, "status_ok": bool((so[0]["st"] == 0).all().item() and (so[1]["st"] == 0).all().item())}
+        exL.close(); exR.close()
+
     # ---- sharded global BA with one RCCL all-reduce per LM trial (N>1) ----
     gba_failed = False
     if world > 1 and not args.no_lba:
@@ -703,14 +755,16 @@ def main():
 
         def _bail():        # a stalled collective must not reach the driver as a successful run: print what we have, then fail
             if rank == 0:
-                out["gba"] = {"error": "watchdog: sharded global BA leg exceeded 150 s"}
+                out["gba"] = {"error": "watchdog: sharded global BA / stereo leg exceeded 240 s"}
                 print(json.dumps(compact_line(out)), flush=True)
             os._exit(3)
-        wd = threading.Timer(150.0, _bail)
+        wd = threading.Timer(240.0, _bail)
         wd.daemon = True
         wd.start()
         try:
-            wg = synth.make_ba_window(3, n_opt=190, n_fixed=10, n_points=8000, obs_per_point=10)
+            # one sharded global BA of 500 poses / 20 k points / 200 k edges (69 MB reduce buffer per trial)
+            wg = synth.make_ba_window(3, n_opt=490, n_fixed=10, n_points=20000, obs_per_point=10)
+            wg["huber_mono"] = 0.0; wg["huber_stereo"] = 0.0        # loop closing: bRobust = false (src/LoopClosing.cc:2288)
             loc, _, _ = dmod.partition_landmarks(wg, rank, world)
             sh = pkg.LbaShard(loc, device=local_rank)
             ad = dmod.HipShard(sh, torch, dev)
@@ -726,13 +780,41 @@ def main():
                 # ring-free bound of a sum over G peers on point-to-point xGMI: reduce-scatter + all-gather moves 2 (G-1)/G of the
                 # buffer per GPU over its 7 links
                 ar_gbs = (2.0 * (world - 1) / world) * ar_bytes * gs["trials"] / max(ar_s, 1e-9) / 1e9 if ar_s else None
-                out["gba"] = {"workload": "200 KF / 8000 MP / %d edges, landmarks sharded over %d GPUs" % (len(wg["edge_point"]), world),
+                out["gba"] = {"workload": "500 KF (490 free) / 20000 MP / %d edges, no robust kernel, landmarks sharded over %d GPUs, optimize(5)" % (len(wg["edge_point"]), world),
                               "allreduce_bytes_per_trial": ar_bytes, "iterations": gs["iterations"], "trials": gs["trials"],
                               "seconds": dtg, "iters_per_s": gs["iterations"] / dtg, "chi2_initial": gs["chi2_initial"], "chi2_final": gs["chi2_final"],
                               "roofline": {"bound": "xgmi", "achieved": ar_gbs, "peak": XGMI_PEAK_GBS, "unit": "GB/s",
                                            "frac": (ar_gbs / XGMI_PEAK_GBS) if ar_gbs else None,
                                            "allreduce_seconds_total": ar_s, "note": "device time of the all-reduces (events on the collective's stream)"}}
             sh.close()
+            # the same solve through the C-ABI driver (lba_shard_optimize + all-reduce callback; a C++ host passes ncclAllReduce).
+            # The callback wraps the library's raw device pointers as tensors: every rank first checks locally that this works
+            # and the ranks agree (MIN) before any of them enters the collective loop.
+            cb2, ok_local = None, 1.0
+            try:
+                cb2 = dmod.rccl_allreduce(dist, torch, dev) if backend_is_nccl else dmod.host_staged_allreduce(dist, torch)
+                if backend_is_nccl:
+                    probe = torch.arange(4, dtype=torch.float64, device=dev)
+                    ok_local = 1.0 if dmod.wrap_device_doubles(torch, probe.data_ptr(), 4, dev).sum().item() == 6.0 else 0.0
+            except Exception as e:  # noqa: BLE001
+                log("rank %d: C-ABI driver leg unavailable: %r" % (rank, e))
+                ok_local = 0.0
+            okt = torch.tensor([ok_local], dtype=torch.float64, device=dev if backend_is_nccl else "cpu")
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if okt.item() > 0.5:
+                sh2 = pkg.LbaShard(loc, device=local_rank)
+                dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                cs = sh2.optimize(cb2, world, max_iters=5)
+                torch.cuda.synchronize()
+                dtc2 = time.perf_counter() - t0
+                if rank == 0:
+                    out["gba"]["c_abi_driver"] = {"iterations": cs["iterations"], "trials": cs["trials"], "seconds": dtc2, "chi2_final": cs["chi2_final"],
+                                                  "iters_per_s": cs["iterations"] / dtc2,
+                                                  "same_path_as_python_driver": (cs["iterations"], cs["trials"]) == (gs["iterations"], gs["trials"])}
+                sh2.close()
+            elif rank == 0:
+                out["gba"]["c_abi_driver"] = {"skipped": "raw device pointers could not be wrapped as tensors on some rank"}
         except Exception as e:     # the frame-sharded headline number stands on its own, but the run is reported as failed
             gba_failed = True
             log("rank %d: sharded global BA failed: %r" % (rank, e))

@@ -441,8 +441,8 @@ int lba_shard_reset(lba_shard* s);     /* back to the initial estimates (benchma
  *     return ncclAllReduce(buf, buf, count, ncclDouble, op == LBA_REDUCE_MAX ? ncclMax : ncclSum, comm, (hipStream_t)hip_stream);
  * It returns 0 on success.  Per LM trial there is one call on the reduce buffer ([S | b_schur | b_p | diag Hpp], n*n + 3n
  * doubles) and two on packs of <= 3 scalars (chi2 / scale / solver-ok; the abort flag as a MAX so that all ranks stop together);
- * the first iteration makes one more exchange for g2o's lambda initialisation.  allreduce == NULL / world_size == 1: no
- * exchange (this is what lba_solve runs).  stop_flag, max_iters, lambda_init, stats: as lba_solve. */
+ * the first iteration makes one more exchange for g2o's lambda initialisation.  allreduce == NULL (world_size must be 1 then):
+ * no exchange -- this is what lba_solve runs.  stop_flag, max_iters, lambda_init, stats: as lba_solve. */
 enum { LBA_REDUCE_SUM = 0, LBA_REDUCE_MAX = 1 };
 typedef int (*lba_allreduce_fn)(void* user, double* device_buffer, int64_t count, int op, void* hip_stream);
 int lba_shard_optimize(lba_shard* s, lba_allreduce_fn allreduce, void* user, int world_size, int max_iters, double lambda_init,

@@ -1605,7 +1605,7 @@ int lba_shard_optimize(lba_shard* s, lba_allreduce_fn allreduce, void* user, int
     if (!s) return fail(ORBX_ERR_ARG, "NULL shard");
     if (world_size < 1 || (world_size > 1 && !allreduce)) return fail(ORBX_ERR_ARG, "world size %d needs an all-reduce callback", world_size);
     LBA_HIP(hipSetDevice(s->device));
-    const bool dist = allreduce != nullptr && world_size > 1;
+    const bool dist = allreduce != nullptr;         // a callback is always used, also by a communicator of one rank
     if (dist) {
         // the all-reduce sits between reduce() and finish() on the shard's own stream: lambda is added afterwards, no host wait
         s->lambda_in_reduce = false;

@@ -286,15 +286,18 @@ def host_staged_allreduce(dist, torch):
     return cb
 
 
+def wrap_device_doubles(torch, dev_ptr, count, device):
+    """a float64 tensor view of `count` doubles at a raw device pointer (no copy)"""
+    class _Arr:         # __cuda_array_interface__ view
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(dev_ptr), False), "version": 2}
+    return torch.as_tensor(_Arr(), device=device)
+
+
 def rccl_allreduce(dist, torch, device):
     """The same callback on RCCL (backend "nccl"): the buffer is wrapped as a tensor and all-reduced on torch's current stream,
     ordered against the shard's stream by events (the C++ form needs neither: ncclAllReduce takes the shard's stream itself)."""
-    import ctypes as C
-
     def cb(dev_ptr, count, op, stream):
-        class _Arr:         # __cuda_array_interface__ view of the raw device pointer
-            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(dev_ptr), False), "version": 2}
-        t = torch.as_tensor(_Arr(), device=device)
+        t = wrap_device_doubles(torch, dev_ptr, count, device)
         ext = torch.cuda.ExternalStream(int(stream) if stream else 0, device=device)
         cur = torch.cuda.current_stream(device)
         cur.wait_stream(ext)

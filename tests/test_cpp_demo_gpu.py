@@ -16,3 +16,17 @@ def test_frontend_demo_builds_and_runs(tmp_path):
                            "-L", libdir, "-lorbslam3_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "frontend demo OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_gba_rccl_demo_builds_and_runs(tmp_path):
+    """examples/gba_rccl_demo.cpp: the sharded global BA from plain C++ with the all-reduce callback being ONE ncclAllReduce on
+    the shard's stream (RCCL communicator over every visible GPU; on the one-GPU test box a communicator of one rank, which
+    still goes through the callback for every exchange), checked against lba_solve on the same map"""
+    exe = tmp_path / "gba_rccl_demo"
+    libdir = os.path.join(ROOT, "orb_slam3-1_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "gba_rccl_demo.cpp"), "-L", libdir, "-lorbslam3_hip", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64",
+                           "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], stderr=subprocess.DEVNULL)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "gba rccl demo OK" in r.stdout, r.stdout + r.stderr[-2000:]

@@ -164,6 +164,13 @@ def test_sharded_hip_path_world1(pkg, synth):
         np.testing.assert_array_equal(sh.download()["points"], out["points"])
         assert stats2["chi2_final"] == stats["chi2_final"]
         sh.close()
+        # the C-ABI Levenberg driver with the all-reduce callback on RCCL (what bench.py's N > 1 global-BA leg runs)
+        sh3 = pkg.LbaShard(w)
+        st3 = sh3.optimize(d.rccl_allreduce(dist, torch, dev), 1, max_iters=10)
+        out3 = sh3.download()
+        sh3.close()
+        assert (st3["iterations"], st3["trials"], st3["stop_reason"]) == (ref["stats"]["iterations"], ref["stats"]["trials"], ref["stats"]["stop_reason"])
+        np.testing.assert_allclose(out3["points"], ref["points"], rtol=0, atol=1e-10)
     finally:
         dist.destroy_process_group()
 
