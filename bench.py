@@ -58,7 +58,7 @@ def compact_line(out):
     line = {k: out[k] for k in keep if k in out}
     if "roofline" in out:
         r = out["roofline"]
-        line["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms",
+        line["roofline"] = {k: r[k] for k in ("bound", "valu_issue_frac", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms",
                                                "pipeline_frac", "stage_ms") if k in r}
         if "stage_ms" in line["roofline"]:
             line["roofline"]["stage_ms"] = {k: round(v, 3) for k, v in line["roofline"]["stage_ms"].items()}
@@ -301,16 +301,37 @@ def main():
         achieved = sb[dom] * B / (acc[dom] * 1e-3) / 1e9
         # PMC counters cannot be read from inside the process: `traffic` is the HBM bytes per launch of the same kernel from the
         # separate rocprofv3 --pmc passes (tools/gpu_round.sh -> profiles/pmc_traffic.json), labelled as such, or null.
+        # The file carries a hash of the kernel sources it was measured on: a stale file gives `traffic: null` and the reason.
         traffic, traffic_from = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from collect_pmc import kernel_sources_sha
                 tj = json.load(open(tpath))
-                traffic = tj.get(dom)
-                traffic_from = "profiles/pmc_traffic.json"
+                if tj.get("_kernel_sources_sha") == kernel_sources_sha(ROOT):
+                    traffic = tj.get(dom)
+                    traffic_from = "profiles/pmc_traffic.json"
+                else:
+                    traffic_from = "null: profiles/pmc_traffic.json was taken on other kernel sources"
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # What actually bounds the kernel (profiles/r03_a_valu_rates.txt): vector-instruction ISSUE.  valu_issue_frac = the kernel's
+        # wave-instructions per SIMD (SQ_INSTS_VALU of a counter pass on these sources, profiles/valu_issue.json) x the measured
+        # issue cost of its instruction class (tools/probes/valu_rates.hip: 1.8 ns for v_perm / v_pk_* / v_min3) / the launch time
+        # measured now.  `frac` stays the HBM figure of the contract.
+        bound, vfrac = "hbm", None
+        vpath = os.path.join(ROOT, "profiles", "valu_issue.json")
+        if os.path.exists(vpath):
+            try:
+                from collect_pmc import kernel_sources_sha
+                vj = json.load(open(vpath))
+                if vj.get("_kernel_sources_sha") == kernel_sources_sha(ROOT) and ("k_" + dom) in vj:
+                    vfrac = vj["k_" + dom]["valu"] / vj["_simds"] * vj["_ns_per_wave_instruction_and_simd"] * 1e-6 / acc[dom]
+                    bound = "valu_issue" if vfrac > 0.5 else "hbm"
+            except Exception:
+                vfrac = None
+        out["roofline"] = {"bound": bound, "valu_issue_frac": vfrac, "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                            "pipeline_frac": ALGO_BYTES_PER_FRAME * value / 1e9 / HBM_PEAK_GBS,
                            "launch_ms": acc[dom], "launch_ms_from": "HIP events, serial schedule",

@@ -31,6 +31,18 @@ def per_kernel(dirname, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
+def kernel_sources_sha(root=ROOT):
+    """sha256 over the extractor / matcher kernel sources: the stamp that ties a counter pass to the kernels it measured
+    (bench.py prints `traffic: null` when the stamp of profiles/pmc_traffic.json is not the running sources')"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "orb_slam3-1_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.startswith(("orbx_", "orbm_")) and name.endswith((".hip", ".inc", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch_dir, write_dir, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
     fetch, nf = per_kernel(fetch_dir, "FETCH_SIZE")
@@ -42,7 +54,8 @@ def main():
         cal_w = known / (write["k_copy_level0"] * 1024.0)
     out = {"_note": "HBM bytes per launch (B=%d frames); raw counters in KiB" % batch,
            "_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --no-cpu --no-lba` (tools/gpu_round.sh)",
-           "_calibration": {"fetch_factor": cal_f, "write_factor": cal_w}, "_raw_kib": {}}
+           "_calibration": {"fetch_factor": cal_f, "write_factor": cal_w}, "_raw_kib": {},
+           "_kernel_sources_sha": kernel_sources_sha()}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
