@@ -73,6 +73,11 @@ def compact_line(out):
         l = out["lba"]
         line["lba"] = {k: l[k] for k in ("metric", "value", "unit", "dtype", "ms_per_iteration", "ms_per_trial", "roofline", "cpu_baseline",
                                           "speedup_vs_cpu_1core", "workload") if k in l}
+        if "batched" in l:
+            bl = l["batched"]
+            line["lba"]["batched"] = {k: bl[k] for k in ("error", "windows", "value", "iters_per_s_whole_call") if k in bl}
+            if "roofline" in bl:
+                line["lba"]["batched"]["roofline_frac"] = bl["roofline"]["frac"]
     if "stereo" in out:
         line["stereo"] = {k: out["stereo"][k] for k in ("value", "unit", "ms_per_step", "stereo_matches_per_frame") if k in out["stereo"]}
     if "gba" in out:        # the short form of the sharded global-BA leg (N > 1); the full record is in bench_detail.json
@@ -414,6 +419,31 @@ def main():
                           "stage_ms_per_trial": stage,
                           "lba_solve_call_ms_incl_upload": 1e3 * dt_call, "chi2_initial": stats["chi2_initial"], "chi2_final": stats["chi2_final"]}
             sh.close(); solver.close()
+
+            # ---- many windows per launch (lba_solve_batch, grid.y = window): 32 different windows of configs[3] ----
+            try:
+                n_w = 32
+                bws = [synth.make_ba_window(100 + i) for i in range(n_w)]
+                lb = pkg.LbaBatch(device=local_rank)
+                bprep = lb.prepare(bws)
+                lb.run(bprep, 10); lb.run(bprep, 10)          # sizes the per-slot arenas and pinned staging buffers
+                n_rep, b_it, b_tr, dev_ms = 3, 0, 0, 0.0
+                t0 = time.perf_counter()
+                for _ in range(n_rep):
+                    rb = lb.run(bprep, 10)
+                    dev_ms += lb.last_device_ms()
+                    b_it += sum(r_["stats"]["iterations"] for r_ in rb); b_tr += sum(r_["stats"]["trials"] for r_ in rb)
+                dtb = time.perf_counter() - t0
+                b_mflop = LBA_MFLOP_FIRST_TRIAL * b_it + LBA_MFLOP_EXTRA_TRIAL * (b_tr - b_it)
+                b_tf = b_mflop * 1e-6 / (dev_ms * 1e-3)
+                out["lba"]["batched"] = {"windows": n_w, "value": b_it / (dev_ms * 1e-3), "unit": "iters/s (aggregate, Levenberg rounds on the device, data resident)",
+                                         "iters_per_s_whole_call": b_it / dtb, "ms_per_call": 1e3 * dtb / n_rep, "device_ms_per_call": dev_ms / n_rep,
+                                         "iterations_per_call": b_it / n_rep, "trials_per_call": b_tr / n_rep,
+                                         "gain_vs_one_window": (b_it / (dev_ms * 1e-3)) / out["lba"]["value"],
+                                         "roofline": {"bound": "mfma", "achieved": b_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": b_tf / FP64_PEAK_TFLOPS}}
+                lb.close()
+            except Exception as e:  # noqa: BLE001
+                out["lba"]["batched"] = {"error": repr(e)}
 
             if args.extra:
                 # ---- independent windows side by side (one map per client session): every window has its own shard, stream and

@@ -387,6 +387,21 @@ int lba_solve(lba_solver* s, const LbaProblem* problem, const volatile uint8_t* 
               double* pose_q_out, double* pose_t_out, double* points_out,
               double* chi2_per_edge, uint8_t* depth_positive, LbaStats* stats);
 
+/* Many windows per launch (one LocalBundleAdjustment per client session / map, src/LocalMapping.cc:158):
+ * n_windows <= 64 independent problems, each solved exactly as lba_solve would solve it (bit-identical results), with ONE sequence
+ * of kernel launches per Levenberg round for all of them (grid.y = window).  outputs[i] / stats[i] belong to problems[i]; any
+ * pointer inside LbaOutputs may be NULL.  stop_flags: NULL, or one pointer per window (entries may be NULL) = that session's
+ * bool* pbStopFlag.  Windows of more than 480 reduced unknowns (80 free key frames) are refused (ORBX_ERR_CAPACITY): use lba_solve. */
+typedef struct LbaOutputs {
+    double* pose_q; double* pose_t; double* points; double* chi2_per_edge; uint8_t* depth_positive;
+} LbaOutputs;
+typedef struct lba_batch lba_batch;
+int lba_batch_create(int device, lba_batch** out);
+void lba_batch_destroy(lba_batch* b);
+int lba_solve_batch(lba_batch* b, const LbaProblem* problems, const LbaOutputs* outputs, int n_windows,
+                    const volatile uint8_t* const* stop_flags, int max_iters, double lambda_init, LbaStats* stats);
+double lba_batch_last_device_ms(const lba_batch* b);   /* device time of the last call's Levenberg rounds (HIP events) */
+
 /* Sharded global BA: landmarks (with all their edges) are partitioned over ranks, poses replicated.
  * The same entry points also drive the single-GPU lba_solve().  One outer LM iteration on every rank:
  *   lba_shard_linearize()                      errors + buildSystem on the accepted state; chi2 and max diagonals

@@ -607,6 +607,63 @@ class LbaSolver:
         return dict(pose_q=q, pose_t=t, points=pts, chi2=chi2, depth_positive=dpos, stats=_stats_dict(st))
 
 
+class LbaOutputs(C.Structure):
+    _fields_ = [("pose_q", C.c_void_p), ("pose_t", C.c_void_p), ("points", C.c_void_p), ("chi2_per_edge", C.c_void_p), ("depth_positive", C.c_void_p)]
+
+
+class LbaBatch:
+    """lba_solve_batch: many LocalBundleAdjustment windows (one per map / client session) per launch."""
+
+    def __init__(self, device=0):
+        lib.lba_batch_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.lba_batch_destroy.argtypes = [C.c_void_p]
+        lib.lba_solve_batch.argtypes = [C.c_void_p, C.POINTER(LbaProblem), C.POINTER(LbaOutputs), C.c_int, C.c_void_p, C.c_int, C.c_double, C.POINTER(LbaStats)]
+        lib.lba_batch_last_device_ms.argtypes = [C.c_void_p]
+        lib.lba_batch_last_device_ms.restype = C.c_double
+        h = C.c_void_p()
+        _check(lib.lba_batch_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.lba_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prepare(self, windows, want_outputs=True):
+        """marshal once (a benchmark re-solves the same windows): problem structs, output arrays, stats"""
+        n = len(windows)
+        prs = [_lba_problem(w) for w in windows]
+        arr = (LbaProblem * n)(*prs)
+        outs, oarr = [], (LbaOutputs * n)()
+        for i, pr in enumerate(prs):
+            k = pr._keep
+            o = dict(pose_q=np.zeros_like(k["pose_q"]), pose_t=np.zeros_like(k["pose_t"]), points=np.zeros_like(k["points"]),
+                     chi2=np.zeros(len(k["edge_point"])), depth_positive=np.zeros(len(k["edge_point"]), np.uint8))
+            outs.append(o)
+            if want_outputs:
+                oarr[i] = LbaOutputs(_p(o["pose_q"]), _p(o["pose_t"]), _p(o["points"]), _p(o["chi2"]), _p(o["depth_positive"]))
+        return dict(n=n, prs=prs, arr=arr, outs=outs, oarr=oarr, stats=(LbaStats * n)(), want=want_outputs)
+
+    def run(self, prep, max_iters=10, lambda_init=0.0, stop_flags=None):
+        flags = None
+        if stop_flags is not None:
+            flags = (C.c_void_p * prep["n"])(*[(f.ctypes.data if f is not None else None) for f in stop_flags])
+        _check(lib.lba_solve_batch(self._h, prep["arr"], prep["oarr"] if prep["want"] else None, prep["n"], flags, max_iters, lambda_init, prep["stats"]))
+        return [dict(o, stats=_stats_dict(prep["stats"][i])) for i, o in enumerate(prep["outs"])]
+
+    def solve(self, windows, max_iters=10, lambda_init=0.0, stop_flags=None):
+        return self.run(self.prepare(windows), max_iters, lambda_init, stop_flags)
+
+    def last_device_ms(self):
+        return float(lib.lba_batch_last_device_ms(self._h))
+
+
 class LbaShard:
     """One rank's share of a landmark-sharded global BA; see INTEGRATION.md."""
 

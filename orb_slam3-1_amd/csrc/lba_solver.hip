@@ -28,6 +28,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbslam3_hip.h"
@@ -123,9 +124,9 @@ __device__ inline void edge_jacobians(const Cam& c, const double* T, const doubl
 }
 
 // ---- errors of a state (SparseOptimizer::computeActiveErrors + per-edge robust chi2) ----
-__global__ __launch_bounds__(256) void k_errors(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+__device__ __forceinline__ void errors_body(Dev d, const double* __restrict__ poses, const double* __restrict__ pts, const int bx)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = bx * 256 + threadIdx.x;
     if (e >= d.nE) return;
     double Xc[3], r[3];
     pose_map(poses + 7 * (size_t)d.e_pose[e], pts + 3 * (size_t)d.e_point[e], Xc);
@@ -138,6 +139,10 @@ __global__ __launch_bounds__(256) void k_errors(Dev d, const double* __restrict_
     huber(d.cam, st, chi, rho0, rho1);
     d.err[3 * (size_t)e] = r[0]; d.err[3 * (size_t)e + 1] = r[1]; d.err[3 * (size_t)e + 2] = r[2];
     d.rho0[e] = rho0;
+}
+__global__ __launch_bounds__(256) void k_errors(Dev d, const double* __restrict__ poses, const double* __restrict__ pts)
+{
+    errors_body(d, poses, pts, (int)blockIdx.x);
 }
 
 // ---- buildSystem, landmark side: Hll, bl and the Hpl blocks W_e = B^T (rho1 Omega) A (6x3) ----
@@ -238,14 +243,14 @@ __device__ __forceinline__ void lin_landmarks_body(const Dev& d, const double* _
 }
 
 // ---- buildSystem, pose side: Hpp (6x6) and bp; one 256-thread workgroup per non-fixed pose, fixed reduction tree ----
-__global__ __launch_bounds__(256) void k_lin_all(Dev d, const double* __restrict__ poses, const double* __restrict__ pts, double lambda)
+__device__ __forceinline__ void lin_all_body(Dev d, const double* __restrict__ poses, const double* __restrict__ pts, double lambda, const int bx)
 {
     __shared__ double s_part[4][27];
-    if ((int)blockIdx.x >= d.nP) {          // landmark workgroups: 32 landmarks x 8 lanes
-        lin_landmarks_body(d, poses, pts, ((int)blockIdx.x - d.nP) * 32 + (threadIdx.x >> 3), lambda);
+    if ((int)bx >= d.nP) {          // landmark workgroups: 32 landmarks x 8 lanes
+        lin_landmarks_body(d, poses, pts, ((int)bx - d.nP) * 32 + (threadIdx.x >> 3), lambda);
         return;
     }
-    const int col = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = bx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ip = d.col_pose[col];
     const double* T = poses + 7 * (size_t)ip;
     double acc[27];      // 21 upper-triangular entries of Hpp + 6 of bp
@@ -296,12 +301,16 @@ __global__ __launch_bounds__(256) void k_lin_all(Dev d, const double* __restrict
         }
     }
 }
+__global__ __launch_bounds__(256) void k_lin_all(Dev d, const double* __restrict__ poses, const double* __restrict__ pts, double lambda)
+{
+    lin_all_body(d, poses, pts, lambda, (int)blockIdx.x);
+}
 
 // ---- deterministic scalar reductions (single workgroup) ----
 // mode 0: chi2 = sum rho0, max diagonals.  mode 1: chi2 = sum rho0, scale = sum partials.
 // The results also go to a host-mapped, coherent buffer followed by a sequence number (system-scope release), so that the
 // host reads them by polling that word instead of a device-to-host copy plus a stream synchronisation per LM trial.
-__global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode, double* __restrict__ hmap, unsigned long long seq)
+__device__ __forceinline__ void reduce_body(Dev d, int mode, double* __restrict__ hmap, unsigned long long seq, const int bx)
 {
     // fixed tree: a strided partial per thread, a butterfly inside each wave, the 16 wave results by wave 0 -- one barrier instead
     // of ten (the kernel is a single workgroup on the critical path of every Levenberg trial)
@@ -342,17 +351,25 @@ __global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode, double* __rest
         }
     }
 }
+__global__ __launch_bounds__(1024) void k_reduce(Dev d, int mode, double* __restrict__ hmap, unsigned long long seq)
+{
+    reduce_body(d, mode, hmap, seq, (int)blockIdx.x);
+}
 
 // ---- Schur, landmark side (block_solver.hpp:381-395): Dinv, db, Z_e = W_e Dinv; 8 lanes per landmark ----
-__global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
+__device__ __forceinline__ void schur_landmarks_body(Dev d, double lambda, const int bx)
 {
-    const int l = blockIdx.x * 8 + (threadIdx.x >> 3);
+    const int l = bx * 8 + (threadIdx.x >> 3);
     const int sub = threadIdx.x & 7;
     if (l >= d.nL) return;
     double A[9];
     for (int k = 0; k < 9; k++) A[k] = d.Hll[9 * (size_t)l + k] + ((k % 4 == 0) ? lambda : 0.0);
     const double* b = d.bl + 3 * (size_t)l;
     schur_landmark(d, l, sub, A, b[0], b[1], b[2]);
+}
+__global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
+{
+    schur_landmarks_body(d, lambda, (int)blockIdx.x);
 }
 
 // ---- Schur, pose side: one workgroup per 6x6 block (i<=j) of the reduced camera system ----
@@ -362,14 +379,18 @@ __global__ __launch_bounds__(64) void k_schur_landmarks(Dev d, double lambda)
 // all-reduces partial systems first and adds lambda afterwards).
 // Workgroups [nBlocks, nBlocks + nP): b_schur = b_p - sum_e W_e db_l(e) (block_solver.hpp:413,436-439), plus copies of
 // b_p and diag(Hpp) for the reduce buffer (additive over shards).
-constexpr int kSchurThreads = 1024, kSchurGroups = 28;     // 28 groups x 36 entries walk a block's pair list (the diagonal blocks
-                                                            // hold a pose's ~400 edges: with 7 groups their chains of dependent loads
-                                                            // were the kernel's time)
-__global__ __launch_bounds__(kSchurThreads) void k_schur_blocks(Dev d, double* __restrict__ S, double lambda_diag,
-                                                      double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out)
+constexpr int kSchurThreads = 256, kSchurGroups = 64;      // 64 groups of 4 lanes walk a block's pair list, a lane owns a 3 x 3 corner
+                                                            // of the 6 x 6 block.  (History: 7 groups x 36 lanes with one entry per lane:
+                                                            // the diagonal blocks' chains of dependent loads were the kernel's time; 28 x 36:
+                                                            // 22 us per window, but every lane loaded 6 doubles for 3 FMAs -- with 32 windows
+                                                            // per launch the kernel moved 7 TB/s out of the caches and took 60 % of a round.
+                                                            // A 3 x 3 corner loads 18 doubles for 27 FMAs.)
+__device__ __forceinline__ void schur_blocks_body(Dev d, double* __restrict__ S, double lambda_diag,
+                                                      double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out, const int bx)
 {
-    __shared__ double s_part[kSchurGroups][36];
-    const int blk = blockIdx.x, tid = threadIdx.x;
+    __shared__ double s_part[kSchurGroups][37];
+    __shared__ double s_seg[4][36];
+    const int blk = bx, tid = threadIdx.x;
     if (blk >= d.nBlocks) {
         const int i = blk - d.nBlocks, lane = tid & 63, wave = tid >> 6;
         double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -394,29 +415,49 @@ __global__ __launch_bounds__(kSchurThreads) void k_schur_blocks(Dev d, double* _
     }
     const int i = d.b_i[blk], j = d.b_j[blk];
     const int n = d.n;
-    const int g = tid / 36, ent = tid - g * 36;
-    if (g < kSchurGroups) {
-        const int r = ent / 6, c = ent - r * 6;
-        double acc = 0.0;
-#pragma unroll 4
+    const int g = tid >> 2, q = tid & 3, rb = q >> 1, cb = q & 1;
+    {
+        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         for (int k = d.b_off[blk] + g; k < d.b_off[blk + 1]; k += kSchurGroups) {
             const int2 pr = d.b_pair[k];
-            const double* Z = d.Z + 18 * (size_t)pr.x + r * 3;
-            const double* W = d.W + 18 * (size_t)pr.y + c * 3;
-            acc += Z[0] * W[0] + Z[1] * W[1] + Z[2] * W[2];
+            const double* Z = d.Z + 18 * (size_t)pr.x + 9 * rb;
+            const double* W = d.W + 18 * (size_t)pr.y + 9 * cb;
+            double z[9], w[9];
+#pragma unroll
+            for (int u = 0; u < 9; u++) { z[u] = Z[u]; w[u] = W[u]; }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) acc[a][b] += z[3 * a] * w[3 * b] + z[3 * a + 1] * w[3 * b + 1] + z[3 * a + 2] * w[3 * b + 2];
         }
-        s_part[g][ent] = acc;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) s_part[g][(3 * rb + a) * 6 + 3 * cb + b] = acc[a][b];
+    }
+    __syncthreads();
+    // fixed order: four segments of 16 groups, then the four segment sums
+    if (tid < 144) {
+        const int ent = tid % 36, seg = tid / 36;
+        double sum = s_part[16 * seg][ent];
+#pragma unroll
+        for (int u = 1; u < 16; u++) sum += s_part[16 * seg + u][ent];
+        s_seg[seg][ent] = sum;
     }
     __syncthreads();
     if (tid < 36) {
         const int r = tid / 6, c = tid - r * 6;
-        double sum = s_part[0][tid];
-        for (int q = 1; q < kSchurGroups; q++) sum += s_part[q][tid];
+        const double sum = ((s_seg[0][tid] + s_seg[1][tid]) + s_seg[2][tid]) + s_seg[3][tid];
         double v = ((i == j) ? d.Hpp[36 * (size_t)i + tid] : 0.0) - sum;
         if (i == j && r == c) v += lambda_diag;
         S[(size_t)(6 * i + r) * n + 6 * j + c] = v;
         if (i != j) S[(size_t)(6 * j + c) * n + 6 * i + r] = v;
     }
+}
+__global__ __launch_bounds__(kSchurThreads) void k_schur_blocks(Dev d, double* __restrict__ S, double lambda_diag,
+                                                      double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out)
+{
+    schur_blocks_body(d, S, lambda_diag, bs, bp_out, diag_out, (int)blockIdx.x);
 }
 
 __global__ void k_add_lambda(double* S, int n, double lambda)
@@ -585,8 +626,8 @@ __device__ __forceinline__ bool chol_tile_mfma(double (&Lr)[4][4], int nb, doubl
 // and is bit-compatible, but slower: 29 us per block against 22 -- the replicated pivot algebra grows with the cube of the group
 // width and outweighs the publish / barrier / operand rounds it saves.  Per 4-column group (tools/lba_step_timing.py): operands +
 // MFMA 1400-1700 cycles, pivot block + M 1000-1300, publish 475, barrier 290.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
-                                                   double* __restrict__ Linv, double* __restrict__ scal)
+__device__ __forceinline__ void chol_diag_body(const double* __restrict__ S, int n, int k0, int nb,
+                                                   double* __restrict__ Linv, double* __restrict__ scal, const int bx)
 {
     __shared__ CholVec4 sv;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -599,6 +640,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             Lr[a][b] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
         }
     if (!chol_tile_mfma(Lr, nb, Linv + (size_t)(k0 / NB) * NB * NB, sv) && tid == 0) scal[5] = 1.0;
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_diag(const double* __restrict__ S, int n, int k0, int nb,
+                                                   double* __restrict__ Linv, double* __restrict__ scal)
+{
+    chol_diag_body(S, n, k0, nb, Linv, scal, (int)blockIdx.x);
 }
 
 // One launch per block column K (instead of panel + update + the next diagonal factorisation): the workgroup of trailing
@@ -615,10 +661,9 @@ __device__ unsigned long long d_step_prof[8];
 constexpr int kFusedMaxBlocks = 8;       // up to 480 reduced unknowns (80 key frames); larger systems keep panel / update launches
 static_assert(NB + 16 * 28 >= kFusedMaxBlocks * NB, "k_chol_solve<true> prefetches at most 28 rows per row group");
 constexpr int kStepLds = (NB * (NB + 1) + 2 * 64 * (NB + 1)) * 8 + (int)sizeof(CholVec4);
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_step(double* __restrict__ S, double* __restrict__ Lp, int n, int K, int nblk,
-                                                   double* __restrict__ Linv, double* __restrict__ scal)
+__device__ __forceinline__ void chol_step_body(double* __restrict__ S, double* __restrict__ Lp, int n, int K, int nblk,
+                                                   double* __restrict__ Linv, double* __restrict__ scal, const int bx, double* __restrict__ sm_step)
 {
-    extern __shared__ __align__(16) double sm_step[];
     constexpr int P = NB + 1;
     double* sI = sm_step;
     double* sXi = sI + NB * P;
@@ -626,7 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     CholVec4& sv = *(CholVec4*)(sXj + 64 * P);
     if (scal[5] != 0.0) return;         // an earlier diagonal block was not positive definite
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    int li = 0, t = blockIdx.x;
+    int li = 0, t = bx;
     while (t > li) { t -= li + 1; li++; }
     const int bi = K + 1 + li, bj = K + 1 + t;
     const bool diag_tile = bi == bj;
@@ -755,6 +800,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (bi == K + 1 && bj == K + 1 && threadIdx.x == 0) d_step_prof[7] += 1;
 #endif
 }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_step(double* __restrict__ S, double* __restrict__ Lp, int n, int K, int nblk,
+                                                   double* __restrict__ Linv, double* __restrict__ scal)
+{
+    extern __shared__ __align__(16) double sm_step[];
+    chol_step_body(S, Lp, n, K, nblk, Linv, scal, (int)blockIdx.x, sm_step);
+}
 
 constexpr int kPanelRows = 64;
 // nr = n + 1: the right-hand side b_schur is stored right behind S in the reduce buffer, i.e. it IS row n of an
@@ -833,11 +884,10 @@ __device__ __forceinline__ double row16_sum(double v)          // sum over the 1
 // serial sweep never waits for global memory.
 constexpr int kSolvePre = 28;       // rows below the first block of a 480-unknown system / 16 row groups, rounded up
 template <bool PRE>
-__global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ S, int n, const double* __restrict__ Linv,
+__device__ __forceinline__ void chol_solve_body(const double* __restrict__ S, int n, const double* __restrict__ Linv,
                                                      const double* __restrict__ yin, const double* __restrict__ yin_last,
-                                                     double* __restrict__ x, const double* __restrict__ scal, int last_forward)
+                                                     double* __restrict__ x, const double* __restrict__ scal, int last_forward, const int bx, double* __restrict__ sm)
 {
-    extern __shared__ double sm[];      // y[n], t[64], part[16][64], Linv block [NB][NB + 1]
     constexpr int P = NB + 1;
     double* y = sm;
     double* t = sm + n;
@@ -915,13 +965,21 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
     __syncthreads();
     for (int i = tid; i < n; i += 1024) x[i] = y[i];
 }
+template <bool PRE>
+__global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ S, int n, const double* __restrict__ Linv,
+                                                     const double* __restrict__ yin, const double* __restrict__ yin_last,
+                                                     double* __restrict__ x, const double* __restrict__ scal, int last_forward)
+{
+    extern __shared__ double sm[];      // y[n], t[64], part[16][64], Linv block [NB][NB + 1]
+    chol_solve_body<PRE>(S, n, Linv, yin, yin_last, x, scal, last_forward, (int)blockIdx.x, sm);
+}
 
 // ---- landmark back-substitution, trial update (oplus) and scale partials (levenberg.cpp:187-194) ----
-__global__ __launch_bounds__(64) void k_backsub_update(Dev d, double lambda, const double* __restrict__ bp_full,
+__device__ __forceinline__ void backsub_update_body(Dev d, double lambda, const double* __restrict__ bp_full,
                                                        const double* __restrict__ poses, const double* __restrict__ pts,
-                                                       double* __restrict__ poses_new, double* __restrict__ pts_new)
+                                                       double* __restrict__ poses_new, double* __restrict__ pts_new, const int bx)
 {
-    const int g = blockIdx.x * 64 + threadIdx.x;
+    const int g = bx * 64 + threadIdx.x;
     if (g < d.nL) {
         const int l = g;
         double c[3] = {d.bl[3 * (size_t)l], d.bl[3 * (size_t)l + 1], d.bl[3 * (size_t)l + 2]};
@@ -976,6 +1034,109 @@ __global__ __launch_bounds__(64) void k_backsub_update(Dev d, double lambda, con
             d.part[d.nL + col] = sc;
         }
     }
+}
+__global__ __launch_bounds__(64) void k_backsub_update(Dev d, double lambda, const double* __restrict__ bp_full,
+                                                       const double* __restrict__ poses, const double* __restrict__ pts,
+                                                       double* __restrict__ poses_new, double* __restrict__ pts_new)
+{
+    backsub_update_body(d, lambda, bp_full, poses, pts, poses_new, pts_new, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched windows (lba_solve_batch): the SAME kernel bodies, one launch per stage for W independent windows, grid.y = window.
+// The single-workgroup stages of a window (diagonal factorisation, block-column steps, substitution, reductions) leave the chip
+// idle; W windows side by side fill it -- SURVEY.md 0 / 7 step 6: "throughput only by batching many windows per launch".
+// BWin = what the single-window launches pass by value (resident on the device, written once per batch); BDynAll = the per-round
+// state of every window (lambda, accepted-state index, which stages it takes part in), 2 KB passed by value with each launch.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMaxBatch = 64;
+struct BWin {
+    Dev d;
+    double* poses[2]; double* pts[2];
+    double* S; double* bs; double* bpf; double* diag; double* Lp; double* Linv;
+    double* hmap;               // this window's 16 host-mapped scalars
+    int nblk;
+};
+struct BDyn { double lambda, hint; unsigned long long seq; int cur, flags; };
+struct BDynAll { BDyn w[kMaxBatch]; };
+enum { kBwErrors = 1, kBwLin = 2, kBwReduce0 = 4, kBwTrial = 8, kBwSchurLm = 16 };
+
+__global__ __launch_bounds__(256) void k_errors_b(const BWin* __restrict__ wins, BDynAll dyn, int trial_state)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & (trial_state ? kBwTrial : kBwErrors))) return;
+    const BWin& w = wins[blockIdx.y];
+    if ((int)blockIdx.x * 256 >= w.d.nE) return;
+    const int st = trial_state ? 1 - y.cur : y.cur;
+    errors_body(w.d, w.poses[st], w.pts[st], (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_lin_all_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwLin)) return;
+    const BWin& w = wins[blockIdx.y];
+    if ((int)blockIdx.x >= w.d.nP + (w.d.nL + 31) / 32) return;
+    lin_all_body(w.d, w.poses[y.cur], w.pts[y.cur], y.hint, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(1024) void k_reduce_b(const BWin* __restrict__ wins, BDynAll dyn, int mode)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & (mode ? kBwTrial : kBwReduce0))) return;
+    const BWin& w = wins[blockIdx.y];
+    reduce_body(w.d, mode, w.hmap, y.seq, 0);
+}
+__global__ __launch_bounds__(64) void k_schur_landmarks_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwSchurLm)) return;
+    const BWin& w = wins[blockIdx.y];
+    if ((int)blockIdx.x * 8 >= w.d.nL) return;
+    schur_landmarks_body(w.d, y.lambda, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(kSchurThreads) void k_schur_blocks_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.d.scal[5] = 0.0;          // (the single-window path clears the failure flag with a memset)
+    if ((int)blockIdx.x >= w.d.nBlocks + w.d.nP) return;
+    schur_blocks_body(w.d, w.S, y.lambda, w.bs, w.bpf, w.diag, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_diag_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    if (w.d.n <= 0) return;
+    chol_diag_body(w.S, w.d.n, 0, min(NB, w.d.n), w.Linv, w.d.scal, 0);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_step_b(const BWin* __restrict__ wins, BDynAll dyn, int K)
+{
+    extern __shared__ __align__(16) double sm_step[];
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    const int T = w.nblk - 1 - K;
+    if (T <= 0 || (int)blockIdx.x >= T * (T + 1) / 2) return;
+    chol_step_body(w.S, w.Lp, w.d.n, K, w.nblk, w.Linv, w.d.scal, (int)blockIdx.x, sm_step);
+}
+__global__ __launch_bounds__(1024) void k_chol_solve_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    extern __shared__ double sm[];
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    const int n = w.d.n;
+    if (n <= 0) return;
+    chol_solve_body<true>(w.Lp, n, w.Linv, w.Lp + (size_t)n * n, w.bs, w.d.x, w.d.scal, 1, 0, sm);
+}
+__global__ __launch_bounds__(64) void k_backsub_update_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= w.d.nL + w.d.nPoses) return;
+    backsub_update_body(w.d, y.lambda, w.bpf, w.poses[y.cur], w.pts[y.cur], w.poses[1 - y.cur], w.pts[1 - y.cur], (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_epilogue(Dev d, const double* __restrict__ poses, const double* __restrict__ pts,
@@ -1149,6 +1310,23 @@ struct lba_solver {
 };
 
 extern "C" void lba_shard_destroy(lba_shard* s);
+
+// grow a solver's arena / pinned staging mirror so that the next window of this size needs no hipMalloc
+static void solver_grow(lba_solver* sv, size_t wanted, size_t wanted_stage)
+{
+    if (wanted > sv->arena_cap) {
+        if (sv->arena) (void)hipFree(sv->arena);
+        sv->arena = nullptr; sv->arena_cap = 0;
+        const size_t cap = wanted + wanted / 4 + (1 << 20);
+        if (hipMalloc((void**)&sv->arena, cap) == hipSuccess) sv->arena_cap = cap;
+    }
+    if (wanted_stage > sv->stage_cap) {
+        if (sv->stage) (void)hipHostFree(sv->stage);
+        sv->stage = nullptr; sv->stage_cap = 0;
+        const size_t cap = wanted_stage + wanted_stage / 4 + (1 << 16);
+        if (hipHostMalloc((void**)&sv->stage, cap) == hipSuccess) sv->stage_cap = cap;
+    }
+}
 
 static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, lba_solver* owner)
 {
@@ -1777,19 +1955,324 @@ int lba_solve(lba_solver* sv, const LbaProblem* problem, const volatile uint8_t*
         std::fprintf(stderr, "[lba_solve] structure + upload %.3f ms, %d iterations / %d trials %.3f ms, epilogue + download %.3f ms, destroy %.3f ms\n",
                      ms(t_start, t_created), st.iterations, st.trials, ms(t_created, t_solved), ms(t_solved, t_down), ms(t_down, std::chrono::steady_clock::now()));
     }
-    if (wanted > sv->arena_cap) {       // grow the arena so that the next window of this size needs no hipMalloc
-        if (sv->arena) (void)hipFree(sv->arena);
-        sv->arena = nullptr; sv->arena_cap = 0;
-        const size_t cap = wanted + wanted / 4 + (1 << 20);
-        if (hipMalloc((void**)&sv->arena, cap) == hipSuccess) sv->arena_cap = cap;
-    }
-    if (wanted_stage > sv->stage_cap) {
-        if (sv->stage) (void)hipHostFree(sv->stage);
-        sv->stage = nullptr; sv->stage_cap = 0;
-        const size_t cap = wanted_stage + wanted_stage / 4 + (1 << 16);
-        if (hipHostMalloc((void**)&sv->stage, cap) == hipSuccess) sv->stage_cap = cap;
-    }
+    solver_grow(sv, wanted, wanted_stage);
     if (stats_out) *stats_out = st;
+    return r;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// lba_solve_batch: W independent windows (one map per client session, SURVEY.md 8(e): "independent maps shard round-robin") through
+// ONE sequence of launches per Levenberg round, grid.y = window.  Every window walks exactly the path lba_solve would walk for it
+// (same kernel bodies, same order of operations -> bit-identical results); the host keeps one LM state machine per window and a
+// round is: [linearise the windows that start an iteration] + [one trial of every window that is not finished].
+// ---------------------------------------------------------------------------------------------------------------
+struct lba_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<lba_solver*> slots;     // arena + pinned staging per window slot (they grow to the windows they have seen)
+    lba::BWin* d_wins = nullptr;
+    double* h_scal = nullptr;           // host-mapped, coherent: 16 doubles per slot
+    double last_device_ms = 0.0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint8_t* h_out = nullptr;           // pinned staging of the results of all windows (one synchronisation per call)
+    size_t h_out_cap = 0;
+};
+
+extern "C" {
+
+int lba_batch_create(int device, lba_batch** out)
+{
+    if (!out) return fail(ORBX_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(ORBX_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(ORBX_ERR_ARG, "device %d out of range", device);
+    LBA_HIP(hipSetDevice(device));
+    lba_batch* b = new lba_batch();
+    b->device = device;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&b->h_scal, lba::kMaxBatch * 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipMalloc((void**)&b->d_wins, lba::kMaxBatch * sizeof(lba::BWin)) != hipSuccess ||
+        hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) {
+        lba_batch_destroy(b);
+        return fail(ORBX_ERR_HIP, "batch handle creation failed");
+    }
+    std::memset(b->h_scal, 0, lba::kMaxBatch * 16 * sizeof(double));
+    *out = b;
+    return ORBX_OK;
+}
+
+void lba_batch_destroy(lba_batch* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (lba_solver* sv : b->slots) {
+        if (sv->arena) (void)hipFree(sv->arena);
+        if (sv->stage) (void)hipHostFree(sv->stage);
+        delete sv;
+    }
+    if (b->d_wins) (void)hipFree(b->d_wins);
+    if (b->h_scal) (void)hipHostFree(b->h_scal);
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+double lba_batch_last_device_ms(const lba_batch* b) { return b ? b->last_device_ms : 0.0; }
+
+int lba_solve_batch(lba_batch* b, const LbaProblem* problems, const LbaOutputs* outputs, int n_windows,
+                    const volatile uint8_t* const* stop_flags, int max_iters, double lambda_init, LbaStats* stats_out)
+{
+    if (!b || !problems || n_windows < 0) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (n_windows > lba::kMaxBatch) return fail(ORBX_ERR_CAPACITY, "at most %d windows per call", lba::kMaxBatch);
+    if (n_windows == 0) return ORBX_OK;
+    LBA_HIP(hipSetDevice(b->device));
+    const int W = n_windows;
+    while ((int)b->slots.size() < W) {
+        lba_solver* sv = new lba_solver();
+        sv->device = b->device; sv->stream = b->stream; sv->h_scal = b->h_scal + 16 * b->slots.size();
+        b->slots.push_back(sv);
+    }
+    std::vector<lba_shard*> sh((size_t)W, nullptr);
+    std::vector<size_t> wanted((size_t)W, 0), wanted_stage((size_t)W, 0);
+    int r = ORBX_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < W; i++) {
+            if (sh[i]) lba_shard_destroy(sh[i]);
+            solver_grow(b->slots[i], wanted[i], wanted_stage[i]);
+        }
+    };
+    std::vector<lba::BWin> hw((size_t)W);
+    int max_lin = 1, max_e = 1, max_lm = 1, max_sb = 1, max_nblk = 1, max_upd = 1, max_n = 0;
+    static const bool timing = std::getenv("ORBX_LBA_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    {
+        // structure build (CSR lists, pair lists) + upload of every window: host work, spread over threads (a window is ~0.3 ms)
+        const int n_thr = std::max(1, std::min({W, (int)std::thread::hardware_concurrency(), 16}));
+        std::vector<int> rcs((size_t)W, ORBX_OK);
+        std::atomic<int> next(0);
+        auto worker = [&]() {
+            (void)hipSetDevice(b->device);
+            for (int i = next.fetch_add(1); i < W; i = next.fetch_add(1)) rcs[i] = shard_create_impl(b->device, &problems[i], &sh[i], b->slots[i]);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_thr; t++) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+        for (int i = 0; i < W; i++) if (rcs[i] && !r) r = fail(rcs[i], "window %d could not be set up (code %d; the worker thread holds the detailed message)", i, rcs[i]);
+    }
+    const auto t_created = std::chrono::steady_clock::now();
+    for (int i = 0; i < W && !r; i++) {
+        lba_shard* s = sh[i];
+        wanted[i] = s->bytes_wanted; wanted_stage[i] = s->upload_bytes;
+        if (s->nblk > lba::kFusedMaxBlocks) { r = fail(ORBX_ERR_CAPACITY, "window %d has %d reduced unknowns: the batched path takes at most %d (use lba_solve)", i, s->d.n, lba::kFusedMaxBlocks * lba::NB); break; }
+        lba::BWin& w = hw[i];
+        w.d = s->d; w.poses[0] = s->poses[0]; w.poses[1] = s->poses[1]; w.pts[0] = s->pts[0]; w.pts[1] = s->pts[1];
+        w.S = s->S(); w.bs = s->bs(); w.bpf = s->bpf(); w.diag = s->diag(); w.Lp = s->Lp; w.Linv = s->Linv; w.hmap = s->d_hmap; w.nblk = s->nblk;
+        const lba::Dev& d = s->d;
+        max_lin = std::max(max_lin, d.nP + (d.nL + 31) / 32); max_e = std::max(max_e, (d.nE + 255) / 256); max_lm = std::max(max_lm, (d.nL + 7) / 8);
+        max_sb = std::max(max_sb, d.nBlocks + d.nP); max_nblk = std::max(max_nblk, s->nblk); max_upd = std::max(max_upd, (d.nL + d.nPoses + 63) / 64);
+        max_n = std::max(max_n, d.n);
+    }
+    if (r) { cleanup(); return r; }
+    const size_t solve_lds = ((size_t)max_n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
+    if (hipFuncSetAttribute((const void*)lba::k_chol_step_b, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lba::k_chol_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)) != hipSuccess ||
+        hipMemcpyAsync(b->d_wins, hw.data(), (size_t)W * sizeof(lba::BWin), hipMemcpyHostToDevice, b->stream) != hipSuccess) {
+        cleanup();
+        return fail(ORBX_ERR_HIP, "batch setup failed");
+    }
+    (void)hipEventRecord(b->ev0, b->stream);
+
+    // ---- one Levenberg state machine per window (the control flow of lba_shard_optimize, cut at the points where it waits for the device) ----
+    enum Phase { kStartIter, kAfterLin, kTrials, kDone };
+    struct WS { Phase ph = kStartIter; double lambda = -1, ni = 2, cur_chi = 0, ini_chi = 0, rho = 0, trial_lambda = 0; int nBad = 0, it = 0, qmax = 0, cur = 0; bool err_current = false, first_trial = false; double hint = -1; LbaStats st; };
+    std::vector<WS> ws((size_t)W);
+    for (auto& x : ws) std::memset(&x.st, 0, sizeof(x.st));
+    auto stopped = [&](int i) { return stop_flags && stop_flags[i] && *stop_flags[i]; };
+    std::vector<unsigned long long> seq((size_t)W);
+    for (int i = 0; i < W; i++) seq[i] = sh[i]->seq;
+    lba::BDynAll dyn;
+    std::memset(&dyn, 0, sizeof(dyn));
+    auto finish_iteration = [&](int i) {        // after the trial loop of an iteration (levenberg.cpp:150-169, sparse_optimizer.cpp:395-414)
+        WS& x = ws[i];
+        x.st.iterations++;
+        if (x.it < 16) x.st.chi2_trace[x.it] = x.cur_chi;
+        x.st.chi2_final = x.cur_chi;
+        if (x.qmax == 10 || x.rho == 0) { x.st.stop_reason = 1; x.ph = kDone; return; }
+        if ((x.ini_chi - x.cur_chi) * 1e3 < x.ini_chi) x.nBad++; else x.nBad = 0;
+        if (x.nBad >= 3) { x.st.stop_reason = 2; x.ph = kDone; return; }
+        x.it++;
+        x.ph = kStartIter;
+    };
+    for (;;) {
+        bool any_lin = false, any_err = false, any_trial = false, any_lm = false;
+        for (int i = 0; i < W; i++) {
+            WS& x = ws[i];
+            lba::BDyn& y = dyn.w[i];
+            y.flags = 0;
+            if (x.ph == kStartIter) {
+                if (x.it >= max_iters) { x.ph = kDone; }
+                else if (stopped(i)) { x.st.stop_reason = 3; x.ph = kDone; }
+                else {
+                    x.hint = x.it > 0 ? x.lambda : (lambda_init > 0 ? lambda_init : -1.0);
+                    y.flags |= lba::kBwLin;
+                    if (!x.err_current) { y.flags |= lba::kBwErrors | lba::kBwReduce0; x.ph = kAfterLin; }       // the host needs chi2 / the diagonals first
+                    else { x.ini_chi = x.cur_chi; x.rho = 0; x.qmax = 0; x.first_trial = true; x.ph = kTrials; }
+                }
+            }
+            if (x.ph == kTrials) {
+                y.flags |= lba::kBwTrial;
+                if (!(x.first_trial && x.hint >= 0.0 && x.hint == x.lambda)) y.flags |= lba::kBwSchurLm;
+                x.trial_lambda = x.lambda;
+            }
+            y.lambda = x.lambda; y.hint = x.hint; y.cur = x.cur;
+            if (y.flags & (lba::kBwReduce0 | lba::kBwTrial)) y.seq = ++seq[i];
+            any_lin |= (y.flags & lba::kBwLin) != 0; any_err |= (y.flags & lba::kBwErrors) != 0;
+            any_trial |= (y.flags & lba::kBwTrial) != 0; any_lm |= (y.flags & lba::kBwSchurLm) != 0;
+        }
+        if (!any_lin && !any_trial) break;
+        hipStream_t st = b->stream;
+        if (any_err) hipLaunchKernelGGL(lba::k_errors_b, dim3(max_e, W), dim3(256), 0, st, (const lba::BWin*)b->d_wins, dyn, 0);
+        if (any_lin) hipLaunchKernelGGL(lba::k_lin_all_b, dim3(max_lin, W), dim3(256), 0, st, (const lba::BWin*)b->d_wins, dyn);
+        if (any_err) hipLaunchKernelGGL(lba::k_reduce_b, dim3(1, W), dim3(1024), 0, st, (const lba::BWin*)b->d_wins, dyn, 0);
+        if (any_trial) {
+            if (any_lm) hipLaunchKernelGGL(lba::k_schur_landmarks_b, dim3(max_lm, W), dim3(64), 0, st, (const lba::BWin*)b->d_wins, dyn);
+            hipLaunchKernelGGL(lba::k_schur_blocks_b, dim3(max_sb, W), dim3(lba::kSchurThreads), 0, st, (const lba::BWin*)b->d_wins, dyn);
+            hipLaunchKernelGGL(lba::k_chol_diag_b, dim3(1, W), dim3(256), 0, st, (const lba::BWin*)b->d_wins, dyn);
+            for (int K = 0; K + 1 < max_nblk; K++) {
+                const int T = max_nblk - 1 - K;
+                hipLaunchKernelGGL(lba::k_chol_step_b, dim3(T * (T + 1) / 2, W), dim3(256), lba::kStepLds, st, (const lba::BWin*)b->d_wins, dyn, K);
+            }
+            hipLaunchKernelGGL(lba::k_chol_solve_b, dim3(1, W), dim3(1024), solve_lds, st, (const lba::BWin*)b->d_wins, dyn);
+            hipLaunchKernelGGL(lba::k_backsub_update_b, dim3(max_upd, W), dim3(64), 0, st, (const lba::BWin*)b->d_wins, dyn);
+            hipLaunchKernelGGL(lba::k_errors_b, dim3(max_e, W), dim3(256), 0, st, (const lba::BWin*)b->d_wins, dyn, 1);
+            hipLaunchKernelGGL(lba::k_reduce_b, dim3(1, W), dim3(1024), 0, st, (const lba::BWin*)b->d_wins, dyn, 1);
+        }
+        if (hipGetLastError() != hipSuccess) { r = fail(ORBX_ERR_HIP, "batched launch failed"); break; }
+        // results of the round: every window that ran a reduction publishes its sequence number last
+        for (int i = 0; i < W && !r; i++) {
+            const int f = dyn.w[i].flags;
+            if (!(f & (lba::kBwReduce0 | lba::kBwTrial))) continue;
+            sh[i]->seq = seq[i];
+            r = read_scalars(sh[i]);
+        }
+        if (r) break;
+        for (int i = 0; i < W; i++) {
+            WS& x = ws[i];
+            const int f = dyn.w[i].flags;
+            const double* h = sh[i]->h_scal;
+            if (f & lba::kBwReduce0) {      // linearised without a trial: chi2 and the diagonal maxima are in
+                x.cur_chi = h[0];
+                x.err_current = true;
+                x.ini_chi = x.cur_chi;
+                if (x.it == 0) {
+                    x.st.chi2_initial = x.cur_chi;
+                    x.lambda = lambda_init > 0 ? lambda_init : 1e-5 * std::max(h[1], h[2]);      // computeLambdaInit (levenberg.cpp:171-185)
+                    x.ni = 2; x.nBad = 0;
+                }
+                x.rho = 0; x.qmax = 0; x.first_trial = true;
+                x.ph = kTrials;
+                continue;
+            }
+            if (!(f & lba::kBwTrial)) continue;
+            double tempChi = h[0];
+            const double sp = h[3], sl = h[4];
+            if (h[5] != 0.0) tempChi = std::numeric_limits<double>::max();       // the reduced system was not positive definite
+            x.first_trial = false;
+            x.err_current = false;
+            x.rho = x.cur_chi - tempChi;
+            double scale = sp + sl;
+            scale += 1e-3;
+            x.rho /= scale;
+            if (x.rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * x.rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                x.lambda *= std::max(1. / 3., alpha);
+                x.ni = 2;
+                x.cur_chi = tempChi;
+                x.cur = 1 - x.cur;              // discardTop(): the trial state becomes the estimate, its errors are the current ones
+                x.err_current = true;
+            } else {
+                x.lambda *= x.ni;
+                x.ni *= 2;
+            }
+            x.qmax++;
+            x.st.trials++;
+            const bool stop_now = stopped(i);
+            if (!(x.rho < 0 && x.qmax < 10 && !stop_now)) finish_iteration(i);
+        }
+    }
+    (void)hipEventRecord(b->ev1, b->stream);
+    const auto t_solved = std::chrono::steady_clock::now();
+#define BTRY(expr) do { if (!r && (expr) != hipSuccess) r = fail(ORBX_ERR_HIP, "%s failed", #expr); } while (0)
+    // results of all windows: epilogue kernels and copies into ONE pinned buffer, one synchronisation, then the scatter
+    {
+        auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+        std::vector<size_t> off((size_t)W + 1, 0);
+        for (int i = 0; i < W; i++) {
+            const lba::Dev& d = sh[i]->d;
+            off[i + 1] = off[i] + al(7 * (size_t)d.nPoses * 8) + al(3 * (size_t)d.nL * 8) + al((size_t)d.nE * 8) + al((size_t)d.nE);
+        }
+        if (outputs && off[W] > b->h_out_cap) {
+            if (b->h_out) (void)hipHostFree(b->h_out);
+            b->h_out = nullptr; b->h_out_cap = 0;
+            const size_t cap = off[W] + off[W] / 4 + 4096;
+            if (hipHostMalloc((void**)&b->h_out, cap) == hipSuccess) b->h_out_cap = cap;
+            else r = fail(ORBX_ERR_HIP, "pinned result buffer allocation failed");
+        }
+        for (int i = 0; i < W && !r; i++) {
+            lba_shard* s = sh[i];
+            s->cur = ws[i].cur;
+            ws[i].st.lambda = ws[i].lambda;
+            if (stats_out) stats_out[i] = ws[i].st;
+            if (!outputs) continue;
+            const lba::Dev& d = s->d;
+            uint8_t* o = b->h_out + off[i];
+            if (d.nE > 0 && (outputs[i].chi2_per_edge || outputs[i].depth_positive))
+                hipLaunchKernelGGL(lba::k_epilogue, dim3((d.nE + 255) / 256), dim3(256), 0, b->stream, d, (const double*)s->poses[s->cur], (const double*)s->pts[s->cur], s->d_chi2, s->d_depth);
+            BTRY(hipMemcpyAsync(o, s->poses[s->cur], 7 * (size_t)d.nPoses * 8, hipMemcpyDeviceToHost, b->stream));
+            o += al(7 * (size_t)d.nPoses * 8);
+            if (outputs[i].points && d.nL > 0) BTRY(hipMemcpyAsync(o, s->pts[s->cur], 3 * (size_t)d.nL * 8, hipMemcpyDeviceToHost, b->stream));
+            o += al(3 * (size_t)d.nL * 8);
+            if (outputs[i].chi2_per_edge && d.nE > 0) BTRY(hipMemcpyAsync(o, s->d_chi2, (size_t)d.nE * 8, hipMemcpyDeviceToHost, b->stream));
+            o += al((size_t)d.nE * 8);
+            if (outputs[i].depth_positive && d.nE > 0) BTRY(hipMemcpyAsync(o, s->d_depth, (size_t)d.nE, hipMemcpyDeviceToHost, b->stream));
+        }
+        if (!r) {
+            BTRY(hipStreamSynchronize(b->stream));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_device_ms = ms;
+        }
+        for (int i = 0; i < W && !r && outputs; i++) {
+            const lba::Dev& d = sh[i]->d;
+            const uint8_t* o = b->h_out + off[i];
+            const double* poses = (const double*)o;
+            for (int k = 0; k < d.nPoses; k++) {
+                if (outputs[i].pose_q) for (int c = 0; c < 4; c++) outputs[i].pose_q[4 * k + c] = poses[7 * (size_t)k + c];
+                if (outputs[i].pose_t) for (int c = 0; c < 3; c++) outputs[i].pose_t[3 * k + c] = poses[7 * (size_t)k + 4 + c];
+            }
+            o += al(7 * (size_t)d.nPoses * 8);
+            if (outputs[i].points && d.nL > 0) std::memcpy(outputs[i].points, o, 3 * (size_t)d.nL * 8);
+            o += al(3 * (size_t)d.nL * 8);
+            if (outputs[i].chi2_per_edge && d.nE > 0) std::memcpy(outputs[i].chi2_per_edge, o, (size_t)d.nE * 8);
+            o += al((size_t)d.nE * 8);
+            if (outputs[i].depth_positive && d.nE > 0) std::memcpy(outputs[i].depth_positive, o, (size_t)d.nE);
+        }
+    }
+#undef BTRY
+    const auto t_down = std::chrono::steady_clock::now();
+    cleanup();
+    if (timing) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+        std::fprintf(stderr, "[lba_solve_batch] %d windows: structure + upload %.3f ms, Levenberg rounds %.3f ms, epilogue + download %.3f ms, destroy %.3f ms\n",
+                     W, ms(t_start, t_created), ms(t_created, t_solved), ms(t_solved, t_down), ms(t_down, std::chrono::steady_clock::now()));
+    }
     return r;
 }
 

@@ -152,3 +152,58 @@ def test_global_ba_at_config5_size(pkg, oracle, synth, robust):
         s.close()
     assert r0["stats"]["iterations"] >= 3 and r0["stats"]["chi2_final"] < 0.5 * r0["stats"]["chi2_initial"]
     _check(w, r0, r1)
+
+
+def test_lba_batch_equals_single_windows(pkg, synth):
+    """lba_solve_batch: windows of different sizes, stereo shares, robust / non-robust, a window whose stop flag is already set and
+    one with two poses, all through ONE sequence of launches per Levenberg round -- every window must come out exactly as
+    lba_solve returns it (same kernel bodies in the same order: bit-identical estimates, chi2, LM path), twice on the same handle"""
+    specs = [(0, dict(n_opt=5, n_fixed=2, n_points=60, obs_per_point=4)), (1, dict(n_opt=12, n_fixed=3, n_points=300, obs_per_point=6)),
+             (2, dict(n_opt=50, n_fixed=10, n_points=2000, obs_per_point=10)), (3, dict(n_opt=23, n_fixed=5, n_points=700, obs_per_point=8, stereo_frac=0.4)),
+             (4, dict(n_opt=1, n_fixed=1, n_points=30, obs_per_point=2)), (5, dict(n_opt=10, n_fixed=2, n_points=200, obs_per_point=5)),
+             (6, dict(n_opt=8, n_fixed=2, n_points=150, obs_per_point=5)), (7, dict(n_opt=31, n_fixed=4, n_points=900, obs_per_point=7))]
+    ws = [synth.make_ba_window(seed, **kw) for seed, kw in specs]
+    ws[5]["huber_mono"] = 0.0
+    flags = [None] * len(ws)
+    flags[6] = np.ones(1, np.uint8)
+    s = pkg.LbaSolver()
+    b = pkg.LbaBatch()
+    try:
+        ref = [s.solve(w, 10, stop_flag=f) for w, f in zip(ws, flags)]
+        for rep in range(2):
+            got = b.solve(ws, 10, stop_flags=flags)
+            for i, (r0, r1) in enumerate(zip(ref, got)):
+                assert r1["stats"] == r0["stats"], "window %d: %r vs %r" % (i, r1["stats"], r0["stats"])
+                for k in ("pose_q", "pose_t", "points", "chi2", "depth_positive"):
+                    np.testing.assert_array_equal(r1[k], r0[k], err_msg="window %d %s" % (i, k))
+        assert ref[6]["stats"]["stop_reason"] == 3 and ref[2]["stats"]["iterations"] >= 3
+        assert len({r["stats"]["trials"] for r in ref}) > 2          # the windows really take different LM paths
+    finally:
+        s.close(); b.close()
+
+
+def test_lba_batch_32_windows_of_config3(pkg, oracle, synth):
+    """the bench's batched leg: 32 different windows of BASELINE configs[3] (50 + 10 key frames, 2000 points, 20 k edges); one of
+    them against the oracle, all of them against lba_solve"""
+    ws = [synth.make_ba_window(100 + i) for i in range(32)]
+    s = pkg.LbaSolver()
+    b = pkg.LbaBatch()
+    try:
+        got = b.solve(ws, 10)
+        for i in (0, 13, 31):
+            r0 = s.solve(ws[i], 10)
+            assert got[i]["stats"] == r0["stats"]
+            np.testing.assert_array_equal(got[i]["points"], r0["points"])
+        _check(ws[7], oracle.lba_solve(ws[7], 10), got[7])
+    finally:
+        s.close(); b.close()
+
+
+def test_lba_batch_refuses_oversized_window(pkg, synth):
+    w = synth.make_ba_window(9, n_opt=90, n_fixed=2, n_points=400, obs_per_point=4)       # 540 reduced unknowns > 480
+    b = pkg.LbaBatch()
+    try:
+        with pytest.raises(pkg.OrbxError):
+            b.solve([w], 2)
+    finally:
+        b.close()

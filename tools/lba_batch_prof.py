@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""lba_solve_batch alone, for rocprofv3 --kernel-trace --stats: W windows of SURVEY config #4 (50 KF / 2000 MP / 20 k edges), N calls.
+  python tools/lba_batch_prof.py [W] [N]"""
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402  (one HIP runtime)
+
+pkg = importlib.import_module("orb_slam3-1_amd")
+synth = importlib.import_module("orb_slam3-1_amd.synth")
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ws = [synth.make_ba_window(100 + i) for i in range(W)]
+b = pkg.LbaBatch()
+prep = b.prepare(ws)
+b.run(prep, 10); b.run(prep, 10)
+t0 = time.perf_counter()
+it, dev = 0, 0.0
+for _ in range(N):
+    r = b.run(prep, 10)
+    it += sum(x["stats"]["iterations"] for x in r); dev += b.last_device_ms()
+dt = time.perf_counter() - t0
+print("%d windows x %d calls: %d iterations, %.3f ms per call, %.3f ms of it Levenberg rounds on the device -> %.0f iterations/s (device), %.0f (whole call)" % (
+    W, N, it, 1e3 * dt / N, dev / N, it / (dev * 1e-3), it / dt))
+b.close()
