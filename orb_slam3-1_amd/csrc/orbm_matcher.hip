@@ -369,6 +369,15 @@ __device__ unsigned long long d_proj_prof[8];
 // smallest candidates in (distance, visiting order) lexicographic order == the reference's best / second best.
 // pt_ur: the point's predicted right-image column (mTrackProjXR, :94 / uv(0) - mbf*invzc, :1753); a candidate that has a
 // right coordinate of its own (mvuRight > 0) is skipped when the two differ by more than the window radius.
+// the LDS traffic of ONE wave executes in order: between its own writes and reads only the compiler has to be held back
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// WAVE_ONLY: the calling wave is one of several in its workgroup and works alone (k_proj_par): no workgroup barrier
+template <bool WAVE_ONLY = false>
 __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float x, float y, float r, int minLevel, int maxLevel,
                               float pt_ur, const unsigned long long* dq, int lane, int* s_col, unsigned long long& best, unsigned long long& second)
 {
@@ -406,7 +415,7 @@ __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8
         inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);
         const int total = __builtin_amdgcn_readlane(inc, nx - 1);
         if (lane < nx) { s_col[lane] = inc - run_n; s_col[16 + lane] = run_b; }
-        __syncthreads();
+        if (WAVE_ONLY) wave_lds_sync(); else __syncthreads();
         for (int t = lane; t < total; t += 64) {
             int cx = 0;
             for (int k = 1; k < nx; k++) cx += (t >= s_col[k]) ? 1 : 0;
@@ -660,6 +669,382 @@ __global__ __launch_bounds__(64) void k_proj(const ProjArgs* __restrict__ jobs)
     __syncthreads();
     for (int i = lane; i < F.n; i += 64) A.occupied[i] = s_occ[i];
     if (lane == 0) *A.n_matches = nmatches;
+}
+
+// ---- the same searches with the points taken 64 at a time (one lane per point) -----------------------------------------
+// The reference walks the points in order and a point only sees the features no earlier point has taken (greedy dependence):
+// k_proj above does exactly that, one point after the other with the wave spread over its window -- about 5.8 k cycles per
+// point, 2.3 ms for 256 frames x 900 points.  Here a block of 64 points is searched SPECULATIVELY, every lane walking its own
+// point's window against the occupancy at the start of the block; then the block is resolved in point order:
+//   * taking features out of the pool can only change a point's outcome if its best (or, where the ratio test looks at it,
+//     its second best) candidate is taken -- every other candidate is irrelevant to the result;
+//   * so a lane is DIRTY iff its best / second best has been occupied since the block began or is claimed by an earlier lane
+//     of the block that will occupy it.  All lanes in front of the first dirty lane d have final results: they commit
+//     (assignment, occupancy, rotation log; same-feature writers in point order), lane d is searched again by the whole wave
+//     against the now exact occupancy (search_window), commits, and the remaining lanes are re-examined.
+// Results are those of the sequential loop, assignment for assignment (tests: every M4 / M5 / key-frame / Sim3 case and the goldens).
+// Speculative search of a block of 64 points, load-balanced: the windows of the 64 points are flattened into ONE list of
+// (point, candidate) items -- a window is at most 16 contiguous CSR runs, one per grid column, and the items of a point are its
+// runs front to back = the reference's visiting order -- and every lane takes an equal, contiguous share of the list (a lane per
+// point would make the wave wait for the largest window: 234 candidates against a mean of 51 on the synthetic frames).  A lane
+// keeps the two best keys of the point it is walking in registers and merges them into the point's LDS slots when it moves on.
+constexpr int kBlkRuns = 16;
+constexpr int kBlkSlots = 64 * 8 + 64;   // threads of a k_proj_par workgroup + points of a block
+struct ProjBlockLds {
+    int run_start[64][kBlkRuns];        // CSR position of the first feature of a run
+    int run_cum[64][kBlkRuns + 1];      // items of the point in front of the run
+    int pt_cum[65];                     // items in front of the point
+    float prm[64][4];                   // x, y, r, predicted right column
+    int lvl[64][2];                     // minLevel, maxLevel
+    unsigned long long dq[64][4];
+    unsigned long long best[64], second[64];
+    unsigned long long part1[kBlkSlots], part2[kBlkSlots];  // (best, second) a thread found for a point, slot = thread + point (unique: both only grow along the list)
+};
+// recs: the frame's key points in CSR (grid) order, 16 bytes each {x, y, octave, feature index}: one LDS read per item whose
+// address does not depend on a previous read, so the record of item t + 1 is in flight while item t is examined (nullptr: built
+// from the separate arrays, the path of frames too large to stage).
+constexpr int kProjWaves = 8;           // waves of a k_proj_par workgroup: all of them walk the item list, wave 0 resolves the block
+constexpr int kProjThreads = 64 * kProjWaves;
+// phase 1 (wave 0, lane = point): window -> runs; returns the point's item count
+__device__ __forceinline__ int block_runs(const ProjFrameDev& F, ProjBlockLds& B, int lane, bool live,
+                                          float x, float y, float r, int minLevel, int maxLevel, float pt_ur, bool& irregular)
+{
+    irregular = false;
+    int cnt = 0, nx = 0;
+    if (live) {
+        const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.winv));
+        const int nMaxCellX = min(F.cols - 1, (int)ceilf((x - F.min_x + r) * F.winv));
+        const int nMinCellY = max(0, (int)floorf((y - F.min_y - r) * F.hinv));
+        const int nMaxCellY = min(F.rows - 1, (int)ceilf((y - F.min_y + r) * F.hinv));
+        if (nMinCellX < F.cols && nMaxCellX >= 0 && nMinCellY < F.rows && nMaxCellY >= 0) {
+            nx = nMaxCellX - nMinCellX + 1;
+            const int ny = nMaxCellY - nMinCellY + 1;
+            if (nx > kBlkRuns) { irregular = true; nx = 0; }       // a window wider than 16 grid columns: left to the wave-wide search
+            for (int k = 0; k < nx; k++) {
+                const int cell0 = (nMinCellX + k) * F.rows + nMinCellY;
+                const int b0 = F.cell_off[cell0];
+                B.run_start[lane][k] = b0;
+                B.run_cum[lane][k] = cnt;
+                cnt += F.cell_off[cell0 + ny] - b0;
+            }
+        }
+    }
+    B.run_cum[lane][nx] = cnt;
+    for (int k = nx + 1; k <= kBlkRuns; k++) B.run_cum[lane][k] = 0x7FFFFFFF;
+    B.prm[lane][0] = x; B.prm[lane][1] = y; B.prm[lane][2] = r; B.prm[lane][3] = pt_ur;
+    B.lvl[lane][0] = minLevel; B.lvl[lane][1] = maxLevel;
+    B.best[lane] = kNoKey; B.second[lane] = kNoKey;
+    for (int q = lane; q < kProjThreads + 64; q += 64) { B.part1[q] = kNoKey; B.part2[q] = kNoKey; }
+    int incl = cnt;                                      // inclusive prefix over the 64 lanes (DPP ladder)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
+    B.pt_cum[lane] = incl - cnt;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (lane == 0) B.pt_cum[64] = total;
+    return cnt;
+}
+// phase 2 (every wave, thread = an equal, contiguous share of the item list)
+__device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* __restrict__ recs, const uint8_t* s_occ, ProjBlockLds& B, int tid)
+{
+    const int total = B.pt_cum[64];
+    if (total == 0) return;
+    const int lane = tid;
+    auto load_rec = [&](int e) -> uint4 {
+        if (recs) return recs[e];
+        const int idx = F.cell_feat[e];
+        return make_uint4(__float_as_uint(F.x[idx]), __float_as_uint(F.y[idx]), (unsigned)F.octave[idx], (unsigned)idx);
+    };
+    const int chunk = (total + kProjThreads - 1) / kProjThreads;
+    const int t0 = lane * chunk, t1 = min(total, t0 + chunk);
+    if (t0 < t1) {
+        int p = 0;                                      // last point with pt_cum[p] <= t0
+        for (int step = 32; step > 0; step >>= 1) if (p + step < 64 && B.pt_cum[p + step] <= t0) p += step;
+        int local = t0 - B.pt_cum[p];
+        int k = 0;                                      // last run of p with run_cum <= local
+        for (int step = 8; step > 0; step >>= 1) if (k + step < kBlkRuns && B.run_cum[p][k + step] <= local) k += step;
+        int e = B.run_start[p][k] + (local - B.run_cum[p][k]);
+        int run_end_local = B.run_cum[p][k + 1];        // first item of the next run (0x7FFFFFFF behind the last run)
+        int pt_end = B.pt_cum[p + 1];
+        int fp = p, ford = local;                       // point and visiting-order position of the record in flight
+        uint4 rec = load_rec(e);
+        int cp = -1;                                    // point whose parameters are in registers
+        float px = 0.f, py = 0.f, pr = 0.f, pur = 0.f;
+        int mnl = 0, mxl = 0;
+        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        unsigned long long k1 = kNoKey, k2 = kNoKey;
+        for (int t = t0; t < t1; t++) {
+            const uint4 cur = rec;
+            const int ip = fp, ord = ford;
+            if (t + 1 < t1) {                           // position of item t + 1; its record's load goes out before item t is examined
+                e++; local++;
+                if (t + 1 >= pt_end) {
+                    do { p++; pt_end = B.pt_cum[p + 1]; } while (t + 1 >= pt_end);
+                    local = t + 1 - B.pt_cum[p]; k = 0;
+                    e = B.run_start[p][0]; run_end_local = B.run_cum[p][1];
+                }
+                while (local >= run_end_local) { k++; e = B.run_start[p][k]; run_end_local = B.run_cum[p][k + 1]; }      // (empty runs are skipped)
+                fp = p; ford = local;
+                rec = load_rec(e);
+            }
+            if (ip != cp) {
+                if (cp >= 0) { B.part1[lane + cp] = k1; B.part2[lane + cp] = k2; }     // plain stores: no atomic round trips in the loop
+                k1 = k2 = kNoKey;
+                cp = ip;
+                px = B.prm[cp][0]; py = B.prm[cp][1]; pr = B.prm[cp][2]; pur = B.prm[cp][3];
+                mnl = B.lvl[cp][0]; mxl = B.lvl[cp][1];
+                q0 = B.dq[cp][0]; q1 = B.dq[cp][1]; q2 = B.dq[cp][2]; q3 = B.dq[cp][3];
+            }
+            const int oc = (int)cur.z, idx = (int)cur.w;
+            const bool bCheckLevels = (mnl > 0) || (mxl >= 0);
+            if (bCheckLevels && (oc < mnl || (mxl >= 0 && oc > mxl))) continue;
+            const float distx = __uint_as_float(cur.x) - px, disty = __uint_as_float(cur.y) - py;
+            if (!(fabsf(distx) < pr && fabsf(disty) < pr)) continue;
+            // the rest only depends on idx: occupancy, right column and descriptor are requested together
+            const unsigned char oc8 = s_occ[idx];
+            const float ur = F.u_right ? F.u_right[idx] : 0.f;
+            const unsigned long long* db = (const unsigned long long*)(F.desc + (size_t)idx * 32);
+            const unsigned long long d0 = db[0], d1 = db[1], d2 = db[2], d3 = db[3];
+            if (oc8) continue;
+            if (F.u_right && ur > 0.f && fabsf(pur - ur) > pr) continue;
+            const int dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
+            if (dist >= 256) continue;
+            const unsigned long long key = ((unsigned long long)dist << 55) | ((unsigned long long)ord << 21) | (unsigned long long)idx;
+            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+        }
+        if (cp >= 0) { B.part1[lane + cp] = k1; B.part2[lane + cp] = k2; }
+    }
+}
+// phase 3 (wave 0, lane = point again): the two smallest keys over the threads that walked a part of its items
+__device__ __forceinline__ void block_merge(ProjBlockLds& B, int lane, int cnt, bool want_second)
+{
+    if (cnt > 0) {
+        const int total = B.pt_cum[64];
+        const int chunk = (total + kProjThreads - 1) / kProjThreads;
+        const int start = B.pt_cum[lane];
+        const int l0 = start / chunk, l1 = (start + cnt - 1) / chunk;
+        unsigned long long k1 = kNoKey, k2 = kNoKey;
+        for (int l = l0; l <= l1; l++) {
+            const unsigned long long a1 = B.part1[l + lane], a2 = B.part2[l + lane];
+            if (a1 < k1) { k2 = min(k1, a2); k1 = a1; } else { k2 = min(k2, a1); }
+        }
+        B.best[lane] = k1;
+        if (want_second) B.second[lane] = k2;
+    }
+}
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src)
+{
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool STAGE>
+__global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __restrict__ jobs)
+{
+    static_assert(kProjThreads + 64 <= kBlkSlots, "ProjBlockLds::part1 / part2");
+    const ProjArgs A = jobs[blockIdx.x];        // one workgroup per job (frame)
+    extern __shared__ __align__(16) uint8_t s_dyn[];
+    __shared__ int s_hist[HISTO_LENGTH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < 64;                   // wave 0 owns the points of a block and resolves it
+    ProjFrameDev F = A.F;
+    const int n = F.n;
+    const size_t tab = ((size_t)n + 15) & ~(size_t)15;
+    int* s_claim = (int*)s_dyn;                 // per feature: first pending lane that will take it out of the pool
+    int* s_last = s_claim + tab;                // per feature: last lane of the committing range that writes it
+    uint8_t* s_occ = s_dyn + 8 * tab;
+    const uint4* s_recs = nullptr;              // key points in grid order (staged frames only)
+    if (STAGE) {
+        const int ncell = F.cols * F.rows;
+        size_t off = tab;
+        uint8_t* s_desc = s_occ + off; off += (size_t)n * 32;
+        float* s_x = (float*)(s_occ + off); off += (size_t)n * 4;
+        float* s_y = (float*)(s_occ + off); off += (size_t)n * 4;
+        int32_t* s_oct = (int32_t*)(s_occ + off); off += (size_t)n * 4;
+        int32_t* s_cfeat = (int32_t*)(s_occ + off); off += (size_t)n * 4;
+        float* s_ur = (float*)(s_occ + off); off += F.u_right ? (size_t)n * 4 : 0;
+        int32_t* s_coff = (int32_t*)(s_occ + off);
+        for (int i = tid; i < n * 8; i += kProjThreads) ((uint32_t*)s_desc)[i] = ((const uint32_t*)F.desc)[i];
+        for (int i = tid; i < n; i += kProjThreads) { s_x[i] = F.x[i]; s_y[i] = F.y[i]; s_oct[i] = F.octave[i]; }
+        if (F.u_right) { for (int i = tid; i < n; i += kProjThreads) s_ur[i] = F.u_right[i]; F.u_right = s_ur; }
+        const int nfeat_cells = F.cell_off[ncell];
+        for (int i = tid; i < nfeat_cells; i += kProjThreads) s_cfeat[i] = F.cell_feat[i];
+        for (int i = tid; i <= ncell; i += kProjThreads) s_coff[i] = F.cell_off[i];
+        off += ((size_t)ncell + 1) * 4;
+        off = (off + 15) & ~(size_t)15;
+        uint4* r4 = (uint4*)(s_occ + off);
+        for (int e = tid; e < nfeat_cells; e += kProjThreads) {
+            const int idx = F.cell_feat[e];
+            r4[e] = make_uint4(__float_as_uint(F.x[idx]), __float_as_uint(F.y[idx]), (unsigned)F.octave[idx], (unsigned)idx);
+        }
+        s_recs = r4;
+        F.desc = s_desc; F.x = s_x; F.y = s_y; F.octave = s_oct; F.cell_feat = s_cfeat; F.cell_off = s_coff;
+    }
+    __shared__ float s_scale[32];
+    __shared__ int s_col[32];
+    __shared__ ProjBlockLds s_blk;
+    if (F.n_levels > 0 && F.n_levels <= 32) {
+        if (tid < F.n_levels) s_scale[tid] = F.scale_factors[tid];
+        F.scale_factors = s_scale;
+    }
+    for (int i = tid; i < n; i += kProjThreads) { s_occ[i] = A.occupied[i]; s_claim[i] = 0x7FFFFFFF; s_last[i] = -1; }
+    if (tid < HISTO_LENGTH) s_hist[tid] = 0;
+    __syncthreads();
+    int nmatches = 0, nlog = 0;
+    const bool bFactor = A.th != 1.0f;
+    const int mode = A.last_frame_mode;
+    const bool ori = mode == 1 && A.check_ori;
+    // acceptance of a (best, second) pair: TH_HIGH / ORBdist / TH_LOW * ratio (:122, :1844, :1967, :522), ratio test of the map-point search (:126-127)
+    auto accept = [&](unsigned long long kb, unsigned long long ks) -> bool {
+        if (kb == kNoKey) return false;
+        const int bestDist = key_dist(kb);
+        if ((float)bestDist > A.dist_th) return false;
+        if (!mode) {
+            const int bestDist2 = (ks == kNoKey) ? 256 : key_dist(ks);
+            const int bestLevel = F.octave[key_idx(kb)];
+            const int bestLevel2 = (ks == kNoKey) ? -1 : F.octave[key_idx(ks)];
+            if (bestLevel == bestLevel2 && (float)bestDist > A.nnratio * (float)bestDist2) return false;
+        }
+        return true;
+    };
+#ifdef ORBM_PROJ_TIMING
+    long long t_blk = clock64();
+#endif
+    for (int base = 0; base < A.n_pts; base += 64) {
+        const int i = base + lane;
+        bool live = false, irregular = false;
+        float x = 0.f, y = 0.f, r = 0.f, pur = 0.f;
+        int minLevel = 0, maxLevel = 0, occval = 1, cnt = 0;
+        unsigned long long dq[4] = {0, 0, 0, 0};
+        if (w0) {
+            live = i < A.n_pts && A.valid[i] != 0;
+            if (live) {
+                x = A.u[i]; y = A.v[i];
+                const int lvl = A.level[i];
+                pur = A.F.u_right ? A.ur[i] : 0.f;
+                if (!mode) {
+                    if ((A.far_points && A.depth[i] > A.th_far) || A.bad[i]) live = false;
+                    r = ((double)A.view_cos[i] > 0.998) ? 2.5f : 4.0f;             // RadiusByViewingCos (:215-221)
+                    if (bFactor) r *= A.th;
+                    r = r * F.scale_factors[lvl];
+                    minLevel = lvl - 1; maxLevel = lvl;
+                } else if (mode == 1) {
+                    if (x < F.min_x || x > F.max_x || y < F.min_y || y > F.max_y) live = false;      // :1711-1714, :1917-1920
+                    r = A.th * F.scale_factors[lvl];
+                    if (A.level_window == ORBM_LEVELS_FORWARD) { minLevel = lvl; maxLevel = -1; }          // :1729
+                    else if (A.level_window == ORBM_LEVELS_BACKWARD) { minLevel = 0; maxLevel = lvl; }     // :1731
+                    else { minLevel = lvl - 1; maxLevel = lvl + 1; }                                        // :1733, :1938
+                } else {
+                    r = A.th * F.scale_factors[lvl];                          // :489
+                    minLevel = lvl - 1; maxLevel = lvl;                        // :509
+                }
+                const unsigned long long* dp = (const unsigned long long*)(A.desc + (size_t)i * 32);
+                dq[0] = dp[0]; dq[1] = dp[1]; dq[2] = dp[2]; dq[3] = dp[3];
+                if (A.has_obs) occval = A.has_obs[i];
+            }
+            s_blk.dq[lane][0] = dq[0]; s_blk.dq[lane][1] = dq[1]; s_blk.dq[lane][2] = dq[2]; s_blk.dq[lane][3] = dq[3];
+            cnt = block_runs(F, s_blk, lane, live, x, y, r, minLevel, maxLevel, pur, irregular);
+        }
+        __syncthreads();
+        // ---- speculative search of the block (every wave), occupancy as of its start ----
+        block_items(F, s_recs, s_occ, s_blk, tid);
+        __syncthreads();
+#ifdef ORBM_PROJ_TIMING
+        if (blockIdx.x == 0 && tid == 0) { const long long t_now = clock64(); d_proj_prof[5] += (unsigned long long)(t_now - t_blk); t_blk = t_now; d_proj_prof[7] += 64; }
+#endif
+        if (w0) {
+            block_merge(s_blk, lane, cnt, !mode);
+            const unsigned long long kb = s_blk.best[lane], ks = s_blk.second[lane];
+            bool acc = live && accept(kb, ks);
+            int bf = acc ? key_idx(kb) : -1;
+            // ---- resolution in point order (this wave alone: its LDS traffic executes in order) ----
+            int committed = 0;
+            for (;;) {
+                const bool pend = live && lane >= committed;
+                const bool osets = pend && acc && occval != 0;
+                if (osets) atomicMin(&s_claim[bf], lane);
+                wave_lds_sync();
+                bool dirty = pend && irregular;            // (a window the block search did not take: searched by the wave in its turn)
+                if (pend && !dirty && kb != kNoKey) {
+                    const int f1 = key_idx(kb);
+                    dirty = s_occ[f1] != 0 || s_claim[f1] < lane;
+                    if (!dirty && !mode && ks != kNoKey) { const int f2 = key_idx(ks); dirty = s_occ[f2] != 0 || s_claim[f2] < lane; }
+                }
+                const unsigned long long dm = __ballot(dirty);
+                const int d = dm ? (int)__ffsll((long long)dm) - 1 : 64;
+                wave_lds_sync();                            // every lane has read the claims
+                if (osets) s_claim[bf] = 0x7FFFFFFF;
+                const bool cm = pend && acc && lane < d;    // clean lanes in front of the first dirty one: final
+                if (cm) atomicMax(&s_last[bf], lane);
+                wave_lds_sync();
+                const unsigned long long cmm = __ballot(cm);
+                if (cm) {
+                    if (s_last[bf] == lane) { A.assign[bf] = i; s_occ[bf] = (uint8_t)occval; }     // same-feature writers: the last in point order
+                    if (ori) {
+                        const int bin = rot_bin(A.angle[i], F.angle[bf]);
+                        const int at = nlog + __popcll(cmm & ((1ull << lane) - 1ull));
+                        A.log_feat[at] = bf; A.log_bin[at] = bin;
+                        atomicAdd(&s_hist[bin], 1);
+                    }
+                }
+                wave_lds_sync();
+                if (cm) s_last[bf] = -1;
+                const int ncm = __popcll(cmm);
+                nmatches += ncm; nlog += ncm;
+#ifdef ORBM_PROJ_TIMING
+                if (blockIdx.x == 0 && lane == 0) d_proj_prof[3] += 1;
+#endif
+                if (d == 64) break;
+#ifdef ORBM_PROJ_TIMING
+                if (blockIdx.x == 0 && lane == 0) d_proj_prof[4] += 1;
+#endif
+                // ---- the first dirty point again, by the whole wave against the exact occupancy ----
+                const float xd = __shfl(x, d), yd = __shfl(y, d), rd = __shfl(r, d), purd = __shfl(pur, d);
+                const int minLd = __shfl(minLevel, d), maxLd = __shfl(maxLevel, d), occd = __shfl(occval, d);
+                const unsigned long long dqd[4] = {shfl64(dq[0], d), shfl64(dq[1], d), shfl64(dq[2], d), shfl64(dq[3], d)};
+                unsigned long long kbd, ksd;
+                search_window<true>(F, s_occ, xd, yd, rd, minLd, maxLd, purd, dqd, lane, s_col, kbd, ksd);
+                if (accept(kbd, ksd)) {
+                    const int f = key_idx(kbd);
+                    if (lane == 0) {
+                        A.assign[f] = base + d;
+                        s_occ[f] = (uint8_t)occd;
+                        if (ori) {
+                            const int bin = rot_bin(A.angle[base + d], F.angle[f]);
+                            A.log_feat[nlog] = f; A.log_bin[nlog] = bin;
+                            s_hist[bin]++;
+                        }
+                    }
+                    nmatches++; nlog++;
+                }
+                wave_lds_sync();
+                committed = d + 1;
+            }
+        }
+        __syncthreads();            // the block's occupancy is final for everybody
+#ifdef ORBM_PROJ_TIMING
+        if (blockIdx.x == 0 && tid == 0) { const long long t_now = clock64(); d_proj_prof[6] += (unsigned long long)(t_now - t_blk); t_blk = t_now; }
+#endif
+    }
+    if (ori && tid == 0) {
+        int i1, i2, i3;
+        three_maxima(s_hist, HISTO_LENGTH, i1, i2, i3);
+        for (int k = 0; k < nlog; k++) {
+            const int b = A.log_bin[k];
+            if (b != i1 && b != i2 && b != i3) {
+                A.assign[A.log_feat[k]] = -1;           // CurrentFrame.mvpMapPoints[...] = NULL (:1878)
+                s_occ[A.log_feat[k]] = 0;
+                nmatches--;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kProjThreads) A.occupied[i] = s_occ[i];
+    if (tid == 0) *A.n_matches = nmatches;
 }
 
 // ---- search core of ORBmatcher::Fuse (src/ORBmatcher.cc:1148-1338 and :1340-1455) ------------------------------
@@ -1271,8 +1656,12 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
     }
     size_t max_cells = 0;
     for (int j = 0; j < n_jobs; j++) max_cells = std::max(max_cells, (size_t)jobs[j].f->grid_cols * jobs[j].f->grid_rows);
-    const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64);
-    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (max_cells + 1) * 4 + 64;     // 52: with u_right staged
+    // k_proj_par (64 points at a time) keeps two int tables per feature in LDS; frames too large for them keep the sequential k_proj
+    static const bool force_seq = std::getenv("ORBM_PROJ_SEQUENTIAL") != nullptr;      // measurement knob (tools/proj_timing.py)
+    const size_t tabs = 8 * ((max_n + 15) & ~(size_t)15);
+    const bool par = !force_seq && tabs + ((max_n + 63) & ~(size_t)63) + 1024 <= 150 * 1024;
+    const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64) + (par ? tabs : 0);
+    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (max_cells + 1) * 4 + 64 + (par ? tabs + max_n * 16 + 32 : 0);     // 52: with u_right staged; k_proj_par: + the records in grid order
     const bool stage = lds_full <= 150 * 1024;
     const size_t lds = stage ? lds_full : lds_occ;
     for (int j = 0; j < n_jobs; j++) args[j].lds_frame = stage ? 1 : 0;
@@ -1283,7 +1672,13 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
         ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_grid, hipFuncAttributeMaxDynamicSharedMemorySize, n_pow2 * 8));
         hipLaunchKernelGGL(orbm::k_grid, dim3(n_jobs), dim3(256), (size_t)n_pow2 * 8, m->stream, (const orbm::ProjArgs*)(base + oargs), n_pow2);
     }
-    if (stage) {
+    if (par && stage) {
+        ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj_par<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(orbm::k_proj_par<true>, dim3(n_jobs), dim3(orbm::kProjThreads), lds, m->stream, (const orbm::ProjArgs*)(base + oargs));
+    } else if (par) {
+        ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj_par<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(orbm::k_proj_par<false>, dim3(n_jobs), dim3(orbm::kProjThreads), lds, m->stream, (const orbm::ProjArgs*)(base + oargs));
+    } else if (stage) {
         ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(orbm::k_proj<true>, dim3(n_jobs), dim3(64), lds, m->stream, (const orbm::ProjArgs*)(base + oargs));
     } else {

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Batched SearchByProjection(CurrentFrame, LastFrame) and SearchByProjection(Frame, MapPoints) for rocprofv3 --kernel-trace --stats:
+256 frames x 1000 features, ~900 projected points each, one launch (a wave per frame).  ORBM_PROJ_SEQUENTIAL=1 selects the
+sequential kernel (one point after the other) for comparison.
+  python tools/proj_batch_prof.py [frames] [calls]"""
+import importlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402
+import numpy as np  # noqa: E402
+
+pkg = importlib.import_module("orb_slam3-1_amd")
+sm = importlib.import_module("orb_slam3-1_amd.synth_match")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cases = [sm.make_last_frame_case(i) for i in range(16)]
+cases = [(g, dF, aF, sc, last, a.copy(), o.copy()) for (g, dF, aF, sc, last, a, o) in cases * (B // 16)]
+m = pkg.Matcher(0.9, True)
+prep = m.prepare_last_batch(cases)
+m.run_last_batch(prep, 15.0)
+t0 = time.perf_counter()
+for _ in range(N):
+    for c in cases:
+        c[5][:] = -1; c[6][:] = 0
+    nm = m.run_last_batch(prep, 15.0)
+dt = (time.perf_counter() - t0) / N
+print("last-frame search: %d frames, %.1f matches per frame, %.3f ms per call (host grid-free packing + upload + k_grid + k_proj + download)" % (len(cases), float(np.mean(nm)), 1e3 * dt))
+m.close()

@@ -21,3 +21,4 @@ n = m.SearchByProjection_last(g, dF, angF, scale, last, 15.0, assign.copy(), occ
 pkg.lib.orbm_debug_proj_prof(out)
 v = list(out)
 print("matches %d, points %d, total cycles %d (%.0f per point): window walk %d, reduction %d" % (n, v[7], v[0], v[0] / max(v[7], 1), v[1], v[2]))
+print("block-parallel kernel: passes %d, re-searched points %d, cycles speculative search %d, resolution %d" % (v[3], v[4], v[5], v[6]))
