@@ -555,6 +555,55 @@ def main():
                 cstep()
             torch.cuda.synchronize()
             dtc_ = (time.perf_counter() - t0) / 10
+            # ---- tracking chain (TrackWithMotionModel's device work per frame, src/Tracking.cc:2975-3053): extract the current frame ->
+            # DBoW2 transform -> SearchByProjection(CurrentFrame, LastFrame) against the resident last frames -> PoseOptimization.
+            # The last frames (the same scenes 3 px to the left) were extracted before the timed loop, as they are in steady state;
+            # the projection of their map points is the known shift here (u = x + 3: a few elementwise device operations);
+            # PoseOptimization runs on pre-staged synthetic problems of the same size (the C ABI has no device-resident pose entry yet).
+            try:
+                d_cur_imgs = torch.roll(d_imgs, 3, dims=2).contiguous()
+                l_kps = torch.zeros_like(d_kps); l_desc = torch.zeros_like(d_desc); l_n = torch.zeros_like(d_n)
+                ex.extract_batch_device(d_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, l_kps.data_ptr(), l_desc.data_ptr(), cap,
+                                        l_n.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
+                torch.cuda.synchronize()
+                lk = l_kps.view(torch.float32).view(B, cap, 7)
+                l_oct = l_kps.view(torch.int32).view(B, cap, 7)[:, :, 5].contiguous()
+                l_ang = lk[:, :, 3].contiguous(); l_v = lk[:, :, 1].contiguous()
+                l_valid = (torch.arange(cap, device=dev)[None, :] < l_n[:, None]).to(torch.uint8).contiguous()
+                t_assign = torch.empty(B * cap, dtype=torch.int32, device=dev); t_occ = torch.empty(B * cap, dtype=torch.uint8, device=dev)
+                t_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+                mtrk = pkg.Matcher(0.9, True, device=local_rank)
+                sfac = ex.GetScaleFactors()
+                pose_t = [synth.make_pose_problem(500 + i, n=300, outlier_frac=0.1, stereo_frac=0.0) for i in range(64)] * (B // 64)
+                ps_t = pkg.PoseSolver(device=local_rank)
+                prep_t = ps_t.prepare(pose_t)
+
+                def tstep():
+                    ex.extract_batch_device(d_cur_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, d_kps.data_ptr(), d_desc.data_ptr(), cap,
+                                            d_n.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
+                    vstep()
+                    l_u = (lk[:, :, 0] + 3.0).contiguous()
+                    t_assign.fill_(-1); t_occ.zero_()
+                    mtrk.SearchByProjection_last_batch_device((d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap),
+                                                              (l_valid.data_ptr(), l_u.data_ptr(), l_v.data_ptr(), l_oct.data_ptr(), l_ang.data_ptr(), l_desc.data_ptr(), l_n.data_ptr(), cap),
+                                                              B, 15.0, t_assign.data_ptr(), t_occ.data_ptr(), t_nm.data_ptr(), stream,
+                                                              bounds=(0.0, 0.0, float(Ww), float(Hh)), scale_factors=sfac)
+                    tstep.keep = l_u
+                    ps_t.launch(prep_t)
+                tstep(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    tstep()
+                torch.cuda.synchronize()
+                dtt = (time.perf_counter() - t0) / 10
+                out["tracking"] = {"metric": "tracking chain frames/s (extract + DBoW2 transform + SearchByProjection(last frame) + PoseOptimization)",
+                                   "value": B / dtt, "unit": "frames/s", "ms_per_batch": 1e3 * dtt,
+                                   "projection_matches_per_frame": float(t_nm.float().mean().item()),
+                                   "workload": "%d streams: current frame = last frame moved by 3 px; the search runs on the extractor's device arrays, "
+                                               "PoseOptimization on synthetic problems of 300 edges (host arrays in and out)" % B}
+                mtrk.close(); ps_t.close()
+            except Exception as e:  # noqa: BLE001
+                out["tracking"] = {"error": repr(e)}
             out["chain"] = {"metric": "device-resident front end frames/s (extract + DBoW2 transform + SearchByBoW vs previous frame)",
                             "value": B / dtc_, "unit": "frames/s", "ms_per_batch": 1e3 * dtc_,
                             "bow_matches_per_pair": float(c_nm.float().mean().item()), "workload": "%d frames = %d consecutive pairs" % (B, B // 2)}

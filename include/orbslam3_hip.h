@@ -263,6 +263,31 @@ typedef struct OrbmProjQuery {
 int orbm_search_by_projection_last_batch(orbm_matcher* m, OrbmProjQuery* queries, int n_frames, float th, int check_orientation);
 int orbm_search_by_projection_batch(orbm_matcher* m, OrbmProjQuery* queries, int n_frames, float th, int far_points, float th_far, float nnratio);
 
+/* Device-resident batch of SearchByProjection(CurrentFrame, LastFrame, th, bMono = true) (src/ORBmatcher.cc:1676-1887;
+ * Tracking::TrackWithMotionModel, src/Tracking.cc:2975) for `batch` monocular streams, nothing visits the host:
+ * the current frames are what orbx_extract_batch_device (or orbe_unpack_batch_device + orbe_undistort_batch_device) left in
+ * HBM -- [batch][cap] key-point records (pt = mvKeysUn[i].pt: for a camera with distortion pass the undistorted records),
+ * descriptors and counts; Frame::AssignFeaturesToGrid (src/Frame.cc:472-503) runs on the device.  One entry per LastFrame
+ * feature i, [batch][cap] arrays: valid = LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i] && invzc >= 0, (u, v) =
+ * project(Tcw * x3Dw) (:1704-1709; the image-bounds test :1711-1714 is done here), octave / angle =
+ * LastFrame.mvKeysUn[i], desc = pMP->GetDescriptor().  d_assign[batch][cur.cap] (in/out): index of the last-frame feature
+ * whose map point feature i now holds; d_occupied likewise = CurrentFrame.mvpMapPoints[i] && Observations() > 0;
+ * d_n_matches[batch].  Only enqueues on `stream`. */
+typedef struct OrbmDeviceFrames {
+    const OrbxKeyPoint* d_kps; const uint8_t* d_desc; const int32_t* d_n; int32_t cap;
+    float min_x, min_y, max_x, max_y;          /* mnMinX .. mnMaxY */
+    int32_t grid_cols, grid_rows;              /* FRAME_GRID_COLS, FRAME_GRID_ROWS */
+    const float* scale_factors; int32_t n_levels;      /* HOST array, mvScaleFactors */
+} OrbmDeviceFrames;
+typedef struct OrbmDeviceLastPoints {
+    const uint8_t* d_valid; const float* d_u; const float* d_v; const int32_t* d_octave; const float* d_angle;
+    const uint8_t* d_desc; const int32_t* d_n; int32_t cap;
+    const uint8_t* d_has_obs;                  /* pMP->Observations() > 0 per entry; NULL = all (monocular maps hold no temporal points) */
+} OrbmDeviceLastPoints;
+int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* last, int batch,
+                                                float th, int check_orientation, int32_t* d_assign, uint8_t* d_occupied,
+                                                int32_t* d_n_matches, void* stream);
+
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, float th,
  *                                    int ORBdist) (src/ORBmatcher.cc:1889-2010; Tracking::Relocalization).
  * One entry per pKF->GetMapPointMatches()[i]: valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP) && dist3D inside

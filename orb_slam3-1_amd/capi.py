@@ -446,6 +446,27 @@ class Matcher:
         _check(lib.orbm_search_by_projection_last_batch(self._h, prep["qs"], prep["n"], C.c_float(th), int(self.check_ori)))
         return [q.n_matches for q in prep["qs"]]
 
+    class _DevFrames(C.Structure):
+        _fields_ = [("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("d_n", C.c_void_p), ("cap", C.c_int32),
+                    ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                    ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("scale_factors", C.c_void_p), ("n_levels", C.c_int32)]
+
+    class _DevLastPoints(C.Structure):
+        _fields_ = [("d_valid", C.c_void_p), ("d_u", C.c_void_p), ("d_v", C.c_void_p), ("d_octave", C.c_void_p), ("d_angle", C.c_void_p),
+                    ("d_desc", C.c_void_p), ("d_n", C.c_void_p), ("cap", C.c_int32), ("d_has_obs", C.c_void_p)]
+
+    def SearchByProjection_last_batch_device(self, cur, last, batch, th, d_assign, d_occupied, d_n_matches, stream=None, bounds=(0.0, 0.0, 640.0, 480.0),
+                                             scale_factors=None, grid=(64, 48)):
+        """cur = (d_kps, d_desc, d_n, cap) as orbx_extract_batch_device left them; last = (d_valid, d_u, d_v, d_octave, d_angle, d_desc, d_n, cap);
+        every d_* a device pointer.  Only enqueues."""
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        self._dev_keep = sf
+        cf = self._DevFrames(cur[0], cur[1], cur[2], int(cur[3]), bounds[0], bounds[1], bounds[2], bounds[3], grid[0], grid[1], sf.ctypes.data, len(sf))
+        lp = self._DevLastPoints(last[0], last[1], last[2], last[3], last[4], last[5], last[6], int(last[7]), last[8] if len(last) > 8 else None)
+        lib.orbm_search_by_projection_last_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib.orbm_search_by_projection_last_batch_device(self._h, C.byref(cf), C.byref(lp), int(batch), C.c_float(th), int(self.check_ori),
+                                                               C.c_void_p(d_assign), C.c_void_p(d_occupied), C.c_void_p(d_n_matches), C.c_void_p(stream or 0)))
+
     class _TriSide(C.Structure):
         _fields_ = [("n", C.c_int32), ("desc", C.c_void_p), ("has_mp", C.c_void_p), ("stereo", C.c_void_p), ("x", C.c_void_p),
                     ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("fv", FeatVec)]

@@ -1047,6 +1047,50 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     if (tid == 0) *A.n_matches = nmatches;
 }
 
+// ---- device-resident batch of SearchByProjection(CurrentFrame, LastFrame) ------------------------------------------------
+// The frames are what orbx_extract_batch_device left in HBM ([batch][cap] OrbxKeyPoint records + descriptors + counts): one
+// setup launch turns them into the SoA arrays the search kernels read and writes the job table ON THE DEVICE (the counts never
+// visit the host); k_grid builds Frame::AssignFeaturesToGrid, k_proj_par searches.
+struct ProjDevSetup {
+    const OrbxKeyPoint* kps; const uint8_t* desc; const int32_t* n; int32_t cap;
+    const uint8_t* p_valid; const float* p_u; const float* p_v; const int32_t* p_oct; const float* p_angle; const uint8_t* p_desc; const int32_t* p_n; int32_t p_cap; const uint8_t* p_obs;
+    float* x; float* y; int32_t* oct; float* ang; int32_t* cell_off; int32_t* cell_feat; int32_t* log_feat; int32_t* log_bin;
+    const float* scale; int32_t n_levels, cols, rows;
+    float min_x, min_y, max_x, max_y, th, dist_th;
+    int32_t check_ori, lds_frame;
+    int32_t* assign; uint8_t* occupied; int32_t* n_matches;
+    ProjArgs* jobs;
+};
+__global__ __launch_bounds__(256) void k_proj_dev_setup(ProjDevSetup P)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(max(P.n[b], 0), P.cap);
+    const OrbxKeyPoint* kp = P.kps + (size_t)b * P.cap;
+    float* x = P.x + (size_t)b * P.cap; float* y = P.y + (size_t)b * P.cap; float* ang = P.ang + (size_t)b * P.cap;
+    int32_t* oct = P.oct + (size_t)b * P.cap;
+    for (int i = tid; i < n; i += 256) { const OrbxKeyPoint k = kp[i]; x[i] = k.x; y[i] = k.y; oct[i] = k.octave; ang[i] = k.angle; }
+    if (tid == 0) {
+        ProjArgs A;
+        A.F.x = x; A.F.y = y; A.F.octave = oct; A.F.angle = ang; A.F.desc = P.desc + (size_t)b * P.cap * 32;
+        A.F.cell_off = P.cell_off + (size_t)b * ((size_t)P.cols * P.rows + 1); A.F.cell_feat = P.cell_feat + (size_t)b * P.cap;
+        A.F.scale_factors = P.scale;
+        A.F.min_x = P.min_x; A.F.min_y = P.min_y; A.F.max_x = P.max_x; A.F.max_y = P.max_y;
+        A.F.winv = (float)P.cols / (P.max_x - P.min_x); A.F.hinv = (float)P.rows / (P.max_y - P.min_y);        // mfGridElementWidthInv / HeightInv
+        A.F.n = n; A.F.cols = P.cols; A.F.rows = P.rows; A.F.n_levels = P.n_levels; A.F.u_right = nullptr;
+        A.n_pts = min(max(P.p_n[b], 0), P.p_cap);
+        A.valid = P.p_valid + (size_t)b * P.p_cap; A.u = P.p_u + (size_t)b * P.p_cap; A.v = P.p_v + (size_t)b * P.p_cap; A.ur = nullptr;
+        A.level = P.p_oct + (size_t)b * P.p_cap; A.view_cos = nullptr; A.depth = nullptr; A.bad = nullptr;
+        A.angle = P.p_angle + (size_t)b * P.p_cap; A.desc = P.p_desc + (size_t)b * P.p_cap * 32; A.has_obs = P.p_obs ? P.p_obs + (size_t)b * P.p_cap : nullptr;
+        A.th = P.th; A.th_far = 0.f; A.nnratio = 0.f; A.dist_th = P.dist_th; A.far_points = 0; A.check_ori = P.check_ori;
+        A.last_frame_mode = 1; A.level_window = ORBM_LEVELS_AROUND;
+        A.assign = P.assign + (size_t)b * P.cap; A.occupied = P.occupied + (size_t)b * P.cap;
+        A.log_feat = P.log_feat + (size_t)b * P.p_cap; A.log_bin = P.log_bin + (size_t)b * P.p_cap;
+        A.n_matches = P.n_matches + b;
+        A.lds_frame = P.lds_frame;
+        P.jobs[b] = A;
+    }
+}
+
 // ---- search core of ORBmatcher::Fuse (src/ORBmatcher.cc:1148-1338 and :1340-1455) ------------------------------
 // The candidate map points are independent of each other (nothing the loop writes feeds back into the search), so this
 // is one wave per map point: 64 lanes walk the cells of the window, the first-minimum in visiting order comes out of the
@@ -1387,6 +1431,9 @@ struct orbm_matcher {
     uint8_t* d_blob = nullptr;
     size_t blob_cap = 0;
     std::vector<uint8_t> h_blob;
+    uint8_t* d_ws = nullptr;            // workspace of the device-resident batch entries (SoA key points, grids, logs, job table)
+    size_t ws_cap = 0;
+    float* d_scale = nullptr;           // scale factors of the last device-resident call
 
     int ensure(size_t bytes)
     {
@@ -1746,6 +1793,8 @@ void orbm_destroy(orbm_matcher* m)
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
     if (m->d_blob) (void)hipFree(m->d_blob);
+    if (m->d_ws) (void)hipFree(m->d_ws);
+    if (m->d_scale) (void)hipFree(m->d_scale);
     delete m;
 }
 
@@ -1983,6 +2032,72 @@ int orbm_search_by_projection_last_batch(orbm_matcher* m, OrbmProjQuery* queries
 int orbm_search_by_projection_batch(orbm_matcher* m, OrbmProjQuery* queries, int n_frames, float th, int far_points, float th_far, float nnratio)
 {
     return run_projection_batch(m, queries, n_frames, 0, th, far_points, th_far, nnratio, 0, (float)orbm::TH_HIGH);
+}
+
+int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* last, int batch,
+                                                float th, int check_orientation, int32_t* d_assign, uint8_t* d_occupied, int32_t* d_n_matches, void* stream)
+{
+    if (!m || !cur || !last || !d_assign || !d_occupied || !d_n_matches) return fail(ORBX_ERR_ARG, "NULL argument");
+    if (batch < 1 || cur->cap < 1 || last->cap < 1) return fail(ORBX_ERR_ARG, "bad batch / capacities");
+    if (!cur->d_kps || !cur->d_desc || !cur->d_n || !cur->scale_factors || cur->n_levels < 1 || cur->n_levels > 32) return fail(ORBX_ERR_ARG, "bad current-frame description");
+    if (!last->d_valid || !last->d_u || !last->d_v || !last->d_octave || !last->d_desc || !last->d_n || (check_orientation && !last->d_angle)) return fail(ORBX_ERR_ARG, "bad last-frame description");
+    if (cur->grid_cols < 1 || cur->grid_rows < 1 || cur->grid_cols * (int64_t)cur->grid_rows > (1 << 20) || !(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y)) return fail(ORBX_ERR_ARG, "bad frame grid");
+    if (cur->cap > 8192) return fail(ORBX_ERR_CAPACITY, "at most 8192 features per frame (the grid is sorted in LDS)");
+    ORBM_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = (size_t)batch, cap = (size_t)cur->cap, pcap = (size_t)last->cap, cells = (size_t)cur->grid_cols * cur->grid_rows;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t o_x = off; off += al(B * cap * 4);
+    const size_t o_y = off; off += al(B * cap * 4);
+    const size_t o_oct = off; off += al(B * cap * 4);
+    const size_t o_ang = off; off += al(B * cap * 4);
+    const size_t o_coff = off; off += al(B * (cells + 1) * 4);
+    const size_t o_cfeat = off; off += al(B * cap * 4);
+    const size_t o_lf = off; off += al(B * pcap * 4);
+    const size_t o_lb = off; off += al(B * pcap * 4);
+    const size_t o_jobs = off; off += al(B * sizeof(orbm::ProjArgs));
+    if (off > m->ws_cap) {
+        if (m->d_ws) { ORBM_HIP(hipDeviceSynchronize()); (void)hipFree(m->d_ws); }
+        m->d_ws = nullptr; m->ws_cap = 0;
+        ORBM_HIP(hipMalloc((void**)&m->d_ws, off + off / 4));
+        m->ws_cap = off + off / 4;
+    }
+    if (!m->d_scale) ORBM_HIP(hipMalloc((void**)&m->d_scale, 32 * sizeof(float)));
+    ORBM_HIP(hipMemcpyAsync(m->d_scale, cur->scale_factors, sizeof(float) * cur->n_levels, hipMemcpyHostToDevice, st));
+    // LDS of the search kernel, as in run_projection_jobs
+    const size_t max_n = cap;
+    const size_t tabs = 8 * ((max_n + 15) & ~(size_t)15);
+    if (tabs + ((max_n + 63) & ~(size_t)63) + 1024 > 150 * 1024) return fail(ORBX_ERR_CAPACITY, "frames of %zu features exceed the search kernel's LDS tables", max_n);
+    const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64) + tabs;
+    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (cells + 1) * 4 + 64 + tabs + max_n * 16 + 32;
+    const bool stage = lds_full <= 150 * 1024;
+    const size_t lds = stage ? lds_full : lds_occ;
+    orbm::ProjDevSetup P;
+    P.kps = cur->d_kps; P.desc = cur->d_desc; P.n = cur->d_n; P.cap = cur->cap;
+    P.p_valid = last->d_valid; P.p_u = last->d_u; P.p_v = last->d_v; P.p_oct = last->d_octave; P.p_angle = last->d_angle; P.p_desc = last->d_desc; P.p_n = last->d_n; P.p_cap = last->cap; P.p_obs = last->d_has_obs;
+    uint8_t* w = m->d_ws;
+    P.x = (float*)(w + o_x); P.y = (float*)(w + o_y); P.oct = (int32_t*)(w + o_oct); P.ang = (float*)(w + o_ang);
+    P.cell_off = (int32_t*)(w + o_coff); P.cell_feat = (int32_t*)(w + o_cfeat); P.log_feat = (int32_t*)(w + o_lf); P.log_bin = (int32_t*)(w + o_lb);
+    P.scale = m->d_scale; P.n_levels = cur->n_levels; P.cols = cur->grid_cols; P.rows = cur->grid_rows;
+    P.min_x = cur->min_x; P.min_y = cur->min_y; P.max_x = cur->max_x; P.max_y = cur->max_y; P.th = th; P.dist_th = (float)orbm::TH_HIGH;
+    P.check_ori = check_orientation; P.lds_frame = stage ? 1 : 0;
+    P.assign = d_assign; P.occupied = d_occupied; P.n_matches = d_n_matches;
+    P.jobs = (orbm::ProjArgs*)(w + o_jobs);
+    hipLaunchKernelGGL(orbm::k_proj_dev_setup, dim3(batch), dim3(256), 0, st, P);
+    int n_pow2 = 2;
+    while ((size_t)n_pow2 < max_n) n_pow2 <<= 1;
+    ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_grid, hipFuncAttributeMaxDynamicSharedMemorySize, n_pow2 * 8));
+    hipLaunchKernelGGL(orbm::k_grid, dim3(batch), dim3(256), (size_t)n_pow2 * 8, st, (const orbm::ProjArgs*)P.jobs, n_pow2);
+    if (stage) {
+        ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj_par<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(orbm::k_proj_par<true>, dim3(batch), dim3(orbm::kProjThreads), lds, st, (const orbm::ProjArgs*)P.jobs);
+    } else {
+        ORBM_HIP(hipFuncSetAttribute((const void*)orbm::k_proj_par<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(orbm::k_proj_par<false>, dim3(batch), dim3(orbm::kProjThreads), lds, st, (const orbm::ProjArgs*)P.jobs);
+    }
+    ORBM_HIP(hipGetLastError());
+    return ORBX_OK;
 }
 
 #ifdef ORBM_PROJ_TIMING

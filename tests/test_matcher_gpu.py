@@ -281,3 +281,47 @@ def test_search_by_projection_last_batch(pkg, oracle, sm):
     for (n0, a0, o0), n1, c in zip(refs, ns, cases):
         assert n1 == n0
         np.testing.assert_array_equal(c[5], a0); np.testing.assert_array_equal(c[6], o0)
+
+
+def test_search_by_projection_last_batch_device(pkg, oracle, sm):
+    """the device-resident batch entry of SearchByProjection(CurrentFrame, LastFrame): frames as [batch][cap] key-point records +
+    descriptors + counts in HBM (what orbx_extract_batch_device leaves), last-frame points as device arrays, ragged counts, the
+    grid built on the device -- against the oracle frame by frame (assignments, occupancy, match counts)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, cap, pcap = 12, 1100, 1000
+    cases = [sm.make_last_frame_case(40 + i, n=1000 - 37 * (i % 5), n_last=900 - 41 * (i % 4)) for i in range(B)]
+    scale = cases[0][3]
+    kps = np.zeros((B, cap), pkg.KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); nn = np.zeros(B, np.int32)
+    pv = np.zeros((B, pcap), np.uint8); pu = np.zeros((B, pcap), np.float32); pw = np.zeros((B, pcap), np.float32)
+    po = np.zeros((B, pcap), np.int32); pa = np.zeros((B, pcap), np.float32); pd = np.zeros((B, pcap, 32), np.uint8); pn = np.zeros(B, np.int32)
+    ph = np.zeros((B, pcap), np.uint8)
+    assign = np.full((B, cap), -1, np.int32); occ = np.zeros((B, cap), np.uint8)
+    for b, (g, dF, aF, sc, last, a, o) in enumerate(cases):
+        n = len(g["x"]); nn[b] = n
+        kps[b, :n]["x"] = g["x"]; kps[b, :n]["y"] = g["y"]; kps[b, :n]["octave"] = g["octave"]; kps[b, :n]["angle"] = aF
+        desc[b, :n] = dF
+        m_ = len(last["u"]); pn[b] = m_
+        pv[b, :m_] = last["valid"]; pu[b, :m_] = last["u"]; pw[b, :m_] = last["v"]; po[b, :m_] = last["octave"]; pa[b, :m_] = last["angle"]; pd[b, :m_] = last["desc"]; ph[b, :m_] = last["has_obs"]
+        assign[b, :n] = a; occ[b, :n] = o
+        assert (g["min_x"], g["min_y"], g["max_x"], g["max_y"]) == (cases[0][0]["min_x"], cases[0][0]["min_y"], cases[0][0]["max_x"], cases[0][0]["max_y"])
+    t = lambda a_: torch.from_numpy(np.ascontiguousarray(a_).view(np.uint8).reshape(-1)).to(dev)
+    d = {k: t(v) for k, v in dict(kps=kps, desc=desc, n=nn, pv=pv, pu=pu, pw=pw, po=po, pa=pa, pd=pd, pn=pn, ph=ph, assign=assign, occ=occ).items()}
+    d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    g0 = cases[0][0]
+    m = pkg.Matcher(0.9, True)
+    try:
+        m.SearchByProjection_last_batch_device((d["kps"].data_ptr(), d["desc"].data_ptr(), d["n"].data_ptr(), cap),
+                                               (d["pv"].data_ptr(), d["pu"].data_ptr(), d["pw"].data_ptr(), d["po"].data_ptr(), d["pa"].data_ptr(), d["pd"].data_ptr(), d["pn"].data_ptr(), pcap, d["ph"].data_ptr()),
+                                               B, 15.0, d["assign"].data_ptr(), d["occ"].data_ptr(), d_nm.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                                               bounds=(g0["min_x"], g0["min_y"], g0["max_x"], g0["max_y"]), scale_factors=scale)
+        torch.cuda.synchronize()
+    finally:
+        m.close()
+    a1 = d["assign"].cpu().numpy().view(np.int32).reshape(B, cap); o1 = d["occ"].cpu().numpy().reshape(B, cap); nm = d_nm.cpu().numpy()
+    for b, (g, dF, aF, sc, last, a, o) in enumerate(cases):
+        a0, o0 = a.copy(), o.copy()
+        n0 = oracle.search_by_projection_last(g, dF, aF, sc, last, 15.0, True, a0, o0)
+        n = len(g["x"])
+        assert nm[b] == n0 > 100, "frame %d" % b
+        np.testing.assert_array_equal(a1[b, :n], a0); np.testing.assert_array_equal(o1[b, :n], o0)
