@@ -63,6 +63,8 @@ struct Dev {        // device pointers of one problem (passed by value to kernel
     double* err; double* rho0;      // [nE][3], [nE]
     double* x;                      // [n + 3 nL]
     double* part;                   // scale partials [nL + nP]
+    double* chi_part;               // robust chi2 of a landmark's edges [nL] (k_update_errors)
+    unsigned int* ticket;           // workgroups of k_update_errors that are done (the last one reduces)
     double* scal;                   // [16] scalars: 0 chi2, 1 max diag (poses), 2 max diag (landmarks), 3 scale poses, 4 scale landmarks, 5 chol fail flag
     Cam cam;
 };
@@ -457,6 +459,7 @@ __device__ __forceinline__ void schur_blocks_body(Dev d, double* __restrict__ S,
 __global__ __launch_bounds__(kSchurThreads) void k_schur_blocks(Dev d, double* __restrict__ S, double lambda_diag,
                                                       double* __restrict__ bs, double* __restrict__ bp_out, double* __restrict__ diag_out)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.scal[5] = 0.0;        // the factorisation's failure flag of this trial (it was a memset per trial)
     schur_blocks_body(d, S, lambda_diag, bs, bp_out, diag_out, (int)blockIdx.x);
 }
 
@@ -1042,6 +1045,143 @@ __global__ __launch_bounds__(64) void k_backsub_update(Dev d, double lambda, con
     backsub_update_body(d, lambda, bp_full, poses, pts, poses_new, pts_new, (int)blockIdx.x);
 }
 
+// ---- the trial's tail in two launches (round 3; it was four: substitution, k_backsub_update, k_errors, k_reduce) ----
+// (a) the substitution workgroup goes straight on to the trial poses: oplus of every pose and the pose part of the scale sum
+__device__ __forceinline__ void pose_update_tail(const Dev& d, double lambda, const double* __restrict__ bp_full,
+                                                 const double* __restrict__ poses, double* __restrict__ poses_new)
+{
+    __syncthreads();                // x of this workgroup's substitution is complete (global memory, same workgroup)
+    for (int ip = threadIdx.x; ip < d.nPoses; ip += blockDim.x) {
+        const int col = d.pose_col[ip];
+        if (col < 0) {
+            for (int k = 0; k < 7; k++) poses_new[7 * (size_t)ip + k] = poses[7 * (size_t)ip + k];
+        } else {
+            const double* xp = d.x + 6 * (size_t)col;
+            pose_oplus(poses + 7 * (size_t)ip, xp, poses_new + 7 * (size_t)ip);
+            double sc = 0;
+            for (int a = 0; a < 6; a++) sc += xp[a] * (lambda * xp[a] + bp_full[6 * (size_t)col + a]);
+            d.part[d.nL + col] = sc;
+        }
+    }
+}
+template <bool PRE>
+__global__ __launch_bounds__(1024) void k_chol_solve_update(const double* __restrict__ S, int n, const double* __restrict__ Linv,
+                                                            const double* __restrict__ yin, const double* __restrict__ yin_last,
+                                                            const double* __restrict__ scal, int last_forward,
+                                                            Dev d, double lambda, const double* __restrict__ bp_full,
+                                                            const double* __restrict__ poses, double* __restrict__ poses_new)
+{
+    extern __shared__ double sm[];
+    if (n > 0) chol_solve_body<PRE>(S, n, Linv, yin, yin_last, d.x, scal, last_forward, 0, sm);
+    pose_update_tail(d, lambda, bp_full, poses, poses_new);
+}
+
+// (b) EIGHT lanes per landmark (a landmark has ~10 edges; one thread per landmark walked them one after the other and the
+// launch took 35 us): the lanes split the edges for the back-substitution sum W_e^T x_p and for the errors + robust chi2 of the
+// landmark's own edges at the trial state (every edge belongs to exactly one landmark), butterfly sums inside the 8 lanes;
+// the workgroup that finishes last sums the per-landmark partials in a fixed order and publishes the scalars to the host
+// (as k_reduce mode 1 did).
+constexpr int kUpdThreads = 256, kUpdLandmarks = kUpdThreads / 8;
+__device__ __forceinline__ void st_agent(double* p, double v)       // agent-scope store (reaches memory every XCD sees)
+{
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void update_errors_body(const Dev& d, double lambda, const double* __restrict__ pts,
+                                                   const double* __restrict__ poses_new, double* __restrict__ pts_new,
+                                                   double* __restrict__ hmap, unsigned long long seq, const int bx, const int n_blocks)
+{
+    __shared__ double s_a[kUpdThreads / 64], s_b[kUpdThreads / 64], s_c[kUpdThreads / 64];
+    __shared__ unsigned int s_ticket;
+    const int tid = threadIdx.x, sub = tid & 7;
+    const int l = bx * kUpdLandmarks + (tid >> 3);
+    const bool live = l < d.nL;
+    double cs[3] = {0, 0, 0};
+    int k0 = 0, k1 = 0;
+    if (live) {
+        k0 = d.l_off[l]; k1 = d.l_off[l + 1];
+        for (int k = k0 + sub; k < k1; k += 8) {
+            const int e = d.l_edge[k];
+            const int col = d.pose_col[d.e_pose[e]];
+            if (col < 0) continue;
+            const double* W = d.W + 18 * (size_t)e;
+            const double* xp = d.x + 6 * (size_t)col;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                double s2 = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) s2 += W[r * 3 + q] * xp[r];
+                cs[q] += s2;
+            }
+        }
+    }
+    for (int q = 0; q < 3; q++)
+        for (int o = 4; o > 0; o >>= 1) cs[q] += __shfl_xor(cs[q], o);
+    double chi_l = 0;
+    if (live) {
+        const double c[3] = {d.bl[3 * (size_t)l] - cs[0], d.bl[3 * (size_t)l + 1] - cs[1], d.bl[3 * (size_t)l + 2] - cs[2]};
+        const double* Di = d.Dinv + 9 * (size_t)l;
+        double sc = 0, Xn[3];
+        for (int a = 0; a < 3; a++) {
+            const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
+            Xn[a] = pts[3 * (size_t)l + a] + xl;
+            sc += xl * (lambda * xl + d.bl[3 * (size_t)l + a]);
+            if (sub == 0) { d.x[(size_t)d.n + 3 * (size_t)l + a] = xl; pts_new[3 * (size_t)l + a] = Xn[a]; }
+        }
+        if (sub == 0) st_agent(d.part + l, sc);
+        // errors of the landmark's edges at the trial state (computeActiveErrors + robustify)
+        for (int k = k0 + sub; k < k1; k += 8) {
+            const int e = d.l_edge[k];
+            double Xc[3], r[3];
+            pose_map(poses_new + 7 * (size_t)d.e_pose[e], Xn, Xc);
+            const int st = d.e_stereo[e];
+            edge_residual(d.cam, Xc, d.e_obs + 3 * (size_t)e, st, r);
+            const double w = d.e_w[e];
+            double chi = r[0] * (w * r[0]) + r[1] * (w * r[1]);
+            if (st) chi += r[2] * (w * r[2]);
+            double rho0, rho1;
+            huber(d.cam, st, chi, rho0, rho1);
+            d.err[3 * (size_t)e] = r[0]; d.err[3 * (size_t)e + 1] = r[1]; d.err[3 * (size_t)e + 2] = r[2];
+            d.rho0[e] = rho0;
+            chi_l += rho0;
+        }
+    }
+    for (int o = 4; o > 0; o >>= 1) chi_l += __shfl_xor(chi_l, o);
+    if (live && sub == 0) st_agent(d.chi_part + l, chi_l);
+    // ---- the last workgroup to get here reduces.  The partials come from workgroups on other XCDs, whose L2 is not coherent with
+    // this one's: they are STORED and LOADED at agent scope (write-through / cache-bypassing accesses of exactly these words) and
+    // drained before the ticket.  (A __threadfence() pair here is a whole-L2 write-back + invalidate per workgroup: with 32 windows
+    // per launch -- 2 000 workgroups -- it made this kernel 380 us.) ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // this thread's stores have left (s_waitcnt vmcnt(0))
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(d.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (unsigned)(n_blocks - 1)) return;
+    auto ld = [](const double* p) {     // agent-scope load: never served from a cache that another XCD's store has not reached
+        return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    double a = 0, b = 0, c = 0;
+    for (int i = tid; i < d.nL; i += kUpdThreads) { a += ld(d.chi_part + i); c += ld(d.part + i); }
+    for (int i = tid; i < d.nP; i += kUpdThreads) b += ld(d.part + d.nL + i);
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    if ((tid & 63) == 0) { s_a[tid >> 6] = a; s_b[tid >> 6] = b; s_c[tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        a = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3]; b = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3]; c = ((s_c[0] + s_c[1]) + s_c[2]) + s_c[3];
+        d.scal[0] = a; d.scal[3] = b; d.scal[4] = c;
+        __hip_atomic_store(d.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hmap) {
+            hmap[0] = a; hmap[3] = b; hmap[4] = c; hmap[5] = d.scal[5];
+            __threadfence_system();
+            __hip_atomic_store((unsigned long long*)(hmap + 8), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ __launch_bounds__(kUpdThreads) void k_update_errors(Dev d, double lambda, const double* __restrict__ pts, const double* __restrict__ poses_new,
+                                                               double* __restrict__ pts_new, double* __restrict__ hmap, unsigned long long seq)
+{
+    update_errors_body(d, lambda, pts, poses_new, pts_new, hmap, seq, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Batched windows (lba_solve_batch): the SAME kernel bodies, one launch per stage for W independent windows, grid.y = window.
 // The single-workgroup stages of a window (diagonal factorisation, block-column steps, substitution, reductions) leave the chip
@@ -1129,6 +1269,25 @@ __global__ __launch_bounds__(1024) void k_chol_solve_b(const BWin* __restrict__ 
     const int n = w.d.n;
     if (n <= 0) return;
     chol_solve_body<true>(w.Lp, n, w.Linv, w.Lp + (size_t)n * n, w.bs, w.d.x, w.d.scal, 1, 0, sm);
+}
+__global__ __launch_bounds__(1024) void k_chol_solve_update_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    extern __shared__ double sm[];
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    const int n = w.d.n;
+    if (n > 0) chol_solve_body<true>(w.Lp, n, w.Linv, w.Lp + (size_t)n * n, w.bs, w.d.x, w.d.scal, 1, 0, sm);
+    pose_update_tail(w.d, y.lambda, w.bpf, w.poses[y.cur], w.poses[1 - y.cur]);
+}
+__global__ __launch_bounds__(kUpdThreads) void k_update_errors_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    const int nb = max((w.d.nL + kUpdLandmarks - 1) / kUpdLandmarks, 1);
+    if ((int)blockIdx.x >= nb) return;
+    update_errors_body(w.d, y.lambda, w.pts[y.cur], w.poses[1 - y.cur], w.pts[1 - y.cur], w.hmap, y.seq, (int)blockIdx.x, nb);
 }
 __global__ __launch_bounds__(64) void k_backsub_update_b(const BWin* __restrict__ wins, BDynAll dyn)
 {
@@ -1420,6 +1579,7 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     LBA_TRY(s->dalloc(&d.Dinv, 9 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.db, 3 * (size_t)d.nL));
     LBA_TRY(s->dalloc(&d.err, 3 * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.rho0, (size_t)d.nE));
     LBA_TRY(s->dalloc(&d.x, (size_t)d.n + 3 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.part, (size_t)d.nL + d.nP));
+    LBA_TRY(s->dalloc(&d.chi_part, (size_t)d.nL)); LBA_TRY(s->dalloc(&d.ticket, 64));
     LBA_TRY(s->dalloc(&d.scal, 16));
     LBA_TRY(s->dalloc(&s->poses[1], 7 * (size_t)p->n_poses)); LBA_TRY(s->dalloc(&s->pts[1], 3 * (size_t)d.nL));
     s->reduce_len = (int64_t)d.n * d.n + 3 * (int64_t)d.n;
@@ -1433,6 +1593,8 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
         if (solve_lds > 160 * 1024) LBA_TRY(fail(ORBX_ERR_CAPACITY, "%d reduced unknowns exceed the substitution kernel's LDS", d.n));
         LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
         LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
+        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
+        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
     }
     LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
@@ -1446,6 +1608,7 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
         (r = s->flush_stage())) { lba_shard_destroy(s); return r; }
     LBA_HIP(hipMemsetAsync(d.err, 0, 3 * (size_t)std::max(d.nE, 1) * sizeof(double), s->stream));
     LBA_HIP(hipMemsetAsync(d.scal, 0, 16 * sizeof(double), s->stream));
+    LBA_HIP(hipMemsetAsync(d.ticket, 0, 64 * sizeof(unsigned int), s->stream));
     d.cam.fx = p->fx; d.cam.fy = p->fy; d.cam.cx = p->cx; d.cam.cy = p->cy; d.cam.bf = p->bf;
     d.cam.huber_mono = p->huber_mono; d.cam.huber_stereo = p->huber_stereo;
     d.cam.dsqr_mono = p->huber_mono * p->huber_mono; d.cam.dsqr_stereo = p->huber_stereo * p->huber_stereo;    // RobustKernelHuber::setDelta
@@ -1693,7 +1856,6 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
     const double* X = s->pts[s->cur];
     double* Pn = s->poses[1 - s->cur];
     double* Xn = s->pts[1 - s->cur];
-    LBA_HIP(hipMemsetAsync(d.scal + 5, 0, sizeof(double), s->stream));
     s->mark(lba::kStageFactor);
     if (n > 0) {
         if (!s->lambda_added) hipLaunchKernelGGL(lba::k_add_lambda, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->S(), n, lambda);
@@ -1717,17 +1879,20 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
                 hipLaunchKernelGGL(lba::k_chol_update, dim3(t, t), dim3(256), 0, s->stream, s->S(), n, n + 1, k0, nb, (const double*)d.scal);
             }
         }
-        s->mark(lba::kStageSolve);
-        hipLaunchKernelGGL(fused ? lba::k_chol_solve<true> : lba::k_chol_solve<false>, dim3(1), dim3(1024),
-                           ((size_t)n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double), s->stream,
-                           (const double*)(fused ? s->Lp : s->S()), n, (const double*)s->Linv,
-                           (const double*)(fused ? s->Lp + (size_t)n * n : s->bs()), (const double*)s->bs(), d.x, (const double*)d.scal, fused ? 1 : 0);
+    }
+    s->mark(lba::kStageSolve);
+    {
+        const bool fused = n > 0 && s->nblk <= lba::kFusedMaxBlocks;
+        const size_t solve_lds = ((size_t)n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
+        if (fused || n == 0)
+            hipLaunchKernelGGL(lba::k_chol_solve_update<true>, dim3(1), dim3(1024), solve_lds, s->stream, (const double*)s->Lp, n, (const double*)s->Linv,
+                               (const double*)(s->Lp ? s->Lp + (size_t)n * n : nullptr), (const double*)s->bs(), (const double*)d.scal, 1, d, lambda, (const double*)s->bpf(), P, Pn);
+        else
+            hipLaunchKernelGGL(lba::k_chol_solve_update<false>, dim3(1), dim3(1024), solve_lds, s->stream, (const double*)s->S(), n, (const double*)s->Linv,
+                               (const double*)s->bs(), (const double*)s->bs(), (const double*)d.scal, 0, d, lambda, (const double*)s->bpf(), P, Pn);
     }
     s->mark(lba::kStageUpdate);
-    hipLaunchKernelGGL(lba::k_backsub_update, dim3((d.nL + d.nPoses + 63) / 64), dim3(64), 0, s->stream, d, lambda, s->bpf(), P, X, Pn, Xn);
-    if (d.nE > 0) hipLaunchKernelGGL(lba::k_errors, dim3((d.nE + 255) / 256), dim3(256), 0, s->stream, d, (const double*)Pn, (const double*)Xn);
-    s->mark(lba::kStageReduce);
-    hipLaunchKernelGGL(lba::k_reduce, dim3(1), dim3(1024), 0, s->stream, d, 1, s->d_hmap, ++s->seq);
+    hipLaunchKernelGGL(lba::k_update_errors, dim3(std::max((d.nL + lba::kUpdLandmarks - 1) / lba::kUpdLandmarks, 1)), dim3(lba::kUpdThreads), 0, s->stream, d, lambda, X, (const double*)Pn, Xn, s->d_hmap, ++s->seq);
     s->mark(lba::kStageIdle);
     LBA_HIP(hipGetLastError());
     int r = read_scalars(s);
@@ -2076,13 +2241,13 @@ int lba_solve_batch(lba_batch* b, const LbaProblem* problems, const LbaOutputs* 
         w.S = s->S(); w.bs = s->bs(); w.bpf = s->bpf(); w.diag = s->diag(); w.Lp = s->Lp; w.Linv = s->Linv; w.hmap = s->d_hmap; w.nblk = s->nblk;
         const lba::Dev& d = s->d;
         max_lin = std::max(max_lin, d.nP + (d.nL + 31) / 32); max_e = std::max(max_e, (d.nE + 255) / 256); max_lm = std::max(max_lm, (d.nL + 7) / 8);
-        max_sb = std::max(max_sb, d.nBlocks + d.nP); max_nblk = std::max(max_nblk, s->nblk); max_upd = std::max(max_upd, (d.nL + d.nPoses + 63) / 64);
+        max_sb = std::max(max_sb, d.nBlocks + d.nP); max_nblk = std::max(max_nblk, s->nblk); max_upd = std::max(max_upd, (d.nL + lba::kUpdLandmarks - 1) / lba::kUpdLandmarks);
         max_n = std::max(max_n, d.n);
     }
     if (r) { cleanup(); return r; }
     const size_t solve_lds = ((size_t)max_n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
     if (hipFuncSetAttribute((const void*)lba::k_chol_step_b, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lba::k_chol_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lba::k_chol_solve_update_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)) != hipSuccess ||
         hipMemcpyAsync(b->d_wins, hw.data(), (size_t)W * sizeof(lba::BWin), hipMemcpyHostToDevice, b->stream) != hipSuccess) {
         cleanup();
         return fail(ORBX_ERR_HIP, "batch setup failed");
@@ -2149,10 +2314,8 @@ int lba_solve_batch(lba_batch* b, const LbaProblem* problems, const LbaOutputs* 
                 const int T = max_nblk - 1 - K;
                 hipLaunchKernelGGL(lba::k_chol_step_b, dim3(T * (T + 1) / 2, W), dim3(256), lba::kStepLds, st, (const lba::BWin*)b->d_wins, dyn, K);
             }
-            hipLaunchKernelGGL(lba::k_chol_solve_b, dim3(1, W), dim3(1024), solve_lds, st, (const lba::BWin*)b->d_wins, dyn);
-            hipLaunchKernelGGL(lba::k_backsub_update_b, dim3(max_upd, W), dim3(64), 0, st, (const lba::BWin*)b->d_wins, dyn);
-            hipLaunchKernelGGL(lba::k_errors_b, dim3(max_e, W), dim3(256), 0, st, (const lba::BWin*)b->d_wins, dyn, 1);
-            hipLaunchKernelGGL(lba::k_reduce_b, dim3(1, W), dim3(1024), 0, st, (const lba::BWin*)b->d_wins, dyn, 1);
+            hipLaunchKernelGGL(lba::k_chol_solve_update_b, dim3(1, W), dim3(1024), solve_lds, st, (const lba::BWin*)b->d_wins, dyn);
+            hipLaunchKernelGGL(lba::k_update_errors_b, dim3(max_upd, W), dim3(lba::kUpdThreads), 0, st, (const lba::BWin*)b->d_wins, dyn);
         }
         if (hipGetLastError() != hipSuccess) { r = fail(ORBX_ERR_HIP, "batched launch failed"); break; }
         // results of the round: every window that ran a reduction publishes its sequence number last
