@@ -56,10 +56,14 @@ def compact_line(out):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config")
     line = {k: out[k] for k in keep if k in out}
+    if "config" in line:
+        line["config"] = {k: v for k, v in line["config"].items() if k not in ("sharding", "frames_per_step")}
     if "roofline" in out:
         r = out["roofline"]
         line["roofline"] = {k: r[k] for k in ("bound", "valu_issue_frac", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "launch_ms",
                                                "pipeline_frac", "stage_ms") if k in r}
+        if line["roofline"].get("traffic") is not None:
+            line["roofline"].pop("traffic_from", None)          # (the file name is in bench_detail.json; a null keeps its reason)
         if "stage_ms" in line["roofline"]:
             line["roofline"]["stage_ms"] = {k: round(v, 3) for k, v in line["roofline"]["stage_ms"].items()}
     for k in ("cpu_baseline", "speedup_vs_cpu_1core"):
@@ -73,6 +77,8 @@ def compact_line(out):
         l = out["lba"]
         line["lba"] = {k: l[k] for k in ("metric", "value", "unit", "dtype", "ms_per_iteration", "ms_per_trial", "roofline", "cpu_baseline",
                                           "speedup_vs_cpu_1core", "workload") if k in l}
+        if "roofline" in line["lba"]:
+            line["lba"]["roofline"] = {k: v for k, v in line["lba"]["roofline"].items() if k not in ("traffic", "mflop_per_iteration")}
         if "batched" in l:
             bl = l["batched"]
             line["lba"]["batched"] = {k: bl[k] for k in ("error", "windows", "value", "iters_per_s_whole_call") if k in bl}
@@ -318,7 +324,7 @@ def main():
                     traffic = tj.get(dom)
                     traffic_from = "profiles/pmc_traffic.json"
                 else:
-                    traffic_from = "null: profiles/pmc_traffic.json was taken on other kernel sources"
+                    traffic_from = "null: stale counter profile (other kernel sources)"
             except Exception:
                 traffic = None
         # What actually bounds the kernel (profiles/r03_a_valu_rates.txt): vector-instruction ISSUE.  valu_issue_frac = the kernel's

@@ -5,7 +5,7 @@ set -o pipefail
 TAG=${1:-rXX}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout -k 10 420 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?
+timeout -k 10 420 python -m pytest tests -m gpu -x -q < /dev/null > $OUT/pytest_gpu.log 2>&1; rc=$?
 tail -3 $OUT/pytest_gpu.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out: stopping"; exit 1; fi
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
@@ -29,6 +29,16 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/l
 timeout -k 10 200 python tools/latency_b1.py > $OUT/latency_b1.log 2>&1 || echo "latency_b1 failed"
 timeout -k 10 200 python tools/pi_latency.py > $OUT/pi_latency.log 2>&1 || echo "pi_latency failed"
 bash tools/pmc_lba.sh $TAG/lba_pmc > $OUT/lba_pmc.log 2>&1 || echo "lba mfma counter pass failed"
+# SQ counters of every kernel of a step (+ LDS / memory instruction counts) -> profiles/valu_issue.json (bench.py: roofline.valu_issue_frac)
+bash tools/pmc_sq.sh $TAG/sq > $OUT/sq_counters.log 2>&1 || echo "sq counter pass failed"
+# the probes behind the issue-cost figures
+(/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/valu_rates.hip -o /tmp/valu_rates && timeout -k 10 120 /tmp/valu_rates > $OUT/valu_rates.txt 2>&1) || echo "valu_rates probe failed"
+(/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/fast_mix.hip -o /tmp/fast_mix && timeout -k 10 120 /tmp/fast_mix > $OUT/fast_mix.txt 2>&1) || echo "fast_mix probe failed"
+# many windows per launch, and the block-parallel projection search (256 frames x 900 points)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lbabatchprof -- python tools/lba_batch_prof.py 32 3 > $OUT/lba_batch_prof.log 2>&1 < /dev/null || echo "lba batch profile failed"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/projprof -- python tools/proj_batch_prof.py 256 3 > $OUT/proj_prof.log 2>&1 < /dev/null || echo "projection profile failed"
+ORBM_PROJ_SEQUENTIAL=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/projprof_seq -- python tools/proj_batch_prof.py 256 3 > $OUT/proj_prof_seq.log 2>&1 < /dev/null || echo "sequential projection profile failed"
+timeout -k 10 400 python bench.py --extra > $OUT/bench_extra.json 2> $OUT/bench_extra.err < /dev/null && cp gpurun_out/bench_detail.json $OUT/bench_detail_extra.json || echo "bench --extra failed"
 python - <<PY
 import json
 d = json.load(open("$OUT/bench.json"))
