@@ -810,6 +810,213 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     chol_step_body(S, Lp, n, K, nblk, Linv, scal, (int)blockIdx.x, sm_step);
 }
 
+// ---- the whole factorisation in ONE launch (round 3): a workgroup per lower-triangle tile (r, c) of the block matrix ----
+// k_chol_diag + k_chol_step x (nblk - 1) is a chain of launches whose critical path is the factoring workgroup of every block
+// column; between two of them lie a launch boundary, a tile write-back and a tile load.  Here tile (r, c) is ONE workgroup
+// for its whole life: it loads its tile into registers once, and for K = 0 .. c-1 waits until block column K is factored
+// (flag fac[K]) and the tiles (r, K), (c, K) are final (flags done[.][K]), recomputes the two panel blocks X_r = A_rK Linv_K^T,
+// X_c (as k_chol_step does), applies T -= X_r X_c^T in registers, and at the end either factors and inverts its tile (r == c,
+// publishes fac[c]) or writes it back (publishes done[r][c]).  The panel inputs of a step are final long before the pivot block
+// they wait for, so everything except [load Linv_K, panel product, update] is off the critical path.
+// Synchronisation between workgroups (other CUs, other XCDs): producer stores, workgroup barrier, thread 0: agent-scope
+// release fence + flag store; consumer thread 0: agent-scope spin on the flag, acquire fence, workgroup barrier, plain loads
+// (MI355X_MICROARCH.md, correctness boundaries).  Flags carry the EPOCH of the trial (no reset between trials).  A workgroup
+// only waits for workgroups of smaller linear index (column-major tile order), so the grid cannot deadlock as long as every XCD
+// starts its workgroups in index order; the launch sites keep the grid within what is resident at once anyway.  Every spin is
+// bounded and also watches the failure flag (a pivot block that is not positive definite ends the factorisation for everybody).
+constexpr int kFlowFlags = kFusedMaxBlocks + kFusedMaxBlocks * kFusedMaxBlocks;
+__device__ __forceinline__ bool flow_wait(const unsigned* flag, unsigned epoch, double* scal)
+{
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 21); spin++) {
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) { ok = 1; break; }
+            if (__longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(scal + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0.0) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)(scal + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0.0)
+            __hip_atomic_store((unsigned long long*)(scal + 5), (unsigned long long)__double_as_longlong(2.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // timed out
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
+    }
+    __syncthreads();
+    const bool r = s_ok != 0;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ void flow_publish(unsigned* flag, unsigned epoch)
+{
+    __syncthreads();                // every thread's stores of the tile / the inverted block are issued and counted
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void chol_flow_body(double* __restrict__ S, double* __restrict__ Lp, int n, int nblk, double* __restrict__ Linv,
+                                               double* __restrict__ scal, unsigned* __restrict__ flow, unsigned epoch, const int bx, double* __restrict__ sm_step)
+{
+    constexpr int P = NB + 1;
+    double* sI = sm_step;
+    double* sXi = sI + NB * P;
+    double* sXj = sXi + 64 * P;
+    CholVec4& sv = *(CholVec4*)(sXj + 64 * P);
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    // column-major tile order: (0,0) (1,0) .. (nblk-1,0) (1,1) (2,1) ..
+    int c = 0, t = bx;
+    while (t >= nblk - c) { t -= nblk - c; c++; }
+    const int r = c + t;
+    unsigned* fac = flow;
+    unsigned* done = flow + kFusedMaxBlocks;
+    const bool diag_tile = r == c;
+    const int r0 = r * NB, nri = min(NB, n - r0) + (r == nblk - 1 ? 1 : 0);         // + the right-hand-side row
+    const int c0 = c * NB, ncj = min(NB, n - c0);
+    if (!diag_tile && c == 0) return;        // the tiles of block column 0 are final as they are: nothing to do, nothing to publish
+    // the tile, in registers for the workgroup's whole life
+    double Lr[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int rr = ty + 16 * a, cc = tx + 16 * b;
+            Lr[a][b] = (rr < nri && cc < ncj) ? S[(size_t)(r0 + rr) * n + c0 + cc] : 0.0;
+        }
+    for (int K = 0; K < c; K++) {
+        const int k0 = K * NB;
+        // the panel inputs A_rK, A_cK: final once the workgroups (r, K), (c, K) are done (block column 0: from the start)
+        if (K > 0) {
+            if (!flow_wait(done + r * kFusedMaxBlocks + K, epoch, scal)) return;
+            if (!diag_tile && !flow_wait(done + c * kFusedMaxBlocks + K, epoch, scal)) return;
+        }
+        {
+            constexpr int H = NB / 2, kIt = (64 * H + 255) / 256;
+            double2 vA[kIt], vB[kIt];
+#pragma unroll
+            for (int it = 0; it < kIt; it++) {
+                const int i = tid + 256 * it, rr = i / H, q2 = i - rr * H;
+                vA[it] = make_double2(0.0, 0.0); vB[it] = vA[it];
+                if (rr < nri) vA[it] = *(const double2*)(S + (size_t)(r0 + rr) * n + k0 + 2 * q2);
+                if (!diag_tile && rr < ncj) vB[it] = *(const double2*)(S + (size_t)(c0 + rr) * n + k0 + 2 * q2);
+            }
+#pragma unroll
+            for (int it = 0; it < kIt; it++) {
+                const int i = tid + 256 * it, rr = i / H, q2 = i - rr * H;
+                if (rr < 64) {
+                    sXi[rr * P + 2 * q2] = vA[it].x; sXi[rr * P + 2 * q2 + 1] = vA[it].y;
+                    sXj[rr * P + 2 * q2] = vB[it].x; sXj[rr * P + 2 * q2 + 1] = vB[it].y;
+                }
+            }
+        }
+        // the inverted pivot block of column K: the critical wait
+        if (!flow_wait(fac + K, epoch, scal)) return;
+        {
+            constexpr int H = NB / 2, kIt = (NB * H + 255) / 256;
+            const double* Lk = Linv + (size_t)K * NB * NB;
+            double2 vI[kIt];
+#pragma unroll
+            for (int it = 0; it < kIt; it++) {
+                const int i = tid + 256 * it, rr = i / H, q2 = i - rr * H;
+                vI[it] = make_double2(0.0, 0.0);
+                if (rr < NB) vI[it] = *(const double2*)(Lk + rr * NB + 2 * q2);
+            }
+#pragma unroll
+            for (int it = 0; it < kIt; it++) {
+                const int i = tid + 256 * it, rr = i / H, q2 = i - rr * H;
+                if (rr < NB) { sI[rr * P + 2 * q2] = vI[it].x; sI[rr * P + 2 * q2 + 1] = vI[it].y; }
+            }
+        }
+        __syncthreads();
+        // X = A Linv^T on the f64 matrix pipe, in place (as k_chol_step)
+        {
+            const int wv = tid >> 6, ln = tid & 63, lr = ln & 15, lk = ln >> 4;
+            mfma_d4 xa[4], xb[4];
+#pragma unroll
+            for (int C = 0; C < 4; C++) { xa[C] = mfma_d4{0.0, 0.0, 0.0, 0.0}; xb[C] = xa[C]; }
+            const double* pa = sXi + (16 * wv + lr) * P + lk;
+            const double* pb = sXj + (16 * wv + lr) * P + lk;
+#pragma unroll
+            for (int ks = 0; ks < NB / 4; ks++) {
+                const double av = pa[4 * ks];
+                const double bv = diag_tile ? 0.0 : pb[4 * ks];
+#pragma unroll
+                for (int C = 0; C < 4; C++) {
+                    if (ks >= 4 * C + 4) continue;
+                    const int cc = 16 * C + lr;
+                    const double lv = (cc < NB) ? sI[cc * P + 4 * ks + lk] : 0.0;
+                    xa[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lv, xa[C], 0, 0, 0);
+                    if (!diag_tile) xb[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, lv, xb[C], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int C = 0; C < 4; C++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int cc = 16 * C + lr;
+                    if (cc < NB) {
+                        sXi[(16 * wv + lk + 4 * i) * P + cc] = xa[C][i];
+                        if (!diag_tile) sXj[(16 * wv + lk + 4 * i) * P + cc] = xb[C][i];
+                    }
+                }
+        }
+        __syncthreads();
+        if (c == K + 1) {       // this tile's X_r is L_rK: the substitution kernel reads it from Lp
+            for (int i = tid; i < nri * NB; i += 256) { const int rr = i / NB, q = i - rr * NB; Lp[(size_t)(r0 + rr) * n + k0 + q] = sXi[rr * P + q]; }
+        }
+        const double* sB = diag_tile ? sXi : sXj;
+        {
+            const int wv = tid >> 6, ln = tid & 63, lr = ln & 15, lk = ln >> 4;
+            const double* pa = sXi + (4 * wv + (lr & 3) + 16 * (lr >> 2)) * P + lk;
+            const double* pb = sB + lr * P + lk;
+            mfma_d4 acc[4];
+#pragma unroll
+            for (int C = 0; C < 4; C++) acc[C] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < NB / 4; ks++) {
+                const double av = pa[4 * ks];
+#pragma unroll
+                for (int C = 0; C < 4; C++) acc[C] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[16 * C * P + 4 * ks], acc[C], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) Lr[a][b] -= acc[b][a];
+        }
+        __syncthreads();                // sXi / sXj are free for the next block column
+    }
+    if (!diag_tile) {
+        // final A_rc (the panel input of block column c for the tiles to its right)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int rr = ty + 16 * a, cc = tx + 16 * b;
+                if (rr < nri && cc < ncj) S[(size_t)(r0 + rr) * n + c0 + cc] = Lr[a][b];
+            }
+        flow_publish(done + r * kFusedMaxBlocks + c, epoch);
+        return;
+    }
+    // diagonal tile: a right-hand-side row riding along goes back to S (the substitution reads it there), then factor + invert
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int rr = ty + 16 * a, cc = tx + 16 * b;
+            if (rr < nri && cc < ncj && rr >= ncj) S[(size_t)(r0 + rr) * n + c0 + cc] = Lr[a][b];
+            if (rr >= ncj || cc >= ncj) Lr[a][b] = (rr == cc) ? 1.0 : 0.0;
+        }
+    if (!chol_tile_mfma(Lr, ncj, Linv + (size_t)c * NB * NB, sv)) {
+        if (tid == 0) __hip_atomic_store((unsigned long long*)(scal + 5), (unsigned long long)__double_as_longlong(1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;                         // (the waiters watch the failure flag)
+    }
+    flow_publish(fac + c, epoch);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_flow(double* __restrict__ S, double* __restrict__ Lp, int n, int nblk,
+                                                   double* __restrict__ Linv, double* __restrict__ scal, unsigned* __restrict__ flow, unsigned epoch)
+{
+    extern __shared__ __align__(16) double sm_step[];
+    chol_flow_body(S, Lp, n, nblk, Linv, scal, flow, epoch, (int)blockIdx.x, sm_step);
+}
+
 constexpr int kPanelRows = 64;
 // nr = n + 1: the right-hand side b_schur is stored right behind S in the reduce buffer, i.e. it IS row n of an
 // (n+1) x n row-major matrix; carrying it through panel/update as an extra row performs the forward substitution
@@ -1195,6 +1402,7 @@ struct BWin {
     double* poses[2]; double* pts[2];
     double* S; double* bs; double* bpf; double* diag; double* Lp; double* Linv;
     double* hmap;               // this window's 16 host-mapped scalars
+    unsigned* flow;             // k_chol_flow flags of this window
     int nblk;
 };
 struct BDyn { double lambda, hint; unsigned long long seq; int cur, flags; };
@@ -1259,6 +1467,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int T = w.nblk - 1 - K;
     if (T <= 0 || (int)blockIdx.x >= T * (T + 1) / 2) return;
     chol_step_body(w.S, w.Lp, w.d.n, K, w.nblk, w.Linv, w.d.scal, (int)blockIdx.x, sm_step);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_chol_flow_b(const BWin* __restrict__ wins, BDynAll dyn)
+{
+    extern __shared__ __align__(16) double sm_step[];
+    const BDyn y = dyn.w[blockIdx.y];
+    if (!(y.flags & kBwTrial)) return;
+    const BWin& w = wins[blockIdx.y];
+    if (w.d.n <= 0 || (int)blockIdx.x >= w.nblk * (w.nblk + 1) / 2) return;
+    chol_flow_body(w.S, w.Lp, w.d.n, w.nblk, w.Linv, w.d.scal, w.flow, (unsigned)y.seq, (int)blockIdx.x, sm_step);
 }
 __global__ __launch_bounds__(1024) void k_chol_solve_b(const BWin* __restrict__ wins, BDynAll dyn)
 {
@@ -1365,6 +1582,8 @@ struct lba_shard {
     std::vector<int> prof_stage;
     int prof_n = 0;
     hipEvent_t ev_fence = nullptr;      // stream hand-over to / from the collective's stream (lba_shard_fence_*)
+    unsigned* flow = nullptr;           // k_chol_flow: per-tile flags (epoch of the trial that published them)
+    unsigned flow_epoch = 0;
     double* d_coll = nullptr;           // lba_shard_optimize: device scratch of the scalar all-reduces (chi2 / scale / flags) ...
     double* h_coll = nullptr;           // ... and its pinned host mirror
     void mark(int stage)
@@ -1588,6 +1807,9 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     LBA_TRY(s->dalloc(&s->Linv, (size_t)std::max(s->nblk, 1) * lba::NB * lba::NB));
     if (s->nblk <= lba::kFusedMaxBlocks) LBA_TRY(s->dalloc(&s->Lp, ((size_t)d.n + 1) * (size_t)std::max(d.n, 1)));
     LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
+    LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_flow, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
+    LBA_TRY(s->dalloc(&s->flow, (size_t)lba::kFlowFlags));
+    LBA_HIP(hipMemsetAsync(s->flow, 0, lba::kFlowFlags * sizeof(unsigned), s->stream));
     {
         const size_t solve_lds = ((size_t)d.n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
         if (solve_lds > 160 * 1024) LBA_TRY(fail(ORBX_ERR_CAPACITY, "%d reduced unknowns exceed the substitution kernel's LDS", d.n));
@@ -1860,7 +2082,12 @@ int lba_shard_finish(lba_shard* s, double lambda, double* chi2_local_new, double
     if (n > 0) {
         if (!s->lambda_added) hipLaunchKernelGGL(lba::k_add_lambda, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->S(), n, lambda);
         const bool fused = s->nblk <= lba::kFusedMaxBlocks;
-        if (fused) {
+        static const bool step_launches = std::getenv("ORBX_LBA_STEPS") != nullptr;       // A/B knob: round 2's launch per block column
+        if (fused && !step_launches) {
+            // the whole factorisation as one launch: a workgroup per lower-triangle tile, flags between them (k_chol_flow)
+            hipLaunchKernelGGL(lba::k_chol_flow, dim3(s->nblk * (s->nblk + 1) / 2), dim3(256), lba::kStepLds, s->stream, s->S(), s->Lp, n, s->nblk, s->Linv, d.scal,
+                               s->flow, ++s->flow_epoch);
+        } else if (fused) {
             // one launch per block column: panel + trailing update + the next diagonal factorisation (k_chol_step)
             hipLaunchKernelGGL(lba::k_chol_diag, dim3(1), dim3(256), 0, s->stream, (const double*)s->S(), n, 0, std::min(lba::NB, n), s->Linv, d.scal);
             for (int K = 0; K + 1 < s->nblk; K++) {
@@ -2238,7 +2465,7 @@ int lba_solve_batch(lba_batch* b, const LbaProblem* problems, const LbaOutputs* 
         if (s->nblk > lba::kFusedMaxBlocks) { r = fail(ORBX_ERR_CAPACITY, "window %d has %d reduced unknowns: the batched path takes at most %d (use lba_solve)", i, s->d.n, lba::kFusedMaxBlocks * lba::NB); break; }
         lba::BWin& w = hw[i];
         w.d = s->d; w.poses[0] = s->poses[0]; w.poses[1] = s->poses[1]; w.pts[0] = s->pts[0]; w.pts[1] = s->pts[1];
-        w.S = s->S(); w.bs = s->bs(); w.bpf = s->bpf(); w.diag = s->diag(); w.Lp = s->Lp; w.Linv = s->Linv; w.hmap = s->d_hmap; w.nblk = s->nblk;
+        w.S = s->S(); w.bs = s->bs(); w.bpf = s->bpf(); w.diag = s->diag(); w.Lp = s->Lp; w.Linv = s->Linv; w.hmap = s->d_hmap; w.flow = s->flow; w.nblk = s->nblk;
         const lba::Dev& d = s->d;
         max_lin = std::max(max_lin, d.nP + (d.nL + 31) / 32); max_e = std::max(max_e, (d.nE + 255) / 256); max_lm = std::max(max_lm, (d.nL + 7) / 8);
         max_sb = std::max(max_sb, d.nBlocks + d.nP); max_nblk = std::max(max_nblk, s->nblk); max_upd = std::max(max_upd, (d.nL + lba::kUpdLandmarks - 1) / lba::kUpdLandmarks);
@@ -2247,6 +2474,7 @@ int lba_solve_batch(lba_batch* b, const LbaProblem* problems, const LbaOutputs* 
     if (r) { cleanup(); return r; }
     const size_t solve_lds = ((size_t)max_n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
     if (hipFuncSetAttribute((const void*)lba::k_chol_step_b, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lba::k_chol_flow_b, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds) != hipSuccess ||
         hipFuncSetAttribute((const void*)lba::k_chol_solve_update_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)) != hipSuccess ||
         hipMemcpyAsync(b->d_wins, hw.data(), (size_t)W * sizeof(lba::BWin), hipMemcpyHostToDevice, b->stream) != hipSuccess) {
         cleanup();
@@ -2309,10 +2537,18 @@ int lba_solve_batch(lba_batch* b, const LbaProblem* problems, const LbaOutputs* 
         if (any_trial) {
             if (any_lm) hipLaunchKernelGGL(lba::k_schur_landmarks_b, dim3(max_lm, W), dim3(64), 0, st, (const lba::BWin*)b->d_wins, dyn);
             hipLaunchKernelGGL(lba::k_schur_blocks_b, dim3(max_sb, W), dim3(lba::kSchurThreads), 0, st, (const lba::BWin*)b->d_wins, dyn);
-            hipLaunchKernelGGL(lba::k_chol_diag_b, dim3(1, W), dim3(256), 0, st, (const lba::BWin*)b->d_wins, dyn);
-            for (int K = 0; K + 1 < max_nblk; K++) {
-                const int T = max_nblk - 1 - K;
-                hipLaunchKernelGGL(lba::k_chol_step_b, dim3(T * (T + 1) / 2, W), dim3(256), lba::kStepLds, st, (const lba::BWin*)b->d_wins, dyn, K);
+            // the factorisation: one launch (a workgroup per tile and window, flags between them) while every workgroup of the launch
+            // can be resident at once (it waits on others), else a launch per block column
+            static const bool step_launches = std::getenv("ORBX_LBA_STEPS") != nullptr;
+            const int tiles = max_nblk * (max_nblk + 1) / 2;
+            if (!step_launches && tiles * W <= 240) {       // (100 KB of LDS per workgroup: one per CU)
+                hipLaunchKernelGGL(lba::k_chol_flow_b, dim3(tiles, W), dim3(256), lba::kStepLds, st, (const lba::BWin*)b->d_wins, dyn);
+            } else {
+                hipLaunchKernelGGL(lba::k_chol_diag_b, dim3(1, W), dim3(256), 0, st, (const lba::BWin*)b->d_wins, dyn);
+                for (int K = 0; K + 1 < max_nblk; K++) {
+                    const int T = max_nblk - 1 - K;
+                    hipLaunchKernelGGL(lba::k_chol_step_b, dim3(T * (T + 1) / 2, W), dim3(256), lba::kStepLds, st, (const lba::BWin*)b->d_wins, dyn, K);
+                }
             }
             hipLaunchKernelGGL(lba::k_chol_solve_update_b, dim3(1, W), dim3(1024), solve_lds, st, (const lba::BWin*)b->d_wins, dyn);
             hipLaunchKernelGGL(lba::k_update_errors_b, dim3(max_upd, W), dim3(lba::kUpdThreads), 0, st, (const lba::BWin*)b->d_wins, dyn);
