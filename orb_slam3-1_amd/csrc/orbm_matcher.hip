@@ -1434,6 +1434,7 @@ struct orbm_matcher {
     uint8_t* d_ws = nullptr;            // workspace of the device-resident batch entries (SoA key points, grids, logs, job table)
     size_t ws_cap = 0;
     float* d_scale = nullptr;           // scale factors of the last device-resident call
+    float h_scale[32] = {};             // ... staged here: the asynchronous copy must not read the caller's array after the call returned
 
     int ensure(size_t bytes)
     {
@@ -2064,7 +2065,11 @@ int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDevic
         m->ws_cap = off + off / 4;
     }
     if (!m->d_scale) ORBM_HIP(hipMalloc((void**)&m->d_scale, 32 * sizeof(float)));
-    ORBM_HIP(hipMemcpyAsync(m->d_scale, cur->scale_factors, sizeof(float) * cur->n_levels, hipMemcpyHostToDevice, st));
+    if (std::memcmp(m->h_scale, cur->scale_factors, sizeof(float) * cur->n_levels) != 0) {      // (unchanged between the calls of a stream of frames)
+        ORBM_HIP(hipStreamSynchronize(st));                 // an earlier copy out of h_scale may still be in flight
+        std::memcpy(m->h_scale, cur->scale_factors, sizeof(float) * cur->n_levels);
+        ORBM_HIP(hipMemcpyAsync(m->d_scale, m->h_scale, sizeof(float) * cur->n_levels, hipMemcpyHostToDevice, st));
+    }
     // LDS of the search kernel, as in run_projection_jobs
     const size_t max_n = cap;
     const size_t tabs = 8 * ((max_n + 15) & ~(size_t)15);
