@@ -207,3 +207,48 @@ def test_lba_batch_refuses_oversized_window(pkg, synth):
             b.solve([w], 2)
     finally:
         b.close()
+
+
+def test_lba_batch_edge_cases(pkg, synth):
+    """an empty batch, a batch of one, a window without a single free pose (n = 0) and one without points beside an ordinary
+    window; every window equals lba_solve"""
+    b = pkg.LbaBatch()
+    s = pkg.LbaSolver()
+    try:
+        assert b.solve([], 5) == []
+        w0 = synth.make_ba_window(21, n_opt=4, n_fixed=2, n_points=50, obs_per_point=3)
+        w_fixed = synth.make_ba_window(22, n_opt=3, n_fixed=2, n_points=40, obs_per_point=3)
+        w_fixed["pose_fixed"][:] = 1                       # setFixed on every pose: only the points move
+        w_nopts = synth.make_ba_window(23, n_opt=3, n_fixed=1, n_points=30, obs_per_point=3)
+        for k in ("edge_point", "edge_pose", "edge_obs", "edge_inv_sigma2", "edge_stereo"):
+            w_nopts[k] = w_nopts[k][:0]
+        w_nopts["points"] = w_nopts["points"][:0]
+        for ws in ([w0], [w_fixed, w0, w_nopts]):
+            got = b.solve(ws, 6)
+            for w, r1 in zip(ws, got):
+                r0 = s.solve(w, 6)
+                assert r1["stats"] == r0["stats"]
+                for k in ("pose_q", "pose_t", "points", "chi2"):
+                    np.testing.assert_array_equal(r1[k], r0[k])
+    finally:
+        b.close(); s.close()
+
+
+def test_lba_shard_optimize_world1_and_stop_flag(pkg, synth):
+    """lba_shard_optimize without a callback is lba_solve's loop; a stop flag that is already set ends it before the first iteration"""
+    w = synth.make_ba_window(24, n_opt=9, n_fixed=2, n_points=180, obs_per_point=5)
+    s = pkg.LbaSolver()
+    ref = s.solve(w, 8)
+    s.close()
+    sh = pkg.LbaShard(w)
+    try:
+        st = sh.optimize(None, 1, max_iters=8)
+        out = sh.download()
+        assert (st["iterations"], st["trials"], st["stop_reason"], st["chi2_final"]) == (ref["stats"]["iterations"], ref["stats"]["trials"], ref["stats"]["stop_reason"], ref["stats"]["chi2_final"])
+        np.testing.assert_array_equal(out["points"], ref["points"])
+        sh.reset()
+        flag = np.ones(1, np.uint8)
+        st2 = sh.optimize(None, 1, max_iters=8, stop_flag=flag)
+        assert st2["iterations"] == 0 and st2["stop_reason"] == 3
+    finally:
+        sh.close()

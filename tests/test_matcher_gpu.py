@@ -325,3 +325,25 @@ def test_search_by_projection_last_batch_device(pkg, oracle, sm):
         n = len(g["x"])
         assert nm[b] == n0 > 100, "frame %d" % b
         np.testing.assert_array_equal(a1[b, :n], a0); np.testing.assert_array_equal(o1[b, :n], o0)
+
+
+def test_search_by_projection_last_batch_device_empty_frames(pkg, sm):
+    """frames without features, frames without points, a batch of one: no matches, nothing written"""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, cap, pcap = 3, 64, 32
+    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    kps = z(B * cap * 28, torch.uint8); desc = z(B * cap * 32, torch.uint8); nn = torch.tensor([0, 5, 0], dtype=torch.int32, device=dev)
+    pv = z(B * pcap, torch.uint8); pu = z(B * pcap, torch.float32); pw = z(B * pcap, torch.float32); po = z(B * pcap, torch.int32)
+    pa = z(B * pcap, torch.float32); pd = z(B * pcap * 32, torch.uint8); pn = torch.tensor([7, 0, 0], dtype=torch.int32, device=dev)
+    assign = torch.full((B * cap,), -1, dtype=torch.int32, device=dev); occ = z(B * cap, torch.uint8); nm = torch.full((B,), 99, dtype=torch.int32, device=dev)
+    m = pkg.Matcher(0.9, True)
+    try:
+        m.SearchByProjection_last_batch_device((kps.data_ptr(), desc.data_ptr(), nn.data_ptr(), cap),
+                                               (pv.data_ptr(), pu.data_ptr(), pw.data_ptr(), po.data_ptr(), pa.data_ptr(), pd.data_ptr(), pn.data_ptr(), pcap),
+                                               B, 15.0, assign.data_ptr(), occ.data_ptr(), nm.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                                               bounds=(0.0, 0.0, 640.0, 480.0), scale_factors=np.float32(1.2) ** np.arange(8, dtype=np.float32))
+        torch.cuda.synchronize()
+    finally:
+        m.close()
+    assert nm.cpu().tolist() == [0, 0, 0] and int((assign != -1).sum().item()) == 0
