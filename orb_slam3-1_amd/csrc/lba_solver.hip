@@ -95,6 +95,38 @@ __device__ __forceinline__ void huber(const Cam& c, int stereo, double chi, doub
     else { const double s = sqrt(chi); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }
 
+// The per-edge 6 x 3 blocks W_e / Z_e are rows of 18 doubles = 144 bytes, 16-byte aligned (the arrays are 256-byte aligned).  A lane
+// that walks its own row with 8-byte accesses makes 18 memory transactions per row and wave instruction slot; the memory system
+// is bound by the NUMBER of such transactions, not by their bytes (k_schur_landmarks_b: 129 memory instructions per wave, 3 000
+// cycles each with 32 windows per launch) -- so rows move as 9 x 16 bytes.
+__device__ __forceinline__ void load18(const double* __restrict__ p, double* v)
+{
+    const double2* q = (const double2*)p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+}
+__device__ __forceinline__ void store18(double* __restrict__ p, const double* v)
+{
+    double2* q = (double2*)p;
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+}
+// rows 3 half .. 3 half + 2 of such a block (9 doubles from offset 72 half bytes): one 8-byte access + four 16-byte ones
+__device__ __forceinline__ void load9(const double* __restrict__ row18, int half, double* v)
+{
+    if (half == 0) {
+        const double2* q = (const double2*)row18;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+        v[8] = row18[8];
+    } else {
+        v[0] = row18[9];
+        const double2* q = (const double2*)(row18 + 10);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const double2 t = q[i]; v[1 + 2 * i] = t.x; v[2 + 2 * i] = t.y; }
+    }
+}
+
 // Jacobians of one edge: Ji (D x 3, point) and Jj (D x 6, pose), rows padded to 3
 __device__ inline void edge_jacobians(const Cam& c, const double* T, const double* Xc, int stereo, double* Ji, double* Jj)
 {
@@ -166,10 +198,13 @@ __device__ __forceinline__ void schur_landmark(const Dev& d, int l, int sub, con
     for (int k = d.l_off[l] + sub; k < d.l_off[l + 1]; k += 8) {
         const int e = d.l_edge[k];
         if (d.pose_col[d.e_pose[e]] < 0) continue;
-        const double* W = d.W + 18 * (size_t)e;
-        double* Z = d.Z + 18 * (size_t)e;
+        double W[18], Z[18];
+        load18(d.W + 18 * (size_t)e, W);
+#pragma unroll
         for (int r = 0; r < 6; r++)
+#pragma unroll
             for (int c = 0; c < 3; c++) Z[r * 3 + c] = W[r * 3] * Di[c] + W[r * 3 + 1] * Di[3 + c] + W[r * 3 + 2] * Di[6 + c];
+        store18(d.Z + 18 * (size_t)e, Z);
     }
 }
 
@@ -216,7 +251,7 @@ __device__ __forceinline__ void lin_landmarks_body(const Dev& d, const double* _
                 acc[6 + a] += sv;
             }
             if (d.pose_col[ip] >= 0) {
-                double* W = d.W + 18 * (size_t)e;
+                double W[18];
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -226,6 +261,7 @@ __device__ __forceinline__ void lin_landmarks_body(const Dev& d, const double* _
                         for (int q = 0; q < 3; q++) h += Jj[q * 6 + a] * wr * Ji[q * 3 + c];
                         W[a * 3 + c] = h;
                     }
+                store18(d.W + 18 * (size_t)e, W);
             }
         }
     }
@@ -398,9 +434,12 @@ __device__ __forceinline__ void schur_blocks_body(Dev d, double* __restrict__ S,
         double acc[6] = {0, 0, 0, 0, 0, 0};
         for (int k = d.p_off[i] + tid; k < d.p_off[i + 1]; k += kSchurThreads) {
             const int e = d.p_edge[k];
-            const double* W = d.W + 18 * (size_t)e;
+            double W[18];
+            load18(d.W + 18 * (size_t)e, W);
             const double* db = d.db + 3 * (size_t)d.e_point[e];
-            for (int r = 0; r < 6; r++) acc[r] += W[r * 3] * db[0] + W[r * 3 + 1] * db[1] + W[r * 3 + 2] * db[2];
+            const double b0 = db[0], b1 = db[1], b2 = db[2];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[r] += W[r * 3] * b0 + W[r * 3 + 1] * b1 + W[r * 3 + 2] * b2;
         }
         for (int r = 0; r < 6; r++)
             for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o);
@@ -422,11 +461,9 @@ __device__ __forceinline__ void schur_blocks_body(Dev d, double* __restrict__ S,
         double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         for (int k = d.b_off[blk] + g; k < d.b_off[blk + 1]; k += kSchurGroups) {
             const int2 pr = d.b_pair[k];
-            const double* Z = d.Z + 18 * (size_t)pr.x + 9 * rb;
-            const double* W = d.W + 18 * (size_t)pr.y + 9 * cb;
             double z[9], w[9];
-#pragma unroll
-            for (int u = 0; u < 9; u++) { z[u] = Z[u]; w[u] = W[u]; }
+            load9(d.Z + 18 * (size_t)pr.x, rb, z);
+            load9(d.W + 18 * (size_t)pr.y, cb, w);
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -1310,8 +1347,13 @@ __device__ __forceinline__ void update_errors_body(const Dev& d, double lambda, 
             const int e = d.l_edge[k];
             const int col = d.pose_col[d.e_pose[e]];
             if (col < 0) continue;
-            const double* W = d.W + 18 * (size_t)e;
-            const double* xp = d.x + 6 * (size_t)col;
+            double W[18], xp[6];
+            load18(d.W + 18 * (size_t)e, W);
+            {
+                const double2* x2 = (const double2*)(d.x + 6 * (size_t)col);        // 48-byte rows of a 256-byte aligned array
+                const double2 a0 = x2[0], a1 = x2[1], a2 = x2[2];
+                xp[0] = a0.x; xp[1] = a0.y; xp[2] = a1.x; xp[3] = a1.y; xp[4] = a2.x; xp[5] = a2.y;
+            }
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 double s2 = 0;
