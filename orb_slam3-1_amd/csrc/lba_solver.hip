@@ -12,8 +12,9 @@
 //   k_schur_blocks     S_ij = [Hpp_ii] - sum_pairs Z_a W_b^T ,  b_s = b_p - sum W_e db        (1 wave / block)
 //   (multi-GPU: the caller all-reduces [S | b_s | b_p | diag Hpp] here -- RCCL over xGMI)
 //   k_add_lambda, blocked Cholesky (k_chol_panel / k_chol_update per 60-column step), k_chol_solve
-//   k_backsub_update   x_l = D^-1 (b_l - W^T x_p), trial state = oplus(state, x), scale partials
-//   k_errors           residuals + Huber rho of the trial state; k_reduce sums chi2 / scale deterministically
+//   k_chol_solve_update  substitution, then trial poses = oplus(poses, x_p) and the pose part of the scale sum
+//   k_update_errors    x_l = D^-1 (b_l - W^T x_p), trial points, residuals + Huber rho of the trial state per landmark; the last
+//                      workgroup sums chi2 / scale in a fixed order
 // Every reduction is ordered (CSR gather or fixed tree), so results are reproducible run to run.
 #include <hip/hip_runtime.h>
 
@@ -95,35 +96,34 @@ __device__ __forceinline__ void huber(const Cam& c, int stereo, double chi, doub
     else { const double s = sqrt(chi); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }
 
-// The per-edge 6 x 3 blocks W_e / Z_e are rows of 18 doubles = 144 bytes, 16-byte aligned (the arrays are 256-byte aligned).  A lane
-// that walks its own row with 8-byte accesses makes 18 memory transactions per row and wave instruction slot; the memory system
-// is bound by the NUMBER of such transactions, not by their bytes (k_schur_landmarks_b: 129 memory instructions per wave, 3 000
-// cycles each with 32 windows per launch) -- so rows move as 9 x 16 bytes.
-__device__ __forceinline__ void load18(const double* __restrict__ p, double* v)
+// The per-edge 6 x 3 blocks W_e / Z_e.  A lane that walks its own block with 8-byte accesses makes 18 memory transactions per
+// block and wave-instruction slot, and the memory system is bound by the NUMBER of such transactions, not by their bytes
+// (k_schur_landmarks_b: 129 memory instructions per wave at ~3 000 cycles each with 32 windows per launch) -- so a block is stored
+// as two 16-byte aligned halves of 9 doubles + 1 of padding (rows 0-2 | rows 3-5: 160 bytes) and moves as 5 + 5 16-byte accesses;
+// the Schur kernel, whose lanes each take one half of a Z block and one half of a W block, reads a half in 5 accesses without
+// any alignment case.
+constexpr int kBlk = 20;        // doubles per stored block
+__device__ __forceinline__ size_t lba_blk(int e) { return (size_t)kBlk * (size_t)e; }
+__device__ __forceinline__ void blk_load_half(const double* __restrict__ blk, int half, double* v)       // rows 3 half .. 3 half + 2
 {
-    const double2* q = (const double2*)p;
+    const double2* q = (const double2*)(blk + 10 * half);
 #pragma unroll
-    for (int i = 0; i < 9; i++) { const double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+    for (int i = 0; i < 4; i++) { const double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
+    v[8] = q[4].x;
 }
-__device__ __forceinline__ void store18(double* __restrict__ p, const double* v)
+__device__ __forceinline__ void blk_load(const double* __restrict__ blk, double* v)
 {
-    double2* q = (double2*)p;
-#pragma unroll
-    for (int i = 0; i < 9; i++) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+    blk_load_half(blk, 0, v);
+    blk_load_half(blk, 1, v + 9);
 }
-// rows 3 half .. 3 half + 2 of such a block (9 doubles from offset 72 half bytes): one 8-byte access + four 16-byte ones
-__device__ __forceinline__ void load9(const double* __restrict__ row18, int half, double* v)
+__device__ __forceinline__ void blk_store(double* __restrict__ blk, const double* v)
 {
-    if (half == 0) {
-        const double2* q = (const double2*)row18;
+    double2* q = (double2*)blk;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const double2 t = q[i]; v[2 * i] = t.x; v[2 * i + 1] = t.y; }
-        v[8] = row18[8];
-    } else {
-        v[0] = row18[9];
-        const double2* q = (const double2*)(row18 + 10);
+    for (int h = 0; h < 2; h++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const double2 t = q[i]; v[1 + 2 * i] = t.x; v[2 + 2 * i] = t.y; }
+        for (int i = 0; i < 4; i++) q[5 * h + i] = make_double2(v[9 * h + 2 * i], v[9 * h + 2 * i + 1]);
+        q[5 * h + 4] = make_double2(v[9 * h + 8], 0.0);
     }
 }
 
@@ -199,12 +199,12 @@ __device__ __forceinline__ void schur_landmark(const Dev& d, int l, int sub, con
         const int e = d.l_edge[k];
         if (d.pose_col[d.e_pose[e]] < 0) continue;
         double W[18], Z[18];
-        load18(d.W + 18 * (size_t)e, W);
+        blk_load(d.W + lba_blk(e), W);
 #pragma unroll
         for (int r = 0; r < 6; r++)
 #pragma unroll
             for (int c = 0; c < 3; c++) Z[r * 3 + c] = W[r * 3] * Di[c] + W[r * 3 + 1] * Di[3 + c] + W[r * 3 + 2] * Di[6 + c];
-        store18(d.Z + 18 * (size_t)e, Z);
+        blk_store(d.Z + lba_blk(e), Z);
     }
 }
 
@@ -261,7 +261,7 @@ __device__ __forceinline__ void lin_landmarks_body(const Dev& d, const double* _
                         for (int q = 0; q < 3; q++) h += Jj[q * 6 + a] * wr * Ji[q * 3 + c];
                         W[a * 3 + c] = h;
                     }
-                store18(d.W + 18 * (size_t)e, W);
+                blk_store(d.W + lba_blk(e), W);
             }
         }
     }
@@ -435,7 +435,7 @@ __device__ __forceinline__ void schur_blocks_body(Dev d, double* __restrict__ S,
         for (int k = d.p_off[i] + tid; k < d.p_off[i + 1]; k += kSchurThreads) {
             const int e = d.p_edge[k];
             double W[18];
-            load18(d.W + 18 * (size_t)e, W);
+            blk_load(d.W + lba_blk(e), W);
             const double* db = d.db + 3 * (size_t)d.e_point[e];
             const double b0 = db[0], b1 = db[1], b2 = db[2];
 #pragma unroll
@@ -462,8 +462,8 @@ __device__ __forceinline__ void schur_blocks_body(Dev d, double* __restrict__ S,
         for (int k = d.b_off[blk] + g; k < d.b_off[blk + 1]; k += kSchurGroups) {
             const int2 pr = d.b_pair[k];
             double z[9], w[9];
-            load9(d.Z + 18 * (size_t)pr.x, rb, z);
-            load9(d.W + 18 * (size_t)pr.y, cb, w);
+            blk_load_half(d.Z + lba_blk(pr.x), rb, z);
+            blk_load_half(d.W + lba_blk(pr.y), cb, w);
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -1221,74 +1221,6 @@ __global__ __launch_bounds__(1024) void k_chol_solve(const double* __restrict__ 
     chol_solve_body<PRE>(S, n, Linv, yin, yin_last, x, scal, last_forward, (int)blockIdx.x, sm);
 }
 
-// ---- landmark back-substitution, trial update (oplus) and scale partials (levenberg.cpp:187-194) ----
-__device__ __forceinline__ void backsub_update_body(Dev d, double lambda, const double* __restrict__ bp_full,
-                                                       const double* __restrict__ poses, const double* __restrict__ pts,
-                                                       double* __restrict__ poses_new, double* __restrict__ pts_new, const int bx)
-{
-    const int g = bx * 64 + threadIdx.x;
-    if (g < d.nL) {
-        const int l = g;
-        double c[3] = {d.bl[3 * (size_t)l], d.bl[3 * (size_t)l + 1], d.bl[3 * (size_t)l + 2]};
-        // four edges at a time: their index chains (edge -> pose -> column -> W, x) are independent, only the subtraction is
-        // kept in edge order (a thread walking one edge after the other paid four dependent memory round trips per edge)
-        const int k1 = d.l_off[l + 1];
-        for (int k = d.l_off[l]; k < k1; k += 4) {
-            int e[4], col[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = (k + u < k1) ? d.l_edge[k + u] : -1;
-#pragma unroll
-            for (int u = 0; u < 4; u++) col[u] = (e[u] >= 0) ? d.pose_col[d.e_pose[e[u]]] : -1;
-            double sv[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                sv[u][0] = 0; sv[u][1] = 0; sv[u][2] = 0;
-                if (col[u] >= 0) {
-                    const double* W = d.W + 18 * (size_t)e[u];
-                    const double* xp = d.x + 6 * (size_t)col[u];
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        double s2 = 0;
-#pragma unroll
-                        for (int r = 0; r < 6; r++) s2 += W[r * 3 + q] * xp[r];
-                        sv[u][q] = s2;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (col[u] >= 0) { c[0] -= sv[u][0]; c[1] -= sv[u][1]; c[2] -= sv[u][2]; }
-        }
-        const double* Di = d.Dinv + 9 * (size_t)l;
-        double sc = 0;
-        for (int a = 0; a < 3; a++) {
-            const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
-            d.x[(size_t)d.n + 3 * (size_t)l + a] = xl;
-            pts_new[3 * (size_t)l + a] = pts[3 * (size_t)l + a] + xl;
-            sc += xl * (lambda * xl + d.bl[3 * (size_t)l + a]);
-        }
-        d.part[l] = sc;
-    } else if (g < d.nL + d.nPoses) {
-        const int ip = g - d.nL;
-        const int col = d.pose_col[ip];
-        if (col < 0) {
-            for (int k = 0; k < 7; k++) poses_new[7 * (size_t)ip + k] = poses[7 * (size_t)ip + k];
-        } else {
-            const double* xp = d.x + 6 * (size_t)col;
-            pose_oplus(poses + 7 * (size_t)ip, xp, poses_new + 7 * (size_t)ip);
-            double sc = 0;
-            for (int a = 0; a < 6; a++) sc += xp[a] * (lambda * xp[a] + bp_full[6 * (size_t)col + a]);
-            d.part[d.nL + col] = sc;
-        }
-    }
-}
-__global__ __launch_bounds__(64) void k_backsub_update(Dev d, double lambda, const double* __restrict__ bp_full,
-                                                       const double* __restrict__ poses, const double* __restrict__ pts,
-                                                       double* __restrict__ poses_new, double* __restrict__ pts_new)
-{
-    backsub_update_body(d, lambda, bp_full, poses, pts, poses_new, pts_new, (int)blockIdx.x);
-}
-
 // ---- the trial's tail in two launches (round 3; it was four: substitution, k_backsub_update, k_errors, k_reduce) ----
 // (a) the substitution workgroup goes straight on to the trial poses: oplus of every pose and the pose part of the scale sum
 __device__ __forceinline__ void pose_update_tail(const Dev& d, double lambda, const double* __restrict__ bp_full,
@@ -1348,7 +1280,7 @@ __device__ __forceinline__ void update_errors_body(const Dev& d, double lambda, 
             const int col = d.pose_col[d.e_pose[e]];
             if (col < 0) continue;
             double W[18], xp[6];
-            load18(d.W + 18 * (size_t)e, W);
+            blk_load(d.W + lba_blk(e), W);
             {
                 const double2* x2 = (const double2*)(d.x + 6 * (size_t)col);        // 48-byte rows of a 256-byte aligned array
                 const double2 a0 = x2[0], a1 = x2[1], a2 = x2[2];
@@ -1547,14 +1479,6 @@ __global__ __launch_bounds__(kUpdThreads) void k_update_errors_b(const BWin* __r
     const int nb = max((w.d.nL + kUpdLandmarks - 1) / kUpdLandmarks, 1);
     if ((int)blockIdx.x >= nb) return;
     update_errors_body(w.d, y.lambda, w.pts[y.cur], w.poses[1 - y.cur], w.pts[1 - y.cur], w.hmap, y.seq, (int)blockIdx.x, nb);
-}
-__global__ __launch_bounds__(64) void k_backsub_update_b(const BWin* __restrict__ wins, BDynAll dyn)
-{
-    const BDyn y = dyn.w[blockIdx.y];
-    if (!(y.flags & kBwTrial)) return;
-    const BWin& w = wins[blockIdx.y];
-    if ((int)blockIdx.x * 64 >= w.d.nL + w.d.nPoses) return;
-    backsub_update_body(w.d, y.lambda, w.bpf, w.poses[y.cur], w.pts[y.cur], w.poses[1 - y.cur], w.pts[1 - y.cur], (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_epilogue(Dev d, const double* __restrict__ poses, const double* __restrict__ pts,
@@ -1836,7 +1760,7 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     s->upload_bytes = s->bytes_wanted;      // everything the host writes lies in front of this offset
     LBA_TRY(s->dalloc(&d.Hll, 9 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.bl, 3 * (size_t)d.nL));
     LBA_TRY(s->dalloc(&d.Hpp, 36 * (size_t)d.nP)); LBA_TRY(s->dalloc(&d.bp, 6 * (size_t)d.nP));
-    LBA_TRY(s->dalloc(&d.W, 18 * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.Z, 18 * (size_t)d.nE));
+    LBA_TRY(s->dalloc(&d.W, lba::kBlk * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.Z, lba::kBlk * (size_t)d.nE));
     LBA_TRY(s->dalloc(&d.Dinv, 9 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.db, 3 * (size_t)d.nL));
     LBA_TRY(s->dalloc(&d.err, 3 * (size_t)d.nE)); LBA_TRY(s->dalloc(&d.rho0, (size_t)d.nE));
     LBA_TRY(s->dalloc(&d.x, (size_t)d.n + 3 * (size_t)d.nL)); LBA_TRY(s->dalloc(&d.part, (size_t)d.nL + d.nP));
