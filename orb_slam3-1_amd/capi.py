@@ -754,8 +754,8 @@ class LbaShard:
         _check(lib.lba_shard_accept(self._h, int(ok)))
 
     STAGES = ("linearize", "schur", "factor", "solve", "update", "reduce", "gaps")
-    STAGE_KERNEL = {"linearize": "k_lin_all", "schur": "k_schur_blocks", "factor": "k_chol_step", "solve": "k_chol_solve",
-                    "update": "k_backsub_update", "reduce": "k_reduce", "gaps": None}
+    STAGE_KERNEL = {"linearize": "k_lin_all", "schur": "k_schur_blocks", "factor": "k_chol_flow", "solve": "k_chol_solve_update",
+                    "update": "k_update_errors", "reduce": "k_reduce", "gaps": None}
 
     def profile_enable(self, on=True):
         lib.lba_shard_profile_enable.argtypes = [C.c_void_p, C.c_int]
