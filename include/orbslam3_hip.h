@@ -287,6 +287,19 @@ typedef struct OrbmDeviceLastPoints {
 int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* last, int batch,
                                                 float th, int check_orientation, int32_t* d_assign, uint8_t* d_occupied,
                                                 int32_t* d_n_matches, void* stream);
+/* The same for SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints) (:43-213;
+ * Tracking::SearchLocalPoints, src/Tracking.cc:3557) on monocular frames: `points` holds per local map point valid =
+ * mbTrackInView, (u, v) = mTrackProjX / Y, octave = mnTrackScaleLevel, desc = GetDescriptor(), d_has_obs = Observations() > 0
+ * (required here; d_angle is not read); `extras` the rest of what the reference reads per point and the call's parameters. */
+typedef struct OrbmDeviceMapPointExtras {
+    const float* d_view_cos;        /* mTrackViewCos, [batch][points->cap] */
+    const float* d_track_depth;     /* mTrackDepth */
+    const uint8_t* d_bad;           /* isBad() */
+    float th_far, nnratio; int32_t far_points;
+} OrbmDeviceMapPointExtras;
+int orbm_search_by_projection_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* points,
+                                           const OrbmDeviceMapPointExtras* extras, int batch, float th,
+                                           int32_t* d_assign, uint8_t* d_occupied, int32_t* d_n_matches, void* stream);
 
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, float th,
  *                                    int ORBdist) (src/ORBmatcher.cc:1889-2010; Tracking::Relocalization).

@@ -467,6 +467,22 @@ class Matcher:
         _check(lib.orbm_search_by_projection_last_batch_device(self._h, C.byref(cf), C.byref(lp), int(batch), C.c_float(th), int(self.check_ori),
                                                                C.c_void_p(d_assign), C.c_void_p(d_occupied), C.c_void_p(d_n_matches), C.c_void_p(stream or 0)))
 
+    class _DevMpExtras(C.Structure):
+        _fields_ = [("d_view_cos", C.c_void_p), ("d_track_depth", C.c_void_p), ("d_bad", C.c_void_p), ("th_far", C.c_float), ("nnratio", C.c_float), ("far_points", C.c_int32)]
+
+    def SearchByProjection_batch_device(self, cur, pts, extras, batch, th, d_assign, d_occupied, d_n_matches, stream=None, bounds=(0.0, 0.0, 640.0, 480.0),
+                                        scale_factors=None, grid=(64, 48), far_points=False, th_far=0.0):
+        """Frame x map points on device arrays: cur as above; pts = (d_valid, d_u, d_v, d_level, 0, d_desc, d_n, cap, d_has_obs);
+        extras = (d_view_cos, d_track_depth, d_bad)"""
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        self._dev_keep = sf
+        cf = self._DevFrames(cur[0], cur[1], cur[2], int(cur[3]), bounds[0], bounds[1], bounds[2], bounds[3], grid[0], grid[1], sf.ctypes.data, len(sf))
+        lp = self._DevLastPoints(pts[0], pts[1], pts[2], pts[3], pts[4] or None, pts[5], pts[6], int(pts[7]), pts[8])
+        ex = self._DevMpExtras(extras[0], extras[1], extras[2], float(th_far), self.nnratio, int(far_points))
+        lib.orbm_search_by_projection_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(lib.orbm_search_by_projection_batch_device(self._h, C.byref(cf), C.byref(lp), C.byref(ex), int(batch), C.c_float(th),
+                                                          C.c_void_p(d_assign), C.c_void_p(d_occupied), C.c_void_p(d_n_matches), C.c_void_p(stream or 0)))
+
     class _TriSide(C.Structure):
         _fields_ = [("n", C.c_int32), ("desc", C.c_void_p), ("has_mp", C.c_void_p), ("stereo", C.c_void_p), ("x", C.c_void_p),
                     ("y", C.c_void_p), ("octave", C.c_void_p), ("angle", C.c_void_p), ("fv", FeatVec)]

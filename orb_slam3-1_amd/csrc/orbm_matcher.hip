@@ -1054,6 +1054,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
 struct ProjDevSetup {
     const OrbxKeyPoint* kps; const uint8_t* desc; const int32_t* n; int32_t cap;
     const uint8_t* p_valid; const float* p_u; const float* p_v; const int32_t* p_oct; const float* p_angle; const uint8_t* p_desc; const int32_t* p_n; int32_t p_cap; const uint8_t* p_obs;
+    const float* p_vcos; const float* p_depth; const uint8_t* p_bad; float th_far, nnratio; int32_t far_points, mode;      // Frame x map points (mode 0)
     float* x; float* y; int32_t* oct; float* ang; int32_t* cell_off; int32_t* cell_feat; int32_t* log_feat; int32_t* log_bin;
     const float* scale; int32_t n_levels, cols, rows;
     float min_x, min_y, max_x, max_y, th, dist_th;
@@ -1079,10 +1080,12 @@ __global__ __launch_bounds__(256) void k_proj_dev_setup(ProjDevSetup P)
         A.F.n = n; A.F.cols = P.cols; A.F.rows = P.rows; A.F.n_levels = P.n_levels; A.F.u_right = nullptr;
         A.n_pts = min(max(P.p_n[b], 0), P.p_cap);
         A.valid = P.p_valid + (size_t)b * P.p_cap; A.u = P.p_u + (size_t)b * P.p_cap; A.v = P.p_v + (size_t)b * P.p_cap; A.ur = nullptr;
-        A.level = P.p_oct + (size_t)b * P.p_cap; A.view_cos = nullptr; A.depth = nullptr; A.bad = nullptr;
-        A.angle = P.p_angle + (size_t)b * P.p_cap; A.desc = P.p_desc + (size_t)b * P.p_cap * 32; A.has_obs = P.p_obs ? P.p_obs + (size_t)b * P.p_cap : nullptr;
-        A.th = P.th; A.th_far = 0.f; A.nnratio = 0.f; A.dist_th = P.dist_th; A.far_points = 0; A.check_ori = P.check_ori;
-        A.last_frame_mode = 1; A.level_window = ORBM_LEVELS_AROUND;
+        A.level = P.p_oct + (size_t)b * P.p_cap;
+        A.view_cos = P.p_vcos ? P.p_vcos + (size_t)b * P.p_cap : nullptr; A.depth = P.p_depth ? P.p_depth + (size_t)b * P.p_cap : nullptr;
+        A.bad = P.p_bad ? P.p_bad + (size_t)b * P.p_cap : nullptr;
+        A.angle = P.p_angle ? P.p_angle + (size_t)b * P.p_cap : nullptr; A.desc = P.p_desc + (size_t)b * P.p_cap * 32; A.has_obs = P.p_obs ? P.p_obs + (size_t)b * P.p_cap : nullptr;
+        A.th = P.th; A.th_far = P.th_far; A.nnratio = P.nnratio; A.dist_th = P.dist_th; A.far_points = P.far_points; A.check_ori = P.check_ori;
+        A.last_frame_mode = P.mode; A.level_window = ORBM_LEVELS_AROUND;
         A.assign = P.assign + (size_t)b * P.cap; A.occupied = P.occupied + (size_t)b * P.cap;
         A.log_feat = P.log_feat + (size_t)b * P.p_cap; A.log_bin = P.log_bin + (size_t)b * P.p_cap;
         A.n_matches = P.n_matches + b;
@@ -2061,13 +2064,15 @@ int orbm_search_by_projection_batch(orbm_matcher* m, OrbmProjQuery* queries, int
     return run_projection_batch(m, queries, n_frames, 0, th, far_points, th_far, nnratio, 0, (float)orbm::TH_HIGH);
 }
 
-int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* last, int batch,
-                                                float th, int check_orientation, int32_t* d_assign, uint8_t* d_occupied, int32_t* d_n_matches, void* stream)
+// shared body of the two device-resident tracking searches (mode 1: last frame, mode 0: Frame x map points)
+static int projection_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* last, const OrbmDeviceMapPointExtras* mp, int mode,
+                                   int batch, float th, int check_orientation, int32_t* d_assign, uint8_t* d_occupied, int32_t* d_n_matches, void* stream)
 {
     if (!m || !cur || !last || !d_assign || !d_occupied || !d_n_matches) return fail(ORBX_ERR_ARG, "NULL argument");
     if (batch < 1 || cur->cap < 1 || last->cap < 1) return fail(ORBX_ERR_ARG, "bad batch / capacities");
     if (!cur->d_kps || !cur->d_desc || !cur->d_n || !cur->scale_factors || cur->n_levels < 1 || cur->n_levels > 32) return fail(ORBX_ERR_ARG, "bad current-frame description");
-    if (!last->d_valid || !last->d_u || !last->d_v || !last->d_octave || !last->d_desc || !last->d_n || (check_orientation && !last->d_angle)) return fail(ORBX_ERR_ARG, "bad last-frame description");
+    if (!last->d_valid || !last->d_u || !last->d_v || !last->d_octave || !last->d_desc || !last->d_n || (mode == 1 && check_orientation && !last->d_angle)) return fail(ORBX_ERR_ARG, "bad point description");
+    if (mode == 0 && (!mp || !mp->d_view_cos || !mp->d_track_depth || !mp->d_bad || !last->d_has_obs)) return fail(ORBX_ERR_ARG, "bad map-point description");
     if (cur->grid_cols < 1 || cur->grid_rows < 1 || cur->grid_cols * (int64_t)cur->grid_rows > (1 << 20) || !(cur->max_x > cur->min_x) || !(cur->max_y > cur->min_y)) return fail(ORBX_ERR_ARG, "bad frame grid");
     if (cur->cap > 8192) return fail(ORBX_ERR_CAPACITY, "at most 8192 features per frame (the grid is sorted in LDS)");
     ORBM_HIP(hipSetDevice(m->device));
@@ -2112,7 +2117,10 @@ int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDevic
     P.cell_off = (int32_t*)(w + o_coff); P.cell_feat = (int32_t*)(w + o_cfeat); P.log_feat = (int32_t*)(w + o_lf); P.log_bin = (int32_t*)(w + o_lb);
     P.scale = m->d_scale; P.n_levels = cur->n_levels; P.cols = cur->grid_cols; P.rows = cur->grid_rows;
     P.min_x = cur->min_x; P.min_y = cur->min_y; P.max_x = cur->max_x; P.max_y = cur->max_y; P.th = th; P.dist_th = (float)orbm::TH_HIGH;
-    P.check_ori = check_orientation; P.lds_frame = stage ? 1 : 0;
+    P.check_ori = mode == 1 ? check_orientation : 0; P.lds_frame = stage ? 1 : 0;
+    P.mode = mode;
+    P.p_vcos = mp ? mp->d_view_cos : nullptr; P.p_depth = mp ? mp->d_track_depth : nullptr; P.p_bad = mp ? mp->d_bad : nullptr;
+    P.th_far = mp ? mp->th_far : 0.f; P.nnratio = mp ? mp->nnratio : 0.f; P.far_points = mp ? mp->far_points : 0;
     P.assign = d_assign; P.occupied = d_occupied; P.n_matches = d_n_matches;
     P.jobs = (orbm::ProjArgs*)(w + o_jobs);
     hipLaunchKernelGGL(orbm::k_proj_dev_setup, dim3(batch), dim3(256), 0, st, P);
@@ -2129,6 +2137,18 @@ int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDevic
     }
     ORBM_HIP(hipGetLastError());
     return ORBX_OK;
+}
+
+int orbm_search_by_projection_last_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* last, int batch,
+                                                float th, int check_orientation, int32_t* d_assign, uint8_t* d_occupied, int32_t* d_n_matches, void* stream)
+{
+    return projection_batch_device(m, cur, last, nullptr, 1, batch, th, check_orientation, d_assign, d_occupied, d_n_matches, stream);
+}
+
+int orbm_search_by_projection_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur, const OrbmDeviceLastPoints* points, const OrbmDeviceMapPointExtras* extras,
+                                           int batch, float th, int32_t* d_assign, uint8_t* d_occupied, int32_t* d_n_matches, void* stream)
+{
+    return projection_batch_device(m, cur, points, extras, 0, batch, th, 0, d_assign, d_occupied, d_n_matches, stream);
 }
 
 #ifdef ORBM_PROJ_TIMING

@@ -347,3 +347,47 @@ def test_search_by_projection_last_batch_device_empty_frames(pkg, sm):
     finally:
         m.close()
     assert nm.cpu().tolist() == [0, 0, 0] and int((assign != -1).sum().item()) == 0
+
+
+def test_search_by_projection_batch_device(pkg, oracle, sm):
+    """the device-resident batch entry of SearchByProjection(Frame, MapPoints): ragged frames and point sets, far-point gate, ratio
+    test -- against the oracle frame by frame"""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, cap, pcap = 10, 1100, 1000
+    cases = [sm.make_projection_case(60 + i, n=1000 - 41 * (i % 4), n_mp=900 - 53 * (i % 5)) for i in range(B)]
+    scale = cases[0][3]
+    kps = np.zeros((B, cap), pkg.KP_DTYPE); desc = np.zeros((B, cap, 32), np.uint8); nn = np.zeros(B, np.int32)
+    pv = np.zeros((B, pcap), np.uint8); pu = np.zeros((B, pcap), np.float32); pw = np.zeros((B, pcap), np.float32); po = np.zeros((B, pcap), np.int32)
+    pd = np.zeros((B, pcap, 32), np.uint8); pn = np.zeros(B, np.int32); ph = np.zeros((B, pcap), np.uint8)
+    vc = np.zeros((B, pcap), np.float32); dp = np.zeros((B, pcap), np.float32); bd = np.zeros((B, pcap), np.uint8)
+    assign = np.full((B, cap), -1, np.int32); occ = np.zeros((B, cap), np.uint8)
+    for b, (g, dF, aF, sc, mp, a, o) in enumerate(cases):
+        n = len(g["x"]); nn[b] = n
+        kps[b, :n]["x"] = g["x"]; kps[b, :n]["y"] = g["y"]; kps[b, :n]["octave"] = g["octave"]; kps[b, :n]["angle"] = aF
+        desc[b, :n] = dF
+        m_ = len(mp["u"]); pn[b] = m_
+        pv[b, :m_] = mp["in_view"]; pu[b, :m_] = mp["u"]; pw[b, :m_] = mp["v"]; po[b, :m_] = mp["level"]; pd[b, :m_] = mp["desc"]; ph[b, :m_] = mp["has_obs"]
+        vc[b, :m_] = mp["view_cos"]; dp[b, :m_] = mp["depth"]; bd[b, :m_] = mp["bad"]
+        assign[b, :n] = a; occ[b, :n] = o
+    t = lambda a_: torch.from_numpy(np.ascontiguousarray(a_).view(np.uint8).reshape(-1)).to(dev)
+    d = {k: t(v) for k, v in dict(kps=kps, desc=desc, n=nn, pv=pv, pu=pu, pw=pw, po=po, pd=pd, pn=pn, ph=ph, vc=vc, dp=dp, bd=bd, assign=assign, occ=occ).items()}
+    d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    g0 = cases[0][0]
+    m = pkg.Matcher(0.8, True)
+    try:
+        m.SearchByProjection_batch_device((d["kps"].data_ptr(), d["desc"].data_ptr(), d["n"].data_ptr(), cap),
+                                          (d["pv"].data_ptr(), d["pu"].data_ptr(), d["pw"].data_ptr(), d["po"].data_ptr(), 0, d["pd"].data_ptr(), d["pn"].data_ptr(), pcap, d["ph"].data_ptr()),
+                                          (d["vc"].data_ptr(), d["dp"].data_ptr(), d["bd"].data_ptr()), B, 3.0, d["assign"].data_ptr(), d["occ"].data_ptr(), d_nm.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream, bounds=(g0["min_x"], g0["min_y"], g0["max_x"], g0["max_y"]), scale_factors=scale,
+                                          far_points=True, th_far=20.0)
+        torch.cuda.synchronize()
+    finally:
+        m.close()
+    a1 = d["assign"].cpu().numpy().view(np.int32).reshape(B, cap); o1 = d["occ"].cpu().numpy().reshape(B, cap); nm = d_nm.cpu().numpy()
+    for b, (g, dF, aF, sc, mp, a, o) in enumerate(cases):
+        a0, o0 = a.copy(), o.copy()
+        n0 = oracle.search_by_projection(g, dF, sc, mp, 3.0, 0.8, a0, o0, b_far=True, th_far=20.0)
+        n = len(g["x"])
+        assert nm[b] == n0 > 100, "frame %d" % b
+        np.testing.assert_array_equal(a1[b, :n], a0); np.testing.assert_array_equal(o1[b, :n], o0)
