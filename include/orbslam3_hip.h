@@ -624,6 +624,26 @@ void liba_destroy(liba_solver* s);
 int  liba_solve(liba_solver* s, const LibaProblem* problem, double* Rwb_out, double* twb_out, double* vel_out, double* bg_out,
                 double* ba_out, double* points_out, double* chi2_per_edge, uint8_t* depth_positive, LbaStats* stats);
 
+/* Many windows per launch (one LocalMapping window per client session or map): every stage of the
+ * Levenberg loop is ONE launch for all windows (grid.y = window), each window keeps its own lambda / accept-reject state on the
+ * host.  liba_solve is this path with one window: results of window i equal liba_solve(problems[i]) bit for bit.  At most 64
+ * windows per call; any output pointer may be NULL. */
+typedef struct LibaOutputs {
+    double* Rwb;                    /* [n_kf][9] */
+    double* twb;                    /* [n_kf][3] */
+    double* vel;
+    double* bg;
+    double* ba;
+    double* points;                 /* [n_points][3] */
+    double* chi2_per_edge;          /* [n_edges] */
+    uint8_t* depth_positive;        /* [n_edges] */
+} LibaOutputs;
+typedef struct liba_batch liba_batch;
+int  liba_batch_create(int device, liba_batch** out);
+void liba_batch_destroy(liba_batch* b);
+int  liba_solve_batch(liba_batch* b, const LibaProblem* problems, const LibaOutputs* outputs, int n_windows, LbaStats* stats);
+double liba_batch_last_device_ms(const liba_batch* b);  /* HIP-event time of the Levenberg rounds of the last call */
+
 /* int Optimizer::PoseInertialOptimizationLastKeyFrame(Frame*, bool bRecInit) (src/Optimizer.cc:4491-4873): the per-frame optimisation
  * of the inertial tracker, for a batch of frames (one per client stream) in one launch.  Index [0] of the state arrays is the last key
  * frame (fixed), [1] the current frame.  Edges = the features holding a map point, in feature order; close_point = mTrackDepth < 10.

@@ -24,5 +24,5 @@ def build(verbose=False):
     return LIB_PATH
 
 
-from .capi import (Extractor, Matcher, LbaSolver, LbaShard, LbaBatch, PoseSolver, Vocabulary, DeviceBowPlan, PacketCodec, InertialSolver, IMU_DTYPE, lib, KP_DTYPE, OrbxError, hamming,  # noqa: E402,F401
+from .capi import (Extractor, Matcher, LbaSolver, LbaShard, LbaBatch, PoseSolver, Vocabulary, DeviceBowPlan, PacketCodec, InertialSolver, LibaBatch, IMU_DTYPE, lib, KP_DTYPE, OrbxError, hamming,  # noqa: E402,F401
                    device_count)

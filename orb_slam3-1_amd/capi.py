@@ -1134,6 +1134,67 @@ class InertialSolver:
         return dict(Rwb=Rwb, twb=twb, vel=vel, bg=bg, ba=ba, points=pts[:m], chi2=chi2[:ne], depth_positive=dpos[:ne], stats=stats)
 
 
+class LibaOutputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("Rwb", "twb", "vel", "bg", "ba", "points", "chi2_per_edge", "depth_positive")]
+
+
+class LibaBatch:
+    """liba_solve_batch: many LocalInertialBA windows (one per map / client session) per launch."""
+
+    def __init__(self, device=0):
+        lib.liba_batch_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.liba_batch_destroy.argtypes = [C.c_void_p]
+        lib.liba_solve_batch.argtypes = [C.c_void_p, C.POINTER(_LibaProblem), C.POINTER(LibaOutputs), C.c_int, C.POINTER(_LibaStats)]
+        lib.liba_batch_last_device_ms.argtypes = [C.c_void_p]
+        lib.liba_batch_last_device_ms.restype = C.c_double
+        h = C.c_void_p()
+        _check(lib.liba_batch_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.liba_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prepare(self, windows, want_outputs=True):
+        """marshal once (a benchmark re-solves the same windows)"""
+        n = len(windows)
+        prs = [_liba_problem(w) for w in windows]
+        arr = (_LibaProblem * n)(*prs)
+        outs, oarr = [], (LibaOutputs * n)()
+        for i, s in enumerate(prs):
+            nk, m, ne = s.n_kf, s.n_points, s.n_edges
+            o = dict(Rwb=np.zeros((nk, 3, 3)), twb=np.zeros((nk, 3)), vel=np.zeros((nk, 3)), bg=np.zeros((nk, 3)), ba=np.zeros((nk, 3)),
+                     points=np.zeros((max(m, 1), 3)), chi2=np.zeros(max(ne, 1)), depth_positive=np.zeros(max(ne, 1), np.uint8))
+            outs.append(o)
+            if want_outputs:
+                oarr[i] = LibaOutputs(*[o[k].ctypes.data for k in ("Rwb", "twb", "vel", "bg", "ba", "points", "chi2", "depth_positive")])
+        return dict(n=n, prs=prs, arr=arr, outs=outs, oarr=oarr, stats=(_LibaStats * n)(), want=want_outputs)
+
+    def run(self, prep):
+        _check(lib.liba_solve_batch(self._h, prep["arr"], prep["oarr"] if prep["want"] else None, prep["n"], prep["stats"]))
+        res = []
+        for i, o in enumerate(prep["outs"]):
+            s, st = prep["prs"][i], prep["stats"][i]
+            stats = dict(iterations=st.iterations, trials=st.trials, stop_reason=st.stop_reason, lambda_=st.lambda_, chi2_initial=st.chi2_initial,
+                         chi2_final=st.chi2_final)
+            res.append(dict(Rwb=o["Rwb"], twb=o["twb"], vel=o["vel"], bg=o["bg"], ba=o["ba"], points=o["points"][:s.n_points], chi2=o["chi2"][:s.n_edges],
+                            depth_positive=o["depth_positive"][:s.n_edges], stats=stats))
+        return res
+
+    def solve(self, windows):
+        return self.run(self.prepare(windows))
+
+    def last_device_ms(self):
+        return float(lib.liba_batch_last_device_ms(self._h))
+
+
 class _LibaPoseProblem(C.Structure):
     _fields_ = [("Rwb", C.c_double * 18), ("twb", C.c_double * 6), ("vel", C.c_double * 6), ("bg", C.c_double * 6), ("ba", C.c_double * 6),
                 ("Rcb", C.c_double * 9), ("tcb", C.c_double * 3), ("tbc", C.c_double * 3),

@@ -107,3 +107,60 @@ def test_golden_inertial_window_on_device(pkg, synth):
     for k in ("twb", "vel", "points"):
         d0, d1 = g[k] - np.asarray(pr[k]), r[k] - np.asarray(pr[k])
         assert np.abs(d0 - d1).max() <= 1e-4 * np.abs(d0).max(), k
+
+
+def test_inertial_batch_equals_single(pkg, synth):
+    """liba_solve_batch: W windows per launch give, window by window, the bits of liba_solve (same kernel bodies, grid.y = window)"""
+    wins = []
+    for seed, kw in ((0, dict(n_opt=6, n_points=200, obs_per_point=5)), (1, dict(n_opt=3, n_points=40)), (2, dict(n_opt=10, n_points=400, obs_per_point=4)),
+                     (3, dict(n_opt=8, n_points=150, bias_error=0.002)), (4, dict(n_opt=25, n_points=600, obs_per_point=6)),
+                     (5, dict(n_opt=4, n_points=90, stereo_frac=0.5, n_covisible_fixed=3))):
+        pr, _ = synth.make_inertial_window(seed, **kw)
+        if seed == 3:
+            pr["lambda_init"] = 1e-2; pr["max_iters"] = 4
+        wins.append(pr)
+    s, b = pkg.InertialSolver(), pkg.LibaBatch()
+    try:
+        single = [s.solve(w) for w in wins]
+        for _ in range(2):                  # the second call runs on the grown arenas
+            batch = b.solve(wins)
+            for i, (r0, r1) in enumerate(zip(single, batch)):
+                assert r1["stats"] == r0["stats"], i
+                for k in ("Rwb", "twb", "vel", "bg", "ba", "points", "chi2", "depth_positive"):
+                    np.testing.assert_array_equal(r1[k], r0[k], err_msg="window %d %s" % (i, k))
+        assert b.last_device_ms() > 0
+    finally:
+        s.close(); b.close()
+
+
+def test_inertial_batch_32_windows_against_oracle(pkg, oracle, synth):
+    """32 windows of different sizes in one call; every fourth is checked against the oracle"""
+    rs = np.random.RandomState(77)
+    wins = []
+    for i in range(32):
+        pr, _ = synth.make_inertial_window(300 + i, n_opt=int(rs.randint(2, 12)), n_points=int(rs.randint(30, 300)), obs_per_point=int(rs.randint(3, 7)),
+                                           stereo_frac=float(rs.choice([0.0, 0.3])), n_covisible_fixed=int(rs.choice([0, 4])))
+        wins.append(pr)
+    b = pkg.LibaBatch()
+    try:
+        res = b.solve(wins)
+    finally:
+        b.close()
+    for i in range(0, 32, 4):
+        _compare(oracle_inertial_solve(oracle, wins[i]), res[i], wins[i], i)
+
+
+def test_inertial_batch_edge_cases(pkg, synth):
+    b = pkg.LibaBatch()
+    try:
+        assert b.solve([]) == []
+        pr, _ = synth.make_inertial_window(1, n_opt=3, n_points=40)
+        with pytest.raises(pkg.OrbxError):
+            b.solve([pr] * 65)
+        bad = dict(pr); bad["lambda_init"] = 0.0
+        with pytest.raises(pkg.OrbxError):
+            b.solve([pr, bad])
+        r = b.solve([pr])               # the handle stays usable after a refused call
+        assert r[0]["stats"]["iterations"] > 0
+    finally:
+        b.close()
