@@ -695,6 +695,18 @@ def main():
                                               "10 inertial links, optimize(10), lambda 1" % len(iw["edge_kf"]),
                                   "chi2_initial": ri["stats"]["chi2_initial"], "chi2_final": ri["stats"]["chi2_final"]}
             isol.close()
+            # many windows per launch (liba_solve_batch): 32 windows of that size, one per client session
+            ib = pkg.LibaBatch(device=local_rank)
+            iws = [synth.make_inertial_window(i, n_opt=10, n_points=800, obs_per_point=6, n_covisible_fixed=10)[0] for i in range(32)]
+            ipre = ib.prepare(iws)
+            ib.run(ipre); ib.run(ipre)
+            t0 = time.perf_counter(); its_b = 0; dev_b = 0.0
+            for _ in range(3):
+                its_b += sum(x["stats"]["iterations"] for x in ib.run(ipre)); dev_b += ib.last_device_ms()
+            dtb = time.perf_counter() - t0
+            out["inertial_ba"]["batched"] = {"windows": 32, "value": its_b / dtb, "unit": "iters/s (whole C call)", "ms_per_call": 1e3 * dtb / 3,
+                                             "device_rounds_iters_per_s": its_b / (dev_b * 1e-3), "device_ms_per_call": dev_b / 3}
+            ib.close()
 
         # ---- per-frame inertial optimisation leg: Optimizer::PoseInertialOptimizationLastKeyFrame for a batch of frames (one per stream) ----
         if args.extra and not args.no_lba:
@@ -811,6 +823,8 @@ def main():
                 out["inertial_ba"]["cpu_baseline"] = {"value": rc["stats"]["iterations"] / dtc, "unit": "iters/s", "cores": 1, "kind": "port",
                                                       "sample": "3 solves of the same window"}
                 out["inertial_ba"]["speedup_vs_cpu_1core"] = out["inertial_ba"]["value"] / (rc["stats"]["iterations"] / dtc)
+                if "batched" in out["inertial_ba"]:
+                    out["inertial_ba"]["batched"]["speedup_vs_cpu_1core"] = out["inertial_ba"]["batched"]["value"] / (rc["stats"]["iterations"] / dtc)
 
     # ---- stereo streams: two extractions per frame with vLappingArea = {0, 0} (src/Frame.cc:122-125, two
     # ORBextractor instances) + Frame::ComputeStereoMatches, B/2 rectified pairs per GPU, sharded like the mono frames ----
