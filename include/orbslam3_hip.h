@@ -124,7 +124,7 @@ int orbx_debug_set_fast_corner_cap(orbx_extractor* h, int cap);
 int orbx_debug_set_tail_delay(orbx_extractor* h, int microseconds);
 /* Test hook: the schedule the LAST extract call used -- bits 0-1 octree instantiation (0 node pool in HBM, 1 keys + nodes in
  * LDS, 2 keys in the L2-resident scratch), 4 two octree launches, 8 level-0 octree started early, 16 level 0 read in place,
- * 32 resize tail on the side stream. */
+ * 32 resize tail on the side stream, 64 the whole resize chain on the side stream beside FAST on level 0. */
 int orbx_debug_last_schedule(orbx_extractor* h);
 
 /* ------------------------------------------------------------------------------------------------
@@ -539,6 +539,27 @@ int  pose_optimize(pose_solver* s, const PoseProblem* problem, PoseResult* resul
 int  pose_optimize_batch(pose_solver* s, const PoseProblem* problems, int n_problems, PoseResult* results, uint8_t* const* outlier_out);
 /* device time of the kernel of the LAST call (HIP events on the solver's stream), milliseconds */
 float pose_last_kernel_ms(const pose_solver* s);
+
+/* Device-resident batch of Optimizer::PoseOptimization (src/Optimizer.cc:814-1115) for `batch` frames whose features and matches
+ * are already in HBM (Tracking::TrackWithMotionModel, src/Tracking.cc:3053: right behind SearchByProjection(CurrentFrame,
+ * LastFrame); TrackLocalMap :3115): nothing visits the host.  The edges of frame b are gathered on the device in feature order
+ * (the order the reference walks pFrame->mvpMapPoints, :861-996): feature i holds a map point iff d_assign[b][i] >= 0 -- the row
+ * of d_mp_xyz[b] with its GetWorldPos() (for the last-frame search: the index orbm_search_by_projection_last_batch_device wrote) --
+ * observation = d_kps[b][i].pt (mvKeysUn: pass undistorted records) and d_u_right[b][i] (stereo edge iff >= 0; NULL = monocular
+ * frames), information = inv_level_sigma2[octave]; floats become doubles exactly where the reference casts them.
+ * Outputs (device, any may be NULL): d_pose_out[batch][7] = optimised Tcw (qx qy qz qw tx ty tz), d_inliers[batch] = the
+ * function's return value, d_outlier[batch][cap] = pFrame->mvbOutlier (0 for features without a map point), d_results[batch].
+ * Only enqueues on `stream`; one solver handle serves one stream at a time. */
+typedef struct PoseDeviceFrames {
+    const OrbxKeyPoint* d_kps; const int32_t* d_n; const float* d_u_right; int32_t cap;
+    const int32_t* d_assign;                /* [batch][cap] */
+    const float* d_mp_xyz; int32_t mp_cap;  /* [batch][mp_cap][3] */
+    const double* d_pose;                   /* [batch][7] pFrame->GetPose() as Tcw, normalised on entry like g2o::SE3Quat */
+    const float* inv_level_sigma2; int32_t n_levels;      /* HOST array, pFrame->mvInvLevelSigma2 (<= 16 levels) */
+    double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
+} PoseDeviceFrames;
+int  pose_optimize_batch_device(pose_solver* s, const PoseDeviceFrames* frames, int batch, double* d_pose_out, int32_t* d_inliers,
+                                uint8_t* d_outlier, PoseResult* d_results, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Vocabulary transform.  Replaces, for FORB descriptors with TF_IDF weights and L1 scoring (what

@@ -843,6 +843,14 @@ class PoseResult(C.Structure):
                 ("iterations", C.c_int32 * 4), ("trials", C.c_int32 * 4), ("chi2", C.c_double * 4)]
 
 
+class PoseDeviceFrames(C.Structure):
+    _fields_ = [("d_kps", C.c_void_p), ("d_n", C.c_void_p), ("d_u_right", C.c_void_p), ("cap", C.c_int32),
+                ("d_assign", C.c_void_p), ("d_mp_xyz", C.c_void_p), ("mp_cap", C.c_int32), ("d_pose", C.c_void_p),
+                ("inv_level_sigma2", C.c_void_p), ("n_levels", C.c_int32),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double),
+                ("huber_mono", C.c_double), ("huber_stereo", C.c_double)]
+
+
 def _pose_problem(w, pr):
     keep = [np.ascontiguousarray(w["Xw"], np.float64), np.ascontiguousarray(w["obs"], np.float64),
             np.ascontiguousarray(w["inv_sigma2"], np.float64), np.ascontiguousarray(w["stereo"], np.uint8)]
@@ -898,6 +906,17 @@ class PoseSolver:
     def run(self, prep):
         self.launch(prep)
         return self.results(prep)
+
+    def optimize_batch_device(self, batch, cap, d_kps, d_n, d_assign, d_mp_xyz, mp_cap, d_pose, inv_level_sigma2, cam, d_pose_out, d_inliers,
+                              d_outlier, stream, d_u_right=None, d_results=None):
+        """pose_optimize_batch_device: every d_* argument is a device address (int); `cam` = dict(fx, fy, cx, cy, bf[, huber_mono,
+        huber_stereo]); inv_level_sigma2 a host float array.  Only enqueues on `stream`."""
+        lib.pose_optimize_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        isig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        f = PoseDeviceFrames(d_kps, d_n, d_u_right, cap, d_assign, d_mp_xyz, mp_cap, d_pose, isig.ctypes.data, len(isig),
+                             float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), float(cam.get("bf", 0.0)),
+                             float(cam.get("huber_mono", np.float32(np.sqrt(5.991)))), float(cam.get("huber_stereo", np.float32(np.sqrt(7.815)))))
+        _check(lib.pose_optimize_batch_device(self._h, C.byref(f), batch, d_pose_out, d_inliers, d_outlier, d_results, stream))
 
     def last_kernel_ms(self):
         lib.pose_last_kernel_ms.restype = C.c_float

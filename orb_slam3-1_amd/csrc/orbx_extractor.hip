@@ -149,7 +149,7 @@ struct orbx_extractor {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // second stream for the octree of the upper pyramid levels (their node pools are small: own launch, own LDS size)
     hipStream_t oct_stream = nullptr;
-    hipEvent_t ev_oct_join = nullptr, ev_fast0 = nullptr;
+    hipEvent_t ev_oct_join = nullptr, ev_fast0 = nullptr, ev_resize = nullptr;
     hipEvent_t ev_tail = nullptr;        // the resize tail's levels are written (the blur on the launch stream reads them)
     int dbg_tail_delay_us = 0;           // tests: a spin kernel in front of the resize tail (orbx_debug_set_tail_delay)
     int last_octree_variant = 0;         // which k_octree instantiation / schedule the last enqueue used (orbx_debug_last_schedule)
@@ -159,6 +159,7 @@ struct orbx_extractor {
     int split_parts = 1;                 // ORBX_SPLIT (measurement knob, see enqueue)
     bool serial_schedule = false;        // ORBX_SERIAL=1: every kernel of a batch on the launch stream, one launch per stage (per-kernel profiles)
     int resize_tail_first = 4;           // first pyramid level of the fused resize tail (ORBX_RESIZE_TAIL; 0: a launch per level)
+    bool resize_beside = true;           // the whole resize chain on the side stream beside FAST on level 0 (ORBX_RESIZE_BESIDE=0: in front of it)
     std::vector<hipStream_t> aux_streams;
     hipEvent_t ev_parts_fork = nullptr;
     std::vector<hipEvent_t> ev_parts_join;
@@ -502,6 +503,14 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         // (resize_tail_first: the levels from there on are one launch, a workgroup per frame -- k_resize_tail)
         // (only with many frames: a single workgroup walks a small batch's levels slower than one wide launch per level does)
         const int l_tail = (nB >= 64 && resize_tail_first >= 2 && resize_tail_first < nlevels) ? resize_tail_first : nlevels;
+        // FAST on level 0 needs no resized level, so the whole resize chain (levels 1 .. and the tail) runs on the side stream beside
+        // it; `s` waits for the levels before the tail (ev_resize) in front of FAST on levels 1 ..  (1.005 -> 0.991 ms per 256-frame
+        // step.  Measured and dropped in the same session: the blur on a stream of its own right behind the resize chain, beside
+        // FAST -- two issue-bound whole-chip kernels side by side: 1.10 ms.)
+        const bool chain_beside = resize_beside && blur_s && oct_stream && n_cells > 0 && l_tail < nlevels && l_tail > 1 &&
+                                  !strips.empty() && strips[0].level == 0;
+        hipStream_t rs = chain_beside ? oct_stream : s;
+        if (chain_beside) { ORBX_HIP(hipEventRecord(ev_fork, s)); ORBX_HIP(hipStreamWaitEvent(rs, ev_fork, 0)); }
         for (int l = 1; l < l_tail; l++) {
             const LevelDesc& D = levels[l];
             dim3 g(xcd_grid(((D.w + kResizeTW - 1) / kResizeTW) * ((D.h + kResizeRows - 1) / kResizeRows)), nB);
@@ -509,10 +518,11 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             SrcImage src;
             src.base = pyr + P.off; src.frame_stride = pyr_frame_bytes; src.stride = P.stride; src.w = P.w; src.h = P.h;
             if (l == 1 && in_place) src = lvl0;
-            hipLaunchKernelGGL(k_resize, g, dim3(256), 0, s, src, pyr, pyr_frame_bytes, D,
+            hipLaunchKernelGGL(k_resize, g, dim3(256), 0, rs, src, pyr, pyr_frame_bytes, D,
                                d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
             ORBX_LAUNCHED("k_resize");
         }
+        if (chain_beside) ORBX_HIP(hipEventRecord(ev_resize, rs));
         // The octree is one wave per (level, frame).  With few frames the chip is empty anyway and a wave's latency is the
         // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
         // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
@@ -532,6 +542,10 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                                    d_cell_count.p + (size_t)f0 * std::max<size_t>(cells.size(), 1), n_cells, d_scratch.p + (size_t)f0 * 2 * cand_frame_entries, (size_t)2 * cand_frame_entries, pool, keys,
                                    sel, sel_frame_entries, sel_cnt, nlevels, o_status + f0,
                                    d_oct_nodes.p ? d_oct_nodes.p + (size_t)f0 * nlevels * oct_node_stride : nullptr, oct_node_stride, lv0);
+        };
+        auto launch_blur = [&](hipStream_t bs) {
+            hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), nB), dim3(256), 0, bs, lvl0, pyr, in_place ? pyr : nullptr, blr, pyr_frame_bytes,
+                               d_levels.p, d_tiles.p, (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
         };
         bool oct0_early = false;            // level 0's octree already runs beside FAST on the levels above it (below)
         bool tail_beside = false;           // the resize tail ran on oct_stream: ev_tail orders its levels before the blur
@@ -553,7 +567,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             // lower levels (which only need the levels before the tail) instead of in front of it.
             const bool beside = blur_s && oct_stream && n_cells > 0 && tail_strip > 0;
             hipStream_t ts = beside ? oct_stream : s;
-            if (beside) { ORBX_HIP(hipEventRecord(ev_fork, s)); ORBX_HIP(hipStreamWaitEvent(ts, ev_fork, 0)); }
+            if (beside && !chain_beside) { ORBX_HIP(hipEventRecord(ev_fork, s)); ORBX_HIP(hipStreamWaitEvent(ts, ev_fork, 0)); }
             if (dbg_tail_delay_us > 0) hipLaunchKernelGGL(k_debug_spin, dim3(1), dim3(64), 0, ts, (long long)dbg_tail_delay_us * 100);
             hipLaunchKernelGGL(k_resize_tail, dim3(nB), dim3(1024), 0, ts, pyr, pyr_frame_bytes, d_levels.p, T, l_tail, nlevels);
             ORBX_LAUNCHED("k_resize_tail");
@@ -574,9 +588,16 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
                     ORBX_HIP(hipStreamWaitEvent(blur_s, ev_fast0, 0));
                     launch_octree(blur_s, 0, 1, o_lds, oct_pool, o_keys);
                     oct0_early = true;
+                    if (chain_beside) ORBX_HIP(hipStreamWaitEvent(s, ev_resize, 0));
                     launch_fast(s, l1_strip, tail_strip);
-                } else
+                } else if (chain_beside && l1_strip > 0 && l1_strip < tail_strip) {
+                    launch_fast(s, 0, l1_strip);
+                    ORBX_HIP(hipStreamWaitEvent(s, ev_resize, 0));
+                    launch_fast(s, l1_strip, tail_strip);
+                } else {
+                    if (chain_beside) ORBX_HIP(hipStreamWaitEvent(s, ev_resize, 0));
                     launch_fast(s, 0, tail_strip);
+                }
                 ORBX_HIP(hipStreamWaitEvent(blur_s, ev_oct_join, 0));
             } else {
                 if (marks) mark();
@@ -588,10 +609,6 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         }
         ORBX_LAUNCHED("k_fast_strips");
         if (marks) mark();
-        auto launch_blur = [&](hipStream_t bs) {
-            hipLaunchKernelGGL(k_blur, dim3(xcd_grid((int)tiles.size()), nB), dim3(256), 0, bs, lvl0, pyr, in_place ? pyr : nullptr, blr, pyr_frame_bytes,
-                               d_levels.p, d_tiles.p, (int)tiles.size(), taps[0], taps[1], taps[2], taps[3]);
-        };
         // With a side stream the throughput-bound blur stays on the launch stream (it starts the moment FAST ends) and the
         // latency-bound octree + index go beside it: octree of the lower levels and the index on `blur_s`, the upper levels'
         // octree on `oct_stream`.  Without one (profiling) everything is serial on `s`.
@@ -610,7 +627,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             if (tail_beside) ORBX_HIP(hipStreamWaitEvent(s, ev_tail, 0));
             launch_blur(s);
         }
-        last_octree_variant = (oct_nodes_hbm ? 0 : (o_keys > 0 ? 1 : 2)) | (two_launches ? 4 : 0) | (oct0_early ? 8 : 0) | (in_place ? 16 : 0) | (tail_beside ? 32 : 0);
+        last_octree_variant = (oct_nodes_hbm ? 0 : (o_keys > 0 ? 1 : 2)) | (two_launches ? 4 : 0) | (oct0_early ? 8 : 0) | (in_place ? 16 : 0) | (tail_beside ? 32 : 0) | (chain_beside ? 64 : 0);
         if (two_launches) ORBX_HIP(hipStreamWaitEvent(os, ev_oct_join, 0));
         ORBX_LAUNCHED("k_octree / k_blur");
         if (marks) mark();
@@ -716,10 +733,12 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
         hipStreamCreateWithFlags(&e->oct_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_oct_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_resize, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fast0, hipEventDisableTiming) != hipSuccess) { orbx_destroy(e); return fail(ORBX_ERR_HIP, "side stream create failed"); }
     if (const char* env = getenv("ORBX_SERIAL")) e->serial_schedule = atoi(env) != 0;
     if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
     if (const char* env = getenv("ORBX_RESIZE_TAIL")) e->resize_tail_first = atoi(env);
+    if (const char* env = getenv("ORBX_RESIZE_BESIDE")) e->resize_beside = atoi(env) != 0;
     for (int i = 0; i + 1 < e->split_parts; i++) {
         hipStream_t s = nullptr; hipEvent_t ev = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
@@ -741,6 +760,7 @@ void orbx_destroy(orbx_extractor* e)
     if (e->oct_stream) { (void)hipStreamSynchronize(e->oct_stream); (void)hipStreamDestroy(e->oct_stream); }
     if (e->ev_oct_join) (void)hipEventDestroy(e->ev_oct_join);
     if (e->ev_fast0) (void)hipEventDestroy(e->ev_fast0);
+    if (e->ev_resize) (void)hipEventDestroy(e->ev_resize);
     if (e->ev_tail) (void)hipEventDestroy(e->ev_tail);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);

@@ -423,6 +423,93 @@ __global__ __launch_bounds__(256) void k_pose_opt(const ProblemDev* __restrict__
     }
 }
 
+
+// ---- device-resident entry (pose_optimize_batch_device): the frame's edges are gathered ON THE DEVICE from the arrays the extractor
+// and the projection search left there, in feature order (the order Optimizer::PoseOptimization walks mvpMapPoints, :861-996) ----
+struct GatherArgs {
+    const OrbxKeyPoint* kps; const int32_t* n_kps; const float* u_right; const int32_t* assign; const float* mp_xyz; const double* pose;
+    int32_t cap, mp_cap, n_levels;
+    float inv_sigma2[16];
+    double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
+    uint8_t* slots; size_t slot_bytes;              // per frame: [Xw | obs | w | err | idx | stereo | outl | act]
+    size_t o_obs, o_w, o_err, o_idx, o_st, o_outl, o_act;
+    ProblemDev* problems; PoseResult* results;
+};
+
+// one workgroup per frame: ordered compaction of the features that hold a map point (assign >= 0) into the solver's edge arrays;
+// float -> double exactly as the reference casts them (obs << kpUn.pt.x ..., GetWorldPos().cast<double>(), mvInvLevelSigma2)
+__global__ __launch_bounds__(256) void k_pose_gather(GatherArgs A)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* slot = A.slots + (size_t)b * A.slot_bytes;
+    double* Xw = (double*)slot; double* obs = (double*)(slot + A.o_obs); double* w = (double*)(slot + A.o_w);
+    int32_t* idx = (int32_t*)(slot + A.o_idx); uint8_t* st = slot + A.o_st;
+    const int n = min(max(A.n_kps[b], 0), A.cap);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        int j = -1;
+        if (i < n) { j = A.assign[(size_t)b * A.cap + i]; if (j >= A.mp_cap) j = -1; }
+        const bool has = j >= 0;
+        const unsigned long long bal = __ballot(has);
+        const int in_wave = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_base;
+        for (int q = 0; q < wave; q++) before += s_wave[q];
+        if (has) {
+            const int e = before + in_wave;
+            const OrbxKeyPoint k = A.kps[(size_t)b * A.cap + i];
+            const float* X = A.mp_xyz + 3 * ((size_t)b * A.mp_cap + j);
+            const float ur = A.u_right ? A.u_right[(size_t)b * A.cap + i] : -1.0f;
+            Xw[3 * (size_t)e] = (double)X[0]; Xw[3 * (size_t)e + 1] = (double)X[1]; Xw[3 * (size_t)e + 2] = (double)X[2];
+            obs[3 * (size_t)e] = (double)k.x; obs[3 * (size_t)e + 1] = (double)k.y; obs[3 * (size_t)e + 2] = (double)ur;
+            const int oc = min(max(k.octave, 0), A.n_levels - 1);
+            w[e] = (double)A.inv_sigma2[oc];
+            st[e] = (A.u_right && !(ur < 0.0f)) ? 1 : 0;          // mvuRight[i] < 0: monocular observation (:869)
+            idx[e] = i;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        ProblemDev P;
+        for (int k = 0; k < 4; k++) P.q[k] = A.pose[7 * (size_t)b + k];
+        for (int k = 0; k < 3; k++) P.t[k] = A.pose[7 * (size_t)b + 4 + k];
+        P.n = s_base;
+        P.Xw = Xw; P.obs = obs; P.w = w; P.stereo = st;
+        P.fx = A.fx; P.fy = A.fy; P.cx = A.cx; P.cy = A.cy; P.bf = A.bf; P.huber_mono = A.huber_mono; P.huber_stereo = A.huber_stereo;
+        P.err = (double*)(slot + A.o_err); P.outlier = slot + A.o_outl; P.active = slot + A.o_act;
+        P.result = A.results + b;
+        A.problems[b] = P;
+    }
+}
+
+// results back into per-feature / per-frame arrays: mvbOutlier[i] (0 for a feature without a map point), the pose, the return value
+__global__ __launch_bounds__(256) void k_pose_scatter(const ProblemDev* __restrict__ problems, const uint8_t* __restrict__ slots, size_t slot_bytes, size_t o_idx,
+                                                      int cap, double* __restrict__ pose_out, int32_t* __restrict__ inliers, uint8_t* __restrict__ outlier,
+                                                      PoseResult* __restrict__ results_out)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const ProblemDev& P = problems[b];
+    const int32_t* idx = (const int32_t*)(slots + (size_t)b * slot_bytes + o_idx);
+    if (outlier) {
+        for (int i = tid; i < cap; i += 256) outlier[(size_t)b * cap + i] = 0;
+        __syncthreads();
+        for (int e = tid; e < P.n; e += 256) outlier[(size_t)b * cap + idx[e]] = P.outlier[e];
+    }
+    if (tid == 0) {
+        const PoseResult R = *P.result;
+        if (pose_out) { for (int k = 0; k < 4; k++) pose_out[7 * (size_t)b + k] = R.q[k]; for (int k = 0; k < 3; k++) pose_out[7 * (size_t)b + 4 + k] = R.t[k]; }
+        if (inliers) inliers[b] = R.inliers;
+        if (results_out) results_out[b] = R;
+    }
+}
+
 }  // namespace poseopt
 
 struct pose_solver {
@@ -432,6 +519,8 @@ struct pose_solver {
     uint8_t* d_blob = nullptr;      // device image of h_blob + scratch
     uint8_t* h_blob = nullptr;      // pinned staging: [descriptors | inputs] up, [results | outlier flags] down
     size_t d_cap = 0, h_cap = 0;
+    uint8_t* d_dev = nullptr;       // arena of the device-resident entry (edge slots, problem descriptors, results)
+    size_t dev_cap = 0;
     float last_kernel_ms = 0;
 };
 
@@ -468,6 +557,7 @@ void pose_destroy(pose_solver* s)
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->d_blob) (void)hipFree(s->d_blob);
+    if (s->d_dev) (void)hipFree(s->d_dev);
     if (s->h_blob) (void)hipHostFree(s->h_blob);
     delete s;
 }
@@ -552,6 +642,52 @@ int pose_optimize_batch(pose_solver* s, const PoseProblem* problems, int n_probl
     if (outlier_out)
         for (int i = 0; i < n_problems; i++)
             if (outlier_out[i] && problems[i].n > 0) std::memcpy(outlier_out[i], s->h_blob + offs[i].outl, (size_t)problems[i].n);
+    return ORBX_OK;
+}
+
+int pose_optimize_batch_device(pose_solver* s, const PoseDeviceFrames* f, int batch, double* d_pose_out, int32_t* d_inliers,
+                               uint8_t* d_outlier, PoseResult* d_results, void* stream)
+{
+    if (!s || !f || batch < 1) return fail(ORBX_ERR_ARG, "bad arguments");
+    if (!f->d_kps || !f->d_n || !f->d_assign || !f->d_mp_xyz || !f->d_pose || !f->inv_level_sigma2) return fail(ORBX_ERR_ARG, "NULL arrays");
+    if (f->cap < 1 || f->mp_cap < 1 || f->n_levels < 1 || f->n_levels > 16) return fail(ORBX_ERR_ARG, "bad cap / mp_cap / n_levels");
+    POSE_HIP(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cap = (size_t)f->cap;
+    poseopt::GatherArgs A;
+    std::memset(&A, 0, sizeof(A));
+    size_t pos = 0;
+    pos = align16(pos + 24 * cap); A.o_obs = pos;
+    pos = align16(pos + 24 * cap); A.o_w = pos;
+    pos = align16(pos + 8 * cap); A.o_err = pos;
+    pos = align16(pos + 24 * cap); A.o_idx = pos;
+    pos = align16(pos + 4 * cap); A.o_st = pos;
+    pos = align16(pos + cap); A.o_outl = pos;
+    pos = align16(pos + cap); A.o_act = pos;
+    pos = align16(pos + cap);
+    A.slot_bytes = pos;
+    const size_t prob_off = pos * (size_t)batch;
+    const size_t res_off = align16(prob_off + sizeof(poseopt::ProblemDev) * (size_t)batch);
+    const size_t total = align16(res_off + sizeof(PoseResult) * (size_t)batch);
+    if (total > s->dev_cap) {           // (first call / larger batch: the only synchronising step)
+        if (s->d_dev) { POSE_HIP(hipDeviceSynchronize()); (void)hipFree(s->d_dev); }
+        s->d_dev = nullptr; s->dev_cap = 0;
+        POSE_HIP(hipMalloc((void**)&s->d_dev, total));
+        s->dev_cap = total;
+    }
+    A.kps = f->d_kps; A.n_kps = f->d_n; A.u_right = f->d_u_right; A.assign = f->d_assign; A.mp_xyz = f->d_mp_xyz; A.pose = f->d_pose;
+    A.cap = f->cap; A.mp_cap = f->mp_cap; A.n_levels = f->n_levels;
+    for (int l = 0; l < f->n_levels; l++) A.inv_sigma2[l] = f->inv_level_sigma2[l];
+    A.fx = f->fx; A.fy = f->fy; A.cx = f->cx; A.cy = f->cy; A.bf = f->bf; A.huber_mono = f->huber_mono; A.huber_stereo = f->huber_stereo;
+    A.slots = s->d_dev;
+    A.problems = (poseopt::ProblemDev*)(s->d_dev + prob_off);
+    A.results = (PoseResult*)(s->d_dev + res_off);
+    hipLaunchKernelGGL(poseopt::k_pose_gather, dim3(batch), dim3(256), 0, st, A);
+    if (f->d_u_right) hipLaunchKernelGGL(poseopt::k_pose_opt<true>, dim3(batch), dim3(256), 0, st, (const poseopt::ProblemDev*)A.problems);
+    else hipLaunchKernelGGL(poseopt::k_pose_opt<false>, dim3(batch), dim3(256), 0, st, (const poseopt::ProblemDev*)A.problems);
+    hipLaunchKernelGGL(poseopt::k_pose_scatter, dim3(batch), dim3(256), 0, st, (const poseopt::ProblemDev*)A.problems, (const uint8_t*)s->d_dev, A.slot_bytes, A.o_idx,
+                       f->cap, d_pose_out, d_inliers, d_outlier, d_results);
+    POSE_HIP(hipGetLastError());
     return ORBX_OK;
 }
 

@@ -254,8 +254,8 @@ def test_large_batch_other_geometries(pkg, oracle, synth, args, size):
         ex.close()
 
 
-@pytest.mark.parametrize("B,tail_delay", [(64, 0), (96, 0), (96, 400)])
-def test_large_batch_device_api_in_place(pkg, oracle, synth, B, tail_delay):
+@pytest.mark.parametrize("B,tail_delay,mode", [(64, 0, 1), (96, 0, 1), (96, 400, 1), (96, 400, 0), (64, 0, 0)])
+def test_large_batch_device_api_in_place(pkg, oracle, synth, monkeypatch, B, tail_delay, mode):
     """the bench's path: device-resident frames read in place (level 0 = the caller's buffer, copied into the pyramid by the
     blur), the large-batch schedule, results left on the device -- twice on the same handle, against the oracle frame by frame.
     Both batch sizes must take the bench's schedule -- octree keys in the L2-resident scratch (at 640x480 a level's candidates
@@ -263,8 +263,11 @@ def test_large_batch_device_api_in_place(pkg, oracle, synth, B, tail_delay):
     test_small_images_keep_octree_keys_in_lds), two octree launches, level 0's octree started early, resize tail on the side
     stream -- and the test asserts that it ran (orbx_debug_last_schedule).  With `tail_delay` a spin kernel holds the resize tail back by 0.4 ms -- far longer than FAST on the lower
     levels -- and the upper pyramid levels are poisoned first, so a blur that does not wait for the tail reads the poison and the
-    upper levels' descriptors differ (the ordering bug of round 2, src/ORBextractor.cc:1132-1138 reads every level)."""
+    upper levels' descriptors differ (the ordering bug of round 2, src/ORBextractor.cc:1132-1138 reads every level).
+    `mode` picks the stream schedule (1, the default: the resize chain on the side stream beside FAST on level 0; 0: in front of it):
+    both must give the same bits, also with the delayed tail."""
     import torch
+    monkeypatch.setenv("ORBX_RESIZE_BESIDE", str(mode & 1))
     distinct = [synth.make_frame(970 + i) for i in range(8)]
     oex = oracle.extractor(1000, 1.2, 8, 20, 7)
     ref = [oex.extract(im, (0, 1000)) for im in distinct]
@@ -288,7 +291,7 @@ def test_large_batch_device_api_in_place(pkg, oracle, synth, B, tail_delay):
             torch.cuda.synchronize()
             sched = ex.debug_last_schedule()
             assert sched & 16, "level 0 was not read in place"
-            assert sched == (2 | 4 | 8 | 16 | 32), "not the bench's schedule: %d" % sched
+            assert sched == (2 | 4 | 8 | 16 | 32 | (64 if mode & 1 else 0)), "not the expected schedule: %d" % sched
             assert int(d_st.abs().sum().item()) == 0
             n = d_n.cpu().numpy(); mono = d_mono.cpu().numpy()
             kps = d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap); desc = d_desc.cpu().numpy().reshape(B, cap, 32)
