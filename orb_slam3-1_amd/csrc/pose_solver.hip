@@ -218,13 +218,14 @@ __device__ __forceinline__ bool edge_is_outlier(const Edge& d, const double* r)
 }
 
 constexpr int kAccRow = 264;        // 256 partials + one pad per 32 (bank spread for the strided second stage)
-constexpr int kRegEdges = 2;        // edges per thread held in registers (n <= 512 never re-reads global memory)
+// kRegEdges (template parameter R of the kernel): edges per thread held in registers -- 2 (n <= 512 never re-reads global memory) or,
+// for frames with more edges (TrackWithMotionModel matches ~750 of 1000 features), 4; the per-thread summation order is the same.
 
 // STEREO = the batch holds at least one stereo edge; the mono instantiation carries 2-row Jacobians only.
 // The Levenberg state (pose, lambda, chi2, counters) and the 6x6 solve are REPLICATED in every thread: all lanes run the
 // same scalar code on the same reduced values, so no broadcast barriers sit between the solve, the trial pass and the
 // accept / reject decision -- the only synchronisation left is inside the two block reductions.
-template <bool STEREO>
+template <bool STEREO, int kRegEdges>
 __global__ __launch_bounds__(256) void k_pose_opt(const ProblemDev* __restrict__ problems)
 {
     __shared__ double s_acc[28][kAccRow];       // per-thread partials of H (21), b (6), chi2 (1), transposed
@@ -526,6 +527,16 @@ struct pose_solver {
 
 namespace {
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+inline void pose_launch(bool stereo, bool many_edges, int n, hipStream_t st, const poseopt::ProblemDev* p)
+{
+    if (stereo) {
+        if (many_edges) hipLaunchKernelGGL((poseopt::k_pose_opt<true, 4>), dim3(n), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((poseopt::k_pose_opt<true, 2>), dim3(n), dim3(256), 0, st, p);
+    } else {
+        if (many_edges) hipLaunchKernelGGL((poseopt::k_pose_opt<false, 4>), dim3(n), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((poseopt::k_pose_opt<false, 2>), dim3(n), dim3(256), 0, st, p);
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -631,8 +642,9 @@ int pose_optimize_batch(pose_solver* s, const PoseProblem* problems, int n_probl
     }
     POSE_HIP(hipMemcpyAsync(base, s->h_blob, up_bytes, hipMemcpyHostToDevice, s->stream));
     POSE_HIP(hipEventRecord(s->ev0, s->stream));
-    if (any_stereo) hipLaunchKernelGGL(poseopt::k_pose_opt<true>, dim3(n_problems), dim3(256), 0, s->stream, (const poseopt::ProblemDev*)base);
-    else hipLaunchKernelGGL(poseopt::k_pose_opt<false>, dim3(n_problems), dim3(256), 0, s->stream, (const poseopt::ProblemDev*)base);
+    int n_max = 0;
+    for (int i = 0; i < n_problems; i++) n_max = std::max(n_max, problems[i].n);
+    pose_launch(any_stereo, n_max > 512, n_problems, s->stream, (const poseopt::ProblemDev*)base);
     POSE_HIP(hipGetLastError());
     POSE_HIP(hipEventRecord(s->ev1, s->stream));
     POSE_HIP(hipMemcpyAsync(s->h_blob + res_off, base + res_off, down_end - res_off, hipMemcpyDeviceToHost, s->stream));
@@ -683,8 +695,7 @@ int pose_optimize_batch_device(pose_solver* s, const PoseDeviceFrames* f, int ba
     A.problems = (poseopt::ProblemDev*)(s->d_dev + prob_off);
     A.results = (PoseResult*)(s->d_dev + res_off);
     hipLaunchKernelGGL(poseopt::k_pose_gather, dim3(batch), dim3(256), 0, st, A);
-    if (f->d_u_right) hipLaunchKernelGGL(poseopt::k_pose_opt<true>, dim3(batch), dim3(256), 0, st, (const poseopt::ProblemDev*)A.problems);
-    else hipLaunchKernelGGL(poseopt::k_pose_opt<false>, dim3(batch), dim3(256), 0, st, (const poseopt::ProblemDev*)A.problems);
+    pose_launch(f->d_u_right != nullptr, f->cap > 512, batch, st, (const poseopt::ProblemDev*)A.problems);
     hipLaunchKernelGGL(poseopt::k_pose_scatter, dim3(batch), dim3(256), 0, st, (const poseopt::ProblemDev*)A.problems, (const uint8_t*)s->d_dev, A.slot_bytes, A.o_idx,
                        f->cap, d_pose_out, d_inliers, d_outlier, d_results);
     POSE_HIP(hipGetLastError());
