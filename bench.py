@@ -318,9 +318,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
-                from collect_pmc import kernel_sources_sha
+                from collect_pmc import stamp_matches
                 tj = json.load(open(tpath))
-                if tj.get("_kernel_sources_sha") == kernel_sources_sha(ROOT):
+                if stamp_matches(tj.get("_kernel_sources_sha"), "k_" + dom, ROOT):
                     traffic = tj.get(dom)
                     traffic_from = "profiles/pmc_traffic.json"
                 else:
@@ -335,9 +335,9 @@ def main():
         vpath = os.path.join(ROOT, "profiles", "valu_issue.json")
         if os.path.exists(vpath):
             try:
-                from collect_pmc import kernel_sources_sha
+                from collect_pmc import stamp_matches
                 vj = json.load(open(vpath))
-                if vj.get("_kernel_sources_sha") == kernel_sources_sha(ROOT) and ("k_" + dom) in vj:
+                if stamp_matches(vj.get("_kernel_sources_sha"), "k_" + dom, ROOT) and ("k_" + dom) in vj:
                     vfrac = vj["k_" + dom]["valu"] / vj["_simds"] * vj["_ns_per_wave_instruction_and_simd"] * 1e-6 / acc[dom]
                     bound = "valu_issue" if vfrac > 0.5 else "hbm"
             except Exception:

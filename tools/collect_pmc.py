@@ -31,16 +31,27 @@ def per_kernel(dirname, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-def kernel_sources_sha(root=ROOT):
-    """sha256 over the extractor / matcher kernel sources: the stamp that ties a counter pass to the kernels it measured
-    (bench.py prints `traffic: null` when the stamp of profiles/pmc_traffic.json is not the running sources')"""
+def kernel_sources_sha(root=ROOT, group="orbx"):
+    """sha256 over one group of kernel sources (`orbx`: the extractor's kernels, `orbm`: the matcher's): the stamp that ties a counter
+    pass to the kernels it measured (bench.py prints `traffic: null` when the stamp of profiles/pmc_traffic.json is not the running
+    sources').  Per group, so that an edit of the matcher does not void the extractor's counters and vice versa."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(root, "orb_slam3-1_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.startswith(("orbx_", "orbm_")) and name.endswith((".hip", ".inc", ".h")):
+        if name.startswith(group + "_") and name.endswith((".hip", ".inc", ".h")):
             h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def kernel_sources_stamp(root=ROOT):
+    return {g: kernel_sources_sha(root, g) for g in ("orbx", "orbm")}
+
+
+def stamp_matches(stamp, kernel, root=ROOT):
+    """is a profile stamped `stamp` valid for `kernel` (k_bow* lives in orbm_*, every other kernel of the step in orbx_*)?"""
+    g = "orbm" if kernel.replace("k_", "").startswith("bow") else "orbx"
+    return isinstance(stamp, dict) and stamp.get(g) == kernel_sources_sha(root, g)
 
 
 def main():
@@ -55,7 +66,7 @@ def main():
     out = {"_note": "HBM bytes per launch (B=%d frames); raw counters in KiB" % batch,
            "_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --no-cpu --no-lba` (tools/gpu_round.sh)",
            "_calibration": {"fetch_factor": cal_f, "write_factor": cal_w}, "_raw_kib": {},
-           "_kernel_sources_sha": kernel_sources_sha()}
+           "_kernel_sources_sha": kernel_sources_stamp()}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue

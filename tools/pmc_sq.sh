@@ -37,9 +37,9 @@ if f2:
             k, v["SQ_INSTS_LDS"] / n, v["SQ_INSTS_SALU"] / n, v["SQ_INSTS_VMEM"] / n, v["SQ_INSTS_SMEM"] / n, v["SQ_LDS_BANK_CONFLICT"] / n, v["SQ_LDS_IDX_ACTIVE"] / n))
 # profiles/valu_issue.json: wave-instructions per STEP of every kernel, stamped with the kernel sources they were counted on
 # (bench.py turns them into roofline.valu_issue_frac with the per-instruction issue cost of tools/probes/valu_rates.hip)
-from collect_pmc import kernel_sources_sha
+from collect_pmc import kernel_sources_stamp
 steps = max(cnt.get("orbx::k_orient_desc", 1), 1)
-out = {"_note": "SQ_INSTS_VALU / SQ_INSTS_LDS wave-instructions per bench step (B=256 frames), tools/pmc_sq.sh", "_kernel_sources_sha": kernel_sources_sha(),
+out = {"_note": "SQ_INSTS_VALU / SQ_INSTS_LDS wave-instructions per bench step (B=256 frames), tools/pmc_sq.sh", "_kernel_sources_sha": kernel_sources_stamp(),
        "_ns_per_wave_instruction_and_simd": 1.80, "_ns_from": "profiles/r03_a_valu_rates.txt / r03_a_fast_mix.txt: v_perm / v_pk_* / v_min3 / v_max3 class and the stage-1 mix at 4-8 waves per SIMD",
        "_simds": 1024}
 for k, v in acc.items():
