@@ -30,3 +30,16 @@ def test_gba_rccl_demo_builds_and_runs(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "gba rccl demo OK" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_tracking_chain_demo_builds_and_runs(tmp_path):
+    """examples/tracking_chain_demo.cpp: TrackWithMotionModel's device work from plain C++ with the HIP runtime -- extraction of the
+    current frames, SearchByProjection(CurrentFrame, LastFrame) and PoseOptimization enqueued back to back on one stream on
+    device-resident arrays; self-checks: matches found, the pose returns to the truth"""
+    exe = tmp_path / "tracking_chain_demo"
+    libdir = os.path.join(ROOT, "orb_slam3-1_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "tracking_chain_demo.cpp"), "-L", libdir, "-lorbslam3_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], stderr=subprocess.DEVNULL)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "tracking chain demo OK" in r.stdout, r.stdout + r.stderr[-2000:]

@@ -8,13 +8,16 @@ mkdir -p $OUT
 timeout -k 10 420 python -m pytest tests -m gpu -x -q < /dev/null > $OUT/pytest_gpu.log 2>&1; rc=$?
 tail -3 $OUT/pytest_gpu.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pytest timed out: stopping"; exit 1; fi
-timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
-cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_prof.json 2> $OUT/bench_prof.err || { echo "rocprof stats failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu --no-lba > /dev/null 2> $OUT/pmc_fetch.err || { echo "pmc fetch failed"; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu --no-lba > /dev/null 2> $OUT/pmc_write.err || { echo "pmc write failed"; exit 1; }
 python tools/collect_pmc.py $OUT/pmc_fetch $OUT/pmc_write 256 > $OUT/pmc_traffic.log && cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+# SQ counters of every kernel of a step (+ LDS / memory instruction counts) -> profiles/valu_issue.json (bench.py: roofline.valu_issue_frac)
+bash tools/pmc_sq.sh $TAG/sq > $OUT/sq_counters.log 2>&1 || echo "sq counter pass failed"
+# the bench line LAST of the three: roofline.traffic / valu_issue_frac come from the counter passes above (stamped with these kernel sources)
+timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
+cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
 cp $(ls $OUT/prof/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 # the same command with the serial schedule (ORBX_SERIAL=1: one launch per stage on one stream): per-kernel averages that can be
 # compared with the HIP-event stage times of the bench line (in the production schedule FAST and the octree are several
@@ -29,8 +32,6 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/l
 timeout -k 10 200 python tools/latency_b1.py > $OUT/latency_b1.log 2>&1 || echo "latency_b1 failed"
 timeout -k 10 200 python tools/pi_latency.py > $OUT/pi_latency.log 2>&1 || echo "pi_latency failed"
 bash tools/pmc_lba.sh $TAG/lba_pmc > $OUT/lba_pmc.log 2>&1 || echo "lba mfma counter pass failed"
-# SQ counters of every kernel of a step (+ LDS / memory instruction counts) -> profiles/valu_issue.json (bench.py: roofline.valu_issue_frac)
-bash tools/pmc_sq.sh $TAG/sq > $OUT/sq_counters.log 2>&1 || echo "sq counter pass failed"
 # the probes behind the issue-cost figures
 (/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/valu_rates.hip -o /tmp/valu_rates && timeout -k 10 120 /tmp/valu_rates > $OUT/valu_rates.txt 2>&1) || echo "valu_rates probe failed"
 (/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/fast_mix.hip -o /tmp/fast_mix && timeout -k 10 120 /tmp/fast_mix > $OUT/fast_mix.txt 2>&1) || echo "fast_mix probe failed"
