@@ -123,7 +123,7 @@ int orbx_debug_set_fast_corner_cap(orbx_extractor* h, int cap);
  * stream for batches >= 64 frames), so that a missing cross-stream dependency on those levels shows up as wrong results. */
 int orbx_debug_set_tail_delay(orbx_extractor* h, int microseconds);
 /* Test hook: the schedule the LAST extract call used -- bits 0-1 octree instantiation (0 node pool in HBM, 1 keys + nodes in
- * LDS, 2 keys in the L2-resident scratch), 4 two octree launches, 8 level-0 octree started early, 16 level 0 read in place,
+ * LDS, 2 keys in the L2-resident scratch, 3 per level and frame: keys in LDS when the level's candidates fit), 4 two octree launches, 8 level-0 octree started early, 16 level 0 read in place,
  * 32 resize tail on the side stream, 64 the whole resize chain on the side stream beside FAST on level 0. */
 int orbx_debug_last_schedule(orbx_extractor* h);
 

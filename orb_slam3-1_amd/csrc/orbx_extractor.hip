@@ -112,6 +112,8 @@ struct orbx_extractor {
     bool oct_nodes_hbm = false;          // the octree's node pool does not fit LDS: it lives in d_oct_nodes
     size_t oct_node_stride = 0;
     size_t oct_small_lds = 0;
+    int oct_dyn_keys = 0;                // k_octree_dyn (batches up to oct_dyn_max_batch frames whose levels' worst-case key buffers do not fit LDS): keys that do
+    size_t oct_dyn_lds = 0;
     bool oct_keys_forced = false;
 
     DevBuf<LevelDesc> d_levels;
@@ -159,6 +161,10 @@ struct orbx_extractor {
     int split_parts = 1;                 // ORBX_SPLIT (measurement knob, see enqueue)
     bool serial_schedule = false;        // ORBX_SERIAL=1: every kernel of a batch on the launch stream, one launch per stage (per-kernel profiles)
     int resize_tail_first = 4;           // first pyramid level of the fused resize tail (ORBX_RESIZE_TAIL; 0: a launch per level)
+    bool oct_dyn_off = false;            // ORBX_OCT_DYN=0: small batches keep the scratch instantiation (measurement / tests)
+    int oct_dyn_max_batch = 64;          // largest batch that takes k_octree_dyn (ORBX_OCT_DYN_MAXB; measured: one frame 0.163 -> 0.136 ms,
+                                         // 64 frames 0.412 -> 0.352 ms per call, 256 frames 0.99 -> 1.12 ms: the LDS is the blur's there)
+    int oct_dyn_keys_beside = 6144;      // LDS keys per workgroup when the blur runs beside the octree (batches of 32 frames and more)
     bool resize_beside = true;           // the whole resize chain on the side stream beside FAST on level 0 (ORBX_RESIZE_BESIDE=0: in front of it)
     std::vector<hipStream_t> aux_streams;
     hipEvent_t ev_parts_fork = nullptr;
@@ -410,9 +416,18 @@ int orbx_extractor::setup_geometry(int w, int h)
     if (oct_nodes_hbm || node_bytes + 8 * (size_t)oct_small_keys > 150 * 1024) oct_small_keys = 0;      // does not fit: small batches use the scratch path too
     oct_small_lds = node_bytes + 8 * (size_t)oct_small_keys + 16;
     if (oct_lds_keys > 0 && oct_lds_keys < max_cand_cap) oct_lds_keys = 0;              // the LDS instantiation needs room for a whole level
+    // third configuration, for the smallest batches when a level's worst case does NOT fit: as many keys as LDS holds beside the
+    // node pool; the kernel takes the LDS body for every (level, frame) whose actual candidates fit (k_octree_dyn)
+    oct_dyn_keys = 0; oct_dyn_lds = 0;
+    if (!oct_nodes_hbm && oct_small_keys == 0 && node_bytes + 8 * 2048 <= 150 * 1024) {
+        oct_dyn_keys = (int)std::min<size_t>((size_t)max_cand_cap, (150 * 1024 - node_bytes) / 8);
+        if (const char* envd = getenv("ORBX_OCT_DYN_KEYS")) oct_dyn_keys = std::max(64, std::min(oct_dyn_keys, atoi(envd)));     // (tests: force the fallback body)
+        oct_dyn_lds = node_bytes + 8 * (size_t)oct_dyn_keys + 16;
+    }
     if (!oct_nodes_hbm) {
         ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)node_bytes + 64));
         ORBX_HIP(hipFuncSetAttribute((const void*)k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(oct_lds, oct_small_lds)));
+        if (oct_dyn_keys > 0) ORBX_HIP(hipFuncSetAttribute((const void*)k_octree_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oct_dyn_lds));
     } else {
         oct_lds = 64; oct_small_lds = 64;
     }
@@ -527,14 +542,18 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         // whole stage: keep the ping-pong key buffers in LDS (no L2 round trip per DivideNode).  With many frames the larger
         // LDS footprint would halve the resident waves, and the L2-resident scratch wins.
         const bool small_batch = !oct_keys_forced && oct_small_keys > 0 && (long long)B * nlevels <= 512;
-        const size_t o_lds = small_batch ? oct_small_lds : oct_lds;
-        const int o_keys = small_batch ? oct_small_keys : oct_lds_keys;
+        // (one wave per level and frame: below 32 frames every workgroup has a CU of its own, LDS is free)
+        const bool dyn_keys = !oct_keys_forced && !small_batch && oct_dyn_keys > 0 && B <= oct_dyn_max_batch && !oct_dyn_off;
+        // (with the blur beside the octree -- 32 frames and more -- a workgroup takes a smaller share of its CU's LDS)
+        const int dyn_k = (blur_s && B >= 32) ? std::min(oct_dyn_keys, oct_dyn_keys_beside) : oct_dyn_keys;
+        const size_t o_lds = small_batch ? oct_small_lds : (dyn_keys ? oct_dyn_lds - 8 * (size_t)(oct_dyn_keys - dyn_k) : oct_lds);
+        const int o_keys = small_batch ? oct_small_keys : (dyn_keys ? dyn_k : oct_lds_keys);
         uint32_t* sel = d_sel.p + (size_t)f0 * sel_frame_entries;
         int* sel_cnt = d_sel_count.p + (size_t)f0 * nlevels;
         int* kp_dst = d_kp_dst.p + (size_t)f0 * sel_frame_entries;
-        auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>);
+        auto oct_kernel = oct_nodes_hbm ? k_octree<false, false> : (dyn_keys ? k_octree_dyn : (o_keys > 0 ? k_octree<true, true> : k_octree<false, true>));
         // (keys in LDS: one launch, the buffers are sized for the largest level anyway)
-        const bool two_launches = !oct_nodes_hbm && o_keys == 0 && oct_split > 0 && oct_stream && blur_s;
+        const bool two_launches = !oct_nodes_hbm && (o_keys == 0 || dyn_keys) && oct_split > 0 && oct_stream && blur_s;
         const int lv_lo = two_launches ? oct_split : nlevels;
         auto launch_octree = [&](hipStream_t qs, int lv0, int lv1, size_t lds, int pool, int keys) {
             if (lv1 > lv0)
@@ -619,7 +638,10 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         }
         if (two_launches) {
             ORBX_HIP(hipStreamWaitEvent(oct_stream, ev_fork, 0));
-            launch_octree(oct_stream, oct_split, nlevels, oct_lds_hi, oct_pool_hi, 0);
+            {   // (dynamic LDS keys: the upper levels hold fewer candidates -- half the allotment)
+                const int k_hi = dyn_keys ? std::max(64, o_keys / 2) : 0;
+                launch_octree(oct_stream, oct_split, nlevels, oct_lds_hi + 8 * (size_t)k_hi, oct_pool_hi, k_hi);
+            }
             ORBX_HIP(hipEventRecord(ev_oct_join, oct_stream));
         }
         launch_octree(os, oct0_early ? 1 : 0, lv_lo, o_lds, oct_pool, o_keys);
@@ -627,7 +649,7 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             if (tail_beside) ORBX_HIP(hipStreamWaitEvent(s, ev_tail, 0));
             launch_blur(s);
         }
-        last_octree_variant = (oct_nodes_hbm ? 0 : (o_keys > 0 ? 1 : 2)) | (two_launches ? 4 : 0) | (oct0_early ? 8 : 0) | (in_place ? 16 : 0) | (tail_beside ? 32 : 0) | (chain_beside ? 64 : 0);
+        last_octree_variant = (oct_nodes_hbm ? 0 : (dyn_keys ? 3 : (o_keys > 0 ? 1 : 2))) | (two_launches ? 4 : 0) | (oct0_early ? 8 : 0) | (in_place ? 16 : 0) | (tail_beside ? 32 : 0) | (chain_beside ? 64 : 0);
         if (two_launches) ORBX_HIP(hipStreamWaitEvent(os, ev_oct_join, 0));
         ORBX_LAUNCHED("k_octree / k_blur");
         if (marks) mark();
@@ -739,6 +761,9 @@ int orbx_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
     if (const char* env = getenv("ORBX_SPLIT")) e->split_parts = std::max(1, std::min(atoi(env), 4));
     if (const char* env = getenv("ORBX_RESIZE_TAIL")) e->resize_tail_first = atoi(env);
     if (const char* env = getenv("ORBX_RESIZE_BESIDE")) e->resize_beside = atoi(env) != 0;
+    if (const char* env = getenv("ORBX_OCT_DYN")) e->oct_dyn_off = atoi(env) == 0;
+    if (const char* env = getenv("ORBX_OCT_DYN_MAXB")) e->oct_dyn_max_batch = atoi(env);
+    if (const char* env = getenv("ORBX_OCT_DYN_KEYS_BESIDE")) e->oct_dyn_keys_beside = std::max(64, atoi(env));
     for (int i = 0; i + 1 < e->split_parts; i++) {
         hipStream_t s = nullptr; hipEvent_t ev = nullptr;
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {

@@ -184,19 +184,18 @@ struct OctLds {
 // child its node slot, its place in the push log and in the next to-expand vector in exactly the order the sequential loop
 // would have produced, and -- in the sorted phase -- the lane at which the running size reaches N (the reference breaks
 // there: later lanes do not divide).
-template <bool LDS_KEYS, bool LDS_NODES = true>
-__global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
-                                               const uint32_t* __restrict__ cand, size_t cand_frame_stride,
-                                               const int* __restrict__ cell_count, int n_cells,
-                                               uint32_t* __restrict__ scratch, size_t scratch_frame_stride,
-                                               int pool, int lds_keys_cap,
-                                               uint32_t* __restrict__ sel, int sel_frame_stride,
-                                               int* __restrict__ sel_count, int n_levels, int* __restrict__ status,
-                                               uint8_t* __restrict__ node_scratch, size_t node_stride, int level_first)
+template <bool LDS_KEYS, bool LDS_NODES>
+__device__ __forceinline__ void octree_body(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
+                                            const uint32_t* __restrict__ cand, size_t cand_frame_stride,
+                                            const int* __restrict__ cell_count, int n_cells,
+                                            uint32_t* __restrict__ scratch, size_t scratch_frame_stride,
+                                            int pool, int lds_keys_cap,
+                                            uint32_t* __restrict__ sel, int sel_frame_stride,
+                                            int* __restrict__ sel_count, int n_levels, int* __restrict__ status,
+                                            uint8_t* __restrict__ node_scratch, size_t node_stride, int level_first,
+                                            uint8_t* __restrict__ smem, int* __restrict__ s_sort_stack)
 {
     static_assert(LDS_NODES || !LDS_KEYS, "a pool too large for LDS leaves no room for LDS keys");
-    extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_sort_stack[3 * kIntrosortStack];       // the sort's explicit stack (in LDS, not in private scratch)
     const int level = level_first + blockIdx.x, frame = blockIdx.y;     // (a launch covers the levels level_first ..: see enqueue())
     const int lane = threadIdx.x;
     const LevelDesc L = levels[level];
@@ -574,6 +573,52 @@ __global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ lev
         d_oct_prof[8] = (unsigned long long)total; d_oct_prof[9] = (unsigned long long)n_div;
     }
 #endif
+}
+
+template <bool LDS_KEYS, bool LDS_NODES = true>
+__global__ __launch_bounds__(64) void k_octree(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
+                                               const uint32_t* __restrict__ cand, size_t cand_frame_stride,
+                                               const int* __restrict__ cell_count, int n_cells,
+                                               uint32_t* __restrict__ scratch, size_t scratch_frame_stride,
+                                               int pool, int lds_keys_cap,
+                                               uint32_t* __restrict__ sel, int sel_frame_stride,
+                                               int* __restrict__ sel_count, int n_levels, int* __restrict__ status,
+                                               uint8_t* __restrict__ node_scratch, size_t node_stride, int level_first)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_sort_stack[3 * kIntrosortStack];       // the sort's explicit stack (in LDS, not in private scratch)
+    octree_body<LDS_KEYS, LDS_NODES>(levels, cells, cand, cand_frame_stride, cell_count, n_cells, scratch, scratch_frame_stride, pool, lds_keys_cap,
+                                     sel, sel_frame_stride, sel_count, n_levels, status, node_scratch, node_stride, level_first, smem, s_sort_stack);
+}
+
+// Small batches (a single frame: the reference's own use) are bound by the latency of the level-0 wave, and a level's key buffers are
+// SIZED for the 3x3-NMS worst case (a quarter of the pixels: 614 KB for two buffers at 640 x 480) while a real level holds a few
+// thousand candidates.  This kernel counts the level's candidates first and takes the keys-in-LDS body when they fit the LDS it was
+// given (no L2 round trip per key-partition step: 0.079 -> 0.062 ms for the octree of one 320 x 200 frame), the scratch body otherwise;
+// both bodies are compiled in, each with its own static addressing (no flat accesses).
+__global__ __launch_bounds__(64) void k_octree_dyn(const LevelDesc* __restrict__ levels, const CellDesc* __restrict__ cells,
+                                                   const uint32_t* __restrict__ cand, size_t cand_frame_stride,
+                                                   const int* __restrict__ cell_count, int n_cells,
+                                                   uint32_t* __restrict__ scratch, size_t scratch_frame_stride,
+                                                   int pool, int lds_keys_cap,
+                                                   uint32_t* __restrict__ sel, int sel_frame_stride,
+                                                   int* __restrict__ sel_count, int n_levels, int* __restrict__ status,
+                                                   uint8_t* __restrict__ node_scratch, size_t node_stride, int level_first)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_sort_stack[3 * kIntrosortStack];
+    const LevelDesc L = levels[level_first + blockIdx.x];
+    const int* cc = cell_count + (size_t)blockIdx.y * n_cells + L.cell_begin;
+    int total = 0;
+    for (int ci = threadIdx.x; ci < L.cell_count; ci += 64) total += cc[ci];
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    total = __builtin_amdgcn_readfirstlane(total);
+    if (total <= lds_keys_cap)
+        octree_body<true, true>(levels, cells, cand, cand_frame_stride, cell_count, n_cells, scratch, scratch_frame_stride, pool, lds_keys_cap,
+                                sel, sel_frame_stride, sel_count, n_levels, status, node_scratch, node_stride, level_first, smem, s_sort_stack);
+    else
+        octree_body<false, true>(levels, cells, cand, cand_frame_stride, cell_count, n_cells, scratch, scratch_frame_stride, pool, lds_keys_cap,
+                                 sel, sel_frame_stride, sel_count, n_levels, status, node_scratch, node_stride, level_first, smem, s_sort_stack);
 }
 
 // test hook: wave_sort_nodes on one array (orbx_debug_wave_sort)

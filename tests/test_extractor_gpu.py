@@ -258,9 +258,9 @@ def test_large_batch_other_geometries(pkg, oracle, synth, args, size):
 def test_large_batch_device_api_in_place(pkg, oracle, synth, monkeypatch, B, tail_delay, mode):
     """the bench's path: device-resident frames read in place (level 0 = the caller's buffer, copied into the pyramid by the
     blur), the large-batch schedule, results left on the device -- twice on the same handle, against the oracle frame by frame.
-    Both batch sizes must take the bench's schedule -- octree keys in the L2-resident scratch (at 640x480 a level's candidates
-    never fit LDS: the keys-in-LDS instantiation only exists for images below about 65 k pixels, see
-    test_small_images_keep_octree_keys_in_lds), two octree launches, level 0's octree started early, resize tail on the side
+    Both batch sizes must take the large-batch schedule -- octree keys in the L2-resident scratch above 64 frames (the bench's 256), per
+    level in LDS when they fit up to 64 (k_octree_dyn; the worst case of a 640x480 level never fits, see
+    test_small_batches_of_large_images_pick_lds_keys_per_level), two octree launches, level 0's octree started early, resize tail on the side
     stream -- and the test asserts that it ran (orbx_debug_last_schedule).  With `tail_delay` a spin kernel holds the resize tail back by 0.4 ms -- far longer than FAST on the lower
     levels -- and the upper pyramid levels are poisoned first, so a blur that does not wait for the tail reads the poison and the
     upper levels' descriptors differ (the ordering bug of round 2, src/ORBextractor.cc:1132-1138 reads every level).
@@ -291,7 +291,8 @@ def test_large_batch_device_api_in_place(pkg, oracle, synth, monkeypatch, B, tai
             torch.cuda.synchronize()
             sched = ex.debug_last_schedule()
             assert sched & 16, "level 0 was not read in place"
-            assert sched == (2 | 4 | 8 | 16 | 32 | (64 if mode & 1 else 0)), "not the expected schedule: %d" % sched
+            # (octree: up to 64 frames k_octree_dyn -- keys in LDS per level when they fit --, above that the scratch instantiation)
+            assert sched == ((3 if B <= 64 else 2) | 4 | 8 | 16 | 32 | (64 if mode & 1 else 0)), "not the expected schedule: %d" % sched
             assert int(d_st.abs().sum().item()) == 0
             n = d_n.cpu().numpy(); mono = d_mono.cpu().numpy()
             kps = d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap); desc = d_desc.cpu().numpy().reshape(B, cap, 32)
@@ -319,5 +320,30 @@ def test_small_images_keep_octree_keys_in_lds(pkg, oracle, synth):
             assert mono[b] == r0 and n[b] == len(k0)
             _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
             np.testing.assert_array_equal(desc[b, :n[b]], d0)
+    finally:
+        ex.close()
+
+
+@pytest.mark.parametrize("env,expect", [({}, 3), ({"ORBX_OCT_DYN_KEYS": "1500"}, 3), ({"ORBX_OCT_DYN": "0"}, 2)])
+def test_small_batches_of_large_images_pick_lds_keys_per_level(pkg, oracle, synth, monkeypatch, env, expect):
+    """640 x 480: a level's worst-case key buffers do not fit LDS, its actual candidates do.  Batches of up to 64 frames run k_octree_dyn,
+    which counts the level's candidates and takes the keys-in-LDS body when they fit, the scratch body otherwise -- with the LDS
+    allotment capped at 1500 keys the lower levels (more candidates) take the scratch body and the upper ones the LDS body inside ONE
+    launch; ORBX_OCT_DYN=0 keeps the scratch instantiation.  Same bits as the oracle in every case, B = 1 and B = 5."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    imgs = np.stack([synth.make_frame(940 + i) for i in range(5)])
+    oex = oracle.extractor(1000, 1.2, 8, 20, 7)
+    ref = [oex.extract(im, (0, 1000)) for im in imgs]
+    ex = pkg.Extractor(1000, 1.2, 8, 20, 7)
+    try:
+        for B in (1, 5):
+            mono, n, kps, desc = ex.extract_batch(imgs[:B])
+            assert ex.debug_last_schedule() & 3 == expect
+            for b in range(B):
+                r0, k0, d0 = ref[b]
+                assert mono[b] == r0 and n[b] == len(k0)
+                _assert_kps_equal(kps[b, :n[b]], k0, "frame %d" % b)
+                np.testing.assert_array_equal(desc[b, :n[b]], d0)
     finally:
         ex.close()
