@@ -1692,6 +1692,8 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     }
     std::memset(&s->d, 0, sizeof(s->d));
     lba::Dev& d = s->d;
+    static const bool build_timing = std::getenv("ORBX_LBA_TIMING") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
     d.nPoses = p->n_poses; d.nL = p->n_points; d.nE = p->n_edges;
     std::vector<int> pose_col(p->n_poses, -1), col_pose;
     for (int i = 0; i < p->n_poses; i++) if (!p->pose_fixed[i]) { pose_col[i] = (int)col_pose.size(); col_pose.push_back(i); }
@@ -1704,6 +1706,7 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     for (int c = 0; c < d.nP; c++) p_off[c + 1] += p_off[c];
     std::vector<int> l_edge(std::max(d.nE, 1)), p_edge(std::max(p_off[d.nP], 1)), lc(l_off.begin(), l_off.end() - 1), pc(p_off.begin(), p_off.end() - 1);
     for (int e = 0; e < d.nE; e++) { l_edge[lc[p->edge_point[e]]++] = e; const int c = pose_col[p->edge_pose[e]]; if (c >= 0) p_edge[pc[c]++] = e; }
+    const auto tb1 = std::chrono::steady_clock::now();
     // pair list per block (i <= j): one gather of (column, edge) per landmark, then count and fill
     std::vector<int> ecol(std::max(d.nE, 1));
     for (int e = 0; e < d.nE; e++) ecol[e] = pose_col[p->edge_pose[e]];
@@ -1744,6 +1747,7 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
                 pairs[bc[brow[j]]++] = pr;
             }
         }
+    const auto tb2 = std::chrono::steady_clock::now();
     std::vector<double> poses(7 * (size_t)p->n_poses);
     for (int i = 0; i < p->n_poses; i++) {
         for (int k = 0; k < 4; k++) poses[7 * i + k] = p->pose_q[4 * i + k];
@@ -1772,17 +1776,26 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
     s->nblk = (d.n + lba::NB - 1) / lba::NB;
     LBA_TRY(s->dalloc(&s->Linv, (size_t)std::max(s->nblk, 1) * lba::NB * lba::NB));
     if (s->nblk <= lba::kFusedMaxBlocks) LBA_TRY(s->dalloc(&s->Lp, ((size_t)d.n + 1) * (size_t)std::max(d.n, 1)));
-    LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
-    LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_flow, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
+    // (the dynamic-LDS limits of the factorisation / substitution kernels: once per device and process, not per window)
+    static std::atomic<unsigned long long> attr_done{0};
+    const bool set_attr = !((attr_done.load() >> device) & 1ull);
+    if (set_attr) {
+        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
+        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_flow, hipFuncAttributeMaxDynamicSharedMemorySize, lba::kStepLds));
+    }
     LBA_TRY(s->dalloc(&s->flow, (size_t)lba::kFlowFlags));
     LBA_HIP(hipMemsetAsync(s->flow, 0, lba::kFlowFlags * sizeof(unsigned), s->stream));
     {
         const size_t solve_lds = ((size_t)d.n + 64 + 16 * 64 + lba::NB * (lba::NB + 1)) * sizeof(double);
         if (solve_lds > 160 * 1024) LBA_TRY(fail(ORBX_ERR_CAPACITY, "%d reduced unknowns exceed the substitution kernel's LDS", d.n));
-        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
-        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
-        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
-        LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(solve_lds, (size_t)65536)));
+        if (set_attr) {     // (a limit, not an allocation: the largest system the check above lets through)
+            const int lim = 160 * 1024;
+            LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            LBA_HIP(hipFuncSetAttribute((const void*)lba::k_chol_solve_update<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            attr_done.fetch_or(1ull << device);
+        }
     }
     LBA_TRY(s->dalloc(&s->Ldiag, (size_t)lba::NB * lba::NB));
     LBA_TRY(s->dalloc(&s->d_chi2, (size_t)d.nE)); LBA_TRY(s->dalloc(&s->d_depth, (size_t)d.nE));
@@ -1806,6 +1819,10 @@ static int shard_create_impl(int device, const LbaProblem* p, lba_shard** out, l
         LBA_HIP(hipMemcpyAsync(s->poses0, s->poses[0], 7 * (size_t)p->n_poses * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         if (d.nL > 0) LBA_HIP(hipMemcpyAsync(s->pts0, s->pts[0], 3 * (size_t)d.nL * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
         LBA_HIP(hipStreamSynchronize(s->stream));
+    }
+    if (build_timing) {
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[lba structure] CSR %.0f us, pair lists %.0f us, staging + enqueue %.0f us\n", us(tb0, tb1), us(tb1, tb2), us(tb2, std::chrono::steady_clock::now()));
     }
     *out = s;
     return ORBX_OK;

@@ -163,7 +163,7 @@ struct orbx_extractor {
     int resize_tail_first = 4;           // first pyramid level of the fused resize tail (ORBX_RESIZE_TAIL; 0: a launch per level)
     bool oct_dyn_off = false;            // ORBX_OCT_DYN=0: small batches keep the scratch instantiation (measurement / tests)
     int oct_dyn_max_batch = 64;          // largest batch that takes k_octree_dyn (ORBX_OCT_DYN_MAXB; measured: one frame 0.163 -> 0.136 ms,
-                                         // 64 frames 0.412 -> 0.352 ms per call, 256 frames 0.99 -> 1.12 ms: the LDS is the blur's there)
+                                         // 64 frames 0.412 -> 0.352 ms per call, 256 frames 0.99 -> 1.12 ms: the LDS is the blur's there; LDS keys for the early level-0 launch alone: 0.993 -> 1.008)
     int oct_dyn_keys_beside = 6144;      // LDS keys per workgroup when the blur runs beside the octree (batches of 32 frames and more)
     bool resize_beside = true;           // the whole resize chain on the side stream beside FAST on level 0 (ORBX_RESIZE_BESIDE=0: in front of it)
     std::vector<hipStream_t> aux_streams;
