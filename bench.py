@@ -627,6 +627,50 @@ def main():
                                    "pose_translation_error_after": float(t_pose[:, 4:].abs().max().item()),
                                    "workload": "%d streams: current frame = last frame moved by 3 px; search and PoseOptimization run on the extractor's device "
                                                "arrays (edges gathered on the device from the search's assignment), nothing visits the host" % B}
+                # ---- TrackLocalMap's device work (src/Tracking.cc:3082-3115: SearchLocalPoints -> SearchByProjection(Frame, vpMapPoints, th),
+                # "the dominant matcher call in steady-state tracking", SURVEY M4 -> PoseOptimization): the current frames as the chain above
+                # left them; the local map of a stream = the last frame's points plus as many again seen nearby (the same descriptors at
+                # positions a few pixels off: the ratio test and the best-level bookkeeping have work to do), 2 x cap points per frame ----
+                try:
+                    pcap_l = 2 * cap
+                    jit = torch.Generator(device=dev); jit.manual_seed(9)
+                    off_u = torch.rand(B, cap, device=dev, generator=jit) * 8.0 - 4.0
+                    m_u = torch.cat([lk[:, :, 0] + 3.0, lk[:, :, 0] + 3.0 + off_u], 1).contiguous()
+                    m_v = torch.cat([lk[:, :, 1], lk[:, :, 1] + off_u.flip(1)], 1).contiguous()
+                    m_lvl = torch.cat([l_oct, l_oct], 1).contiguous()
+                    m_desc = torch.cat([l_desc.view(B, cap, 32), l_desc.view(B, cap, 32)], 1).contiguous()
+                    m_valid = torch.cat([l_valid, l_valid], 1).contiguous()
+                    # the points of frame b are packed [0, l_n[b]) + [cap, cap + l_n[b]): mark the gap invalid instead of compacting
+                    m_n = torch.full_like(l_n, pcap_l)
+                    m_cos = torch.full((B, pcap_l), 0.999, dtype=torch.float32, device=dev)
+                    m_depth = torch.cat([l_z, l_z], 1).contiguous()
+                    m_bad = torch.zeros(B, pcap_l, dtype=torch.uint8, device=dev); m_obs = torch.ones(B, pcap_l, dtype=torch.uint8, device=dev)
+                    m_xyz = torch.cat([l_mp, l_mp], 1).contiguous()
+                    ml = pkg.Matcher(0.8, True, device=local_rank)
+                    lm_assign = torch.empty(B * cap, dtype=torch.int32, device=dev); lm_occ = torch.empty(B * cap, dtype=torch.uint8, device=dev)
+                    lm_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+
+                    def lstep():
+                        lm_assign.fill_(-1); lm_occ.zero_()
+                        ml.SearchByProjection_batch_device((d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap),
+                                                           (m_valid.data_ptr(), m_u.data_ptr(), m_v.data_ptr(), m_lvl.data_ptr(), 0, m_desc.data_ptr(), m_n.data_ptr(), pcap_l, m_obs.data_ptr()),
+                                                           (m_cos.data_ptr(), m_depth.data_ptr(), m_bad.data_ptr()), B, 1.0, lm_assign.data_ptr(), lm_occ.data_ptr(), lm_nm.data_ptr(),
+                                                           stream, bounds=(0.0, 0.0, float(Ww), float(Hh)), scale_factors=sfac)
+                        ps_t.optimize_batch_device(B, cap, d_kps.data_ptr(), d_n.data_ptr(), lm_assign.data_ptr(), m_xyz.data_ptr(), pcap_l, t_pose0.data_ptr(), isig_t, cam_t,
+                                                   t_pose.data_ptr(), t_inl.data_ptr(), t_outl.data_ptr(), stream)
+                    lstep(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        lstep()
+                    torch.cuda.synchronize()
+                    dtl = (time.perf_counter() - t0) / 10
+                    out["track_local_map"] = {"metric": "TrackLocalMap device work frames/s (SearchByProjection(Frame, MapPoints) + PoseOptimization, device-resident)",
+                                              "value": B / dtl, "unit": "frames/s", "ms_per_batch": 1e3 * dtl, "local_map_points_per_frame": int(pcap_l),
+                                              "matches_per_frame": float(lm_nm.float().mean().item()), "pose_inliers_per_frame": float(t_inl.float().mean().item()),
+                                              "workload": "%d streams x %d local map points (th 1, nnratio 0.8, ratio and level tests), then PoseOptimization on the matches" % (B, pcap_l)}
+                    ml.close()
+                except Exception as e:  # noqa: BLE001
+                    out["track_local_map"] = {"error": repr(e)}
                 mtrk.close(); ps_t.close()
             except Exception as e:  # noqa: BLE001
                 out["tracking"] = {"error": repr(e)}
