@@ -124,6 +124,9 @@ struct orbx_extractor {
     std::vector<DevBuf<int> > d_qsx0, d_yofs;
     std::vector<DevBuf<uint4> > d_qsel, d_qalpha;
     std::vector<DevBuf<short> > d_ibeta;
+    std::vector<DevBuf<int> > d_xofs;            // per-column tables of the levels that take k_resize_generic (resize_generic[l])
+    std::vector<DevBuf<short> > d_ialpha;
+    std::vector<uint8_t> resize_generic;
 
     // per-batch scratch
     int batch_cap = 0, last_batch = 0;
@@ -201,7 +204,10 @@ static void build_tables(orbx_extractor* e)
     }
     e->nfeat[nl - 1] = std::max(e->nfeatures - sum, 0);
     e->max_kp = 0;
-    for (int l = 0; l < nl; l++) e->max_kp += e->nfeat[l] + 3;
+    // per level the octree returns at most N + 3 nodes -- except that its FIRST pass divides every root without looking at N
+    // (src/ORBextractor.cc:606-672: the size test follows the pass), so a level with a tiny budget still returns up to 4 nodes per root
+    // (nIni = round(width / height) roots; 8 roots = images up to 8.5 : 1 are covered by this bound, wider ones report ORBX_ERR_CAPACITY)
+    for (int l = 0; l < nl; l++) e->max_kp += std::max(e->nfeat[l] + 3, 32);
     gauss_taps_q8(7, 2.0, e->taps);
 }
 
@@ -214,7 +220,9 @@ int orbx_extractor::setup_geometry(int w, int h)
     strips.clear();
     size_t off = 0;
     int cand_off = 0, sel_off = 0, max_tw = 0, max_th = 0, max_nfeat = 0;
+    std::vector<int> node_need(nlevels, 0);
     d_qsx0.resize(nlevels); d_yofs.resize(nlevels); d_qsel.resize(nlevels); d_qalpha.resize(nlevels); d_ibeta.resize(nlevels);
+    d_xofs.resize(nlevels); d_ialpha.resize(nlevels); resize_generic.assign(nlevels, 0);
     for (int l = 0; l < nlevels; l++) {
         LevelDesc& L = levels[l];
         L.w = (int)std::nearbyintf((float)w * inv_scale[l]);      // ComputePyramid :1175
@@ -228,9 +236,14 @@ int orbx_extractor::setup_geometry(int w, int h)
         L.nfeat = nfeat[l];
         L.scale = scale[l];
         L.patch_size = (int)(kPatch * scale[l]);
-        L.sel_off = sel_off; L.sel_cap = nfeat[l] + 3;
+        {   // (see build_tables: N + 3, or what the first pass makes of the roots when the level's budget is tiny)
+            const int bw = (L.w - kEdge + 3) - (kEdge - 3), bh = (L.h - kEdge + 3) - (kEdge - 3);
+            const int n_ini = bh > 0 ? (int)std::roundf((float)bw / (float)bh) : 0;
+            L.sel_off = sel_off; L.sel_cap = std::max({nfeat[l] + 3, 32, 4 * std::max(n_ini, 0)});
+            node_need[l] = std::max(nfeat[l], 4 * std::max(n_ini, 0));         // nodes the level's list can hold at once (+ 16 below)
+        }
         sel_off += (L.sel_cap + 1) & ~1;        // even: the two key points of a wave of k_orient_desc share a level
-        max_nfeat = std::max(max_nfeat, nfeat[l]);
+        max_nfeat = std::max(max_nfeat, node_need[l]);
         // FAST cells (ComputeKeyPointsOctTree :787-822)
         L.cell_begin = (int)cells.size();
         L.cand_off = cand_off;
@@ -328,7 +341,8 @@ int orbx_extractor::setup_geometry(int w, int h)
                     const int dx = 4 * q + k;
                     if (dx < L.w) {
                         const int o = xofs[dx] - qsx0[q];
-                        if (o < 0 || o > 6) return fail(ORBX_ERR_INTERNAL, "resize table: source offset %d outside the 8-byte window", o);
+                        if (o < 0) return fail(ORBX_ERR_INTERNAL, "resize table: source offset %d", o);
+                        if (o > 6) { resize_generic[l] = 1; se[k] = 0x0C0C0C0Cu; al[k] = 0u; continue; }     // scale factors >= 2: the level takes k_resize_generic
                         se[k] = (uint32_t)o | 0x0C000C00u | ((uint32_t)(o + 1) << 16);
                         al[k] = (uint32_t)(uint16_t)ia[2 * dx] | ((uint32_t)(uint16_t)ia[2 * dx + 1] << 16);
                     } else { se[k] = 0x0C0C0C0Cu; al[k] = 0u; }
@@ -337,6 +351,7 @@ int orbx_extractor::setup_geometry(int w, int h)
                 qal[q] = make_uint4(al[0], al[1], al[2], al[3]);
             }
             int r;
+            if (resize_generic[l] && ((r = d_xofs[l].upload(xofs)) || (r = d_ialpha[l].upload(ia)))) return r;
             if ((r = d_qsx0[l].upload(qsx0)) || (r = d_yofs[l].upload(yofs)) || (r = d_qsel[l].upload(qsel)) || (r = d_qalpha[l].upload(qal)) ||
                 (r = d_ibeta[l].upload(ib))) return r;
         }
@@ -396,7 +411,7 @@ int orbx_extractor::setup_geometry(int w, int h)
         size_t best = (size_t)nlevels * node_bytes;
         for (int sp = 1; sp < nlevels; sp++) {
             int hi = 0;
-            for (int l = sp; l < nlevels; l++) hi = std::max(hi, levels[l].nfeat);
+            for (int l = sp; l < nlevels; l++) hi = std::max(hi, node_need[l]);
             const size_t cost = (size_t)sp * node_bytes + (size_t)(nlevels - sp) * pool_bytes(hi + 16);
             if (cost < best) { best = cost; oct_split = sp; oct_pool_hi = hi + 16; oct_lds_hi = pool_bytes(hi + 16) + 16; }
         }
@@ -517,7 +532,8 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
         if (marks) mark();
         // (resize_tail_first: the levels from there on are one launch, a workgroup per frame -- k_resize_tail)
         // (only with many frames: a single workgroup walks a small batch's levels slower than one wide launch per level does)
-        const int l_tail = (nB >= 64 && resize_tail_first >= 2 && resize_tail_first < nlevels) ? resize_tail_first : nlevels;
+        int l_tail = (nB >= 64 && resize_tail_first >= 2 && resize_tail_first < nlevels) ? resize_tail_first : nlevels;
+        for (int l = l_tail; l < nlevels; l++) if (resize_generic[l]) l_tail = nlevels;      // (the fused tail only knows the table-driven kernel)
         // FAST on level 0 needs no resized level, so the whole resize chain (levels 1 .. and the tail) runs on the side stream beside
         // it; `s` waits for the levels before the tail (ev_resize) in front of FAST on levels 1 ..  (1.005 -> 0.991 ms per 256-frame
         // step.  Measured and dropped in the same session: the blur on a stream of its own right behind the resize chain, beside
@@ -533,6 +549,10 @@ int orbx_extractor::enqueue(const uint8_t* d_imgs, bool level0_ready, int batch,
             SrcImage src;
             src.base = pyr + P.off; src.frame_stride = pyr_frame_bytes; src.stride = P.stride; src.w = P.w; src.h = P.h;
             if (l == 1 && in_place) src = lvl0;
+            if (resize_generic[l])
+                hipLaunchKernelGGL(k_resize_generic, dim3((D.w + 255) / 256, D.h, nB), dim3(256), 0, rs, src, pyr, pyr_frame_bytes, D,
+                                   d_xofs[l].p, d_ialpha[l].p, d_yofs[l].p, d_ibeta[l].p);
+            else
             hipLaunchKernelGGL(k_resize, g, dim3(256), 0, rs, src, pyr, pyr_frame_bytes, D,
                                d_qsx0[l].p, d_qsel[l].p, d_qalpha[l].p, d_yofs[l].p, d_ibeta[l].p);
             ORBX_LAUNCHED("k_resize");
@@ -798,6 +818,8 @@ void orbx_destroy(orbx_extractor* e)
     for (auto& b : e->d_qsel) b.release();
     for (auto& b : e->d_qalpha) b.release();
     for (auto& b : e->d_ibeta) b.release();
+    for (auto& b : e->d_xofs) b.release();
+    for (auto& b : e->d_ialpha) b.release();
     e->d_pyr.release(); e->d_blur.release(); e->d_cand.release(); e->d_scratch.release(); e->d_sel.release(); e->d_oct_nodes.release();
     e->d_cell_count.release(); e->d_sel_count.release(); e->d_kp_dst.release(); e->d_lvl_kps.release();
     e->d_kps.release(); e->d_desc.release(); e->d_n.release(); e->d_mono.release(); e->d_status.release();

@@ -126,6 +126,28 @@ __global__ __launch_bounds__(256) void k_resize(SrcImage src, uint8_t* __restric
                 __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
+// Fallback for levels whose four-column source span exceeds the 8-byte window of the table-driven kernel above (scale factors of
+// 2 and more: 3 x scale_x >= 6 source columns between the first and the last pixel of a quad, plus its right neighbour): one thread
+// per output pixel straight from the per-column / per-row tables of cv::resize -- the same fixed-point arithmetic, no window.
+__global__ __launch_bounds__(256) void k_resize_generic(SrcImage src, uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc dst,
+                                                        const int* __restrict__ xofs, const short* __restrict__ ialpha,
+                                                        const int* __restrict__ yofs, const short* __restrict__ ibeta)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y, frame = blockIdx.z;
+    if (dx >= dst.w) return;
+    const uint8_t* S = src.base + (size_t)frame * src.frame_stride;
+    const int sx = xofs[dx], sy = yofs[dy];
+    const uint32_t a0 = (uint16_t)ialpha[2 * dx], a1 = (uint16_t)ialpha[2 * dx + 1];
+    const uint32_t b0 = (uint16_t)ibeta[2 * dy], b1 = (uint16_t)ibeta[2 * dy + 1];
+    const int sy0 = min(max(sy, 0), src.h - 1), sy1 = min(max(sy + 1, 0), src.h - 1);
+    const int sx1 = min(sx + 1, src.w - 1);                     // (its coefficient is 0 where sx is the last column)
+    const uint8_t* r0 = S + (size_t)sy0 * src.stride;
+    const uint8_t* r1 = S + (size_t)sy1 * src.stride;
+    const uint32_t h0 = r0[sx] * a0 + r0[sx1] * a1, h1 = r1[sx] * a0 + r1[sx1] * a1;
+    const uint32_t val = ((__umul24(b0, h0 >> 4) >> 16) + (__umul24(b1, h1 >> 4) >> 16) + 2u) >> 2;
+    pyr[(size_t)frame * frame_stride + dst.off + (size_t)dy * dst.stride + dx] = (uint8_t)min(val, 255u);
+}
+
 // The upper pyramid levels are small and each depends on the one below: as launches of their own they are a chain of short,
 // launch-latency-bound kernels.  Here ONE 1024-thread workgroup per frame walks the levels l_first .. n_levels-1 in turn (four
 // tiles at a time, a workgroup barrier between levels: the level just written is read back by the same CU).

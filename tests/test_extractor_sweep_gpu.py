@@ -56,3 +56,52 @@ def test_feature_budgets_beyond_the_lds_node_pool(pkg, oracle, synth, args, size
     for f in k0.dtype.names:
         np.testing.assert_array_equal(k1[f], k0[f], err_msg=f)
     np.testing.assert_array_equal(d1, d0)
+
+
+@pytest.mark.parametrize("w,h,scale,nlev,B", [(333, 250, 2.0, 3, 1), (397, 301, 2.0, 2, 5), (640, 481, 2.5, 3, 70), (333, 250, 2.0, 3, 66)])
+def test_scale_factors_of_two_and_more(pkg, oracle, synth, w, h, scale, nlev, B):
+    """found by tools/soak_extractor.py: with scaleFactor >= 2 a quad of destination columns can span more than the 8 source bytes the
+    table-driven resize kernel holds (e.g. 333 -> 166 columns: offsets 0, 2, 4, 7); such levels take k_resize_generic (and keep out of
+    the fused resize tail of large batches) -- same bits as the oracle, small and large batches"""
+    imgs = np.stack([synth.make_frame(700 + k, w, h) for k in range(min(B, 3))])
+    oex = oracle.extractor(500, scale, nlev, 20, 7)
+    ref = [oex.extract(im, (0, 1000)) for im in imgs]
+    ex = pkg.Extractor(500, scale, nlev, 20, 7)
+    try:
+        mono, n, kps, desc = ex.extract_batch(np.ascontiguousarray(imgs[np.arange(B) % len(imgs)]))
+    finally:
+        ex.close()
+    for b in range(B):
+        r0, k0, d0 = ref[b % len(imgs)]
+        assert mono[b] == r0 and n[b] == len(k0) > 20
+        for f in k0.dtype.names:
+            np.testing.assert_array_equal(kps[b, :n[b]][f], k0[f], err_msg=f)
+        np.testing.assert_array_equal(desc[b, :n[b]], d0)
+
+
+@pytest.mark.parametrize("nfeat,nlev,size,B,expect_over", [(100, 10, (756, 481), 1, True), (100, 10, (756, 481), 65, True), (40, 8, (640, 480), 3, False),
+                                                             (12, 4, (900, 200), 2, True)])
+def test_tiny_per_level_budgets_return_what_the_first_pass_makes(pkg, oracle, synth, nfeat, nlev, size, B, expect_over):
+    """found by tools/soak_extractor.py: DistributeOctTree's first pass divides every root without looking at N (the size test follows
+    the pass, src/ORBextractor.cc:606-672), so a level whose budget is below 4 x nIni still returns up to 4 nodes per root -- more than
+    N + 3 (e.g. 100 features over 10 levels: the last level's budget is 1, it returns 8 key points).  The per-level selection capacity
+    and orbx_max_keypoints cover that (it used to trip the device-side guard: ORBX_ERR_INTERNAL)."""
+    w, h = size
+    imgs = np.stack([synth.make_frame(720 + k, w, h) for k in range(min(B, 3))])
+    oex = oracle.extractor(nfeat, 1.2, nlev, 20, 7)
+    ref = [oex.extract(im, (0, 0)) for im in imgs]
+    ex = pkg.Extractor(nfeat, 1.2, nlev, 20, 7)
+    try:
+        per_level = ex.features_per_level()
+        mono, n, kps, desc = ex.extract_batch(np.ascontiguousarray(imgs[np.arange(B) % len(imgs)]), (0, 0))
+    finally:
+        ex.close()
+    over = False
+    for b in range(B):
+        r0, k0, d0 = ref[b % len(imgs)]
+        assert mono[b] == r0 and n[b] == len(k0)
+        for f in k0.dtype.names:
+            np.testing.assert_array_equal(kps[b, :n[b]][f], k0[f], err_msg=f)
+        np.testing.assert_array_equal(desc[b, :n[b]], d0)
+        over = over or bool((np.bincount(k0["octave"], minlength=nlev) > per_level + 3).any())
+    assert over == expect_over, "the case should%s exercise a level that returns more than N + 3 key points" % ("" if expect_over else " not")

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Soak of the extractor (GPU box; not part of the test suite): random configurations (image size, feature budget, pyramid depth, scale
+factor, FAST thresholds, lapping area) x random BATCH sizes (1 .. 80: single-stream path, k_octree_dyn with and without side streams,
+the large-batch schedule with the resize chain beside FAST) through the host-batch and the device-resident entry points, every frame
+against the CPU oracle bit for bit (key points, order, angles, responses, descriptors).  usage: soak_extractor.py [n_configs]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from oracle_api import Oracle  # noqa: E402
+
+pkg = importlib.import_module("orb_slam3-1_amd")
+synth = importlib.import_module("orb_slam3-1_amd.synth")
+o = Oracle()
+dev = torch.device("cuda", 0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rs = np.random.RandomState(777)
+bad = 0; frames = 0; scheds = {}
+t0 = time.time()
+for ci in range(N):
+    w = int(rs.randint(96, 900)) & ~3 if rs.uniform() < 0.5 else int(rs.randint(96, 900))
+    h = int(rs.randint(80, 620))
+    nfeat = int(rs.choice([100, 300, 700, 1000, 1000, 1500, 2500]))
+    scale = float(rs.choice([1.1, 1.2, 1.2, 1.25, 1.33, 1.5, 2.0]))
+    nlev = int(rs.randint(1, 11))
+    while nlev > 1 and min(w, h) / scale ** (nlev - 1) < 60:
+        nlev -= 1
+    ini = int(rs.choice([20, 20, 12, 30])); mn = min(int(rs.choice([7, 7, 5, 10])), ini)
+    lap = (0, 1000) if rs.uniform() < 0.5 else ((0, 0) if rs.uniform() < 0.5 else (int(w * 0.3), int(w * 0.6)))
+    B = int(rs.choice([1, 1, 2, 5, 16, 31, 32, 40, 64, 65, 80]))
+    n_img = min(B, 6)
+    imgs = np.stack([synth.make_frame(3000 + 10 * ci + k, w, h) for k in range(n_img)])
+    oex = o.extractor(nfeat, scale, nlev, ini, mn)
+    ref = [oex.extract(im, lap) for im in imgs]
+    batch = np.ascontiguousarray(imgs[np.arange(B) % n_img])
+    ex = pkg.Extractor(nfeat, scale, nlev, ini, mn)
+    try:
+        cap = ex.max_keypoints
+        results = []
+        mono, n, kps, desc = ex.extract_batch(batch, lap)
+        results.append(("host", mono, n, kps, desc, ex.debug_last_schedule()))
+        if w % 16 == 0 or rs.uniform() < 0.5:           # device entry: in place when the rows are 16-byte aligned, copied otherwise
+            d_img = torch.from_numpy(batch.copy()).to(dev)
+            d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev); d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+            d_n = torch.zeros(B, dtype=torch.int32, device=dev); d_mono = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+            for _ in range(2):
+                ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), d_mono.data_ptr(), d_st.data_ptr(),
+                                        lap, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert int(d_st.abs().sum().item()) == 0
+            results.append(("device", d_mono.cpu().numpy(), d_n.cpu().numpy(), d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap),
+                            d_desc.cpu().numpy().reshape(B, cap, 32), ex.debug_last_schedule()))
+        for name, mono, n, kps, desc, sched in results:
+            scheds[sched] = scheds.get(sched, 0) + 1
+            for b in range(B):
+                r0, k0, d0 = ref[b % n_img]
+                frames += 1
+                ok = mono[b] == r0 and n[b] == len(k0) and all(np.array_equal(kps[b, :n[b]][f], k0[f]) for f in k0.dtype.names) and np.array_equal(desc[b, :n[b]], d0)
+                if not ok:
+                    bad += 1
+                    print("MISMATCH config %d (%dx%d nfeat %d scale %.2f levels %d th %d/%d lap %s B %d) entry %s frame %d schedule %d" %
+                          (ci, w, h, nfeat, scale, nlev, ini, mn, lap, B, name, b, sched), flush=True)
+    except pkg.OrbxError as e_:
+        bad += 1
+        print("ERROR config %d (%dx%d nfeat %d scale %.2f levels %d th %d/%d lap %s B %d): %s" % (ci, w, h, nfeat, scale, nlev, ini, mn, lap, B, e_), flush=True)
+    finally:
+        ex.close()
+    if ci % 10 == 9:
+        print("... %d configurations, %d frames, %d mismatches, %.0f s" % (ci + 1, frames, bad, time.time() - t0), flush=True)
+print("extractor soak: %d configurations, %d frames compared with the oracle bit for bit, %d mismatches; schedules seen (bits of orbx_debug_last_schedule: count) %s" %
+      (N, frames, bad, dict(sorted(scheds.items()))))
+sys.exit(1 if bad else 0)
