@@ -68,7 +68,9 @@ def test_lba_sweep(pkg, oracle, synth, seed):
     # weakly constrained windows (3 observations per point) amplify the rounding of the reduced solve: 5.4e-9 relative is the
     # largest difference measured (seed 4, gpurun_out/lba_fused.log, round 1).  FROZEN at 1e-7: three decades inside the 1e-4
     # contract of BASELINE.json and twenty times the observed worst case -- a change that needs more is a regression.
-    np.testing.assert_allclose(s1["chi2_final"], s0["chi2_final"], rtol=1e-7)
+    # (found by tools/soak_sweeps.py, seed 1034: an exactly solvable window ends at chi2 ~ 1e-23, pure rounding noise on both sides --
+    # the absolute floor is 1e-18 of where the window started)
+    np.testing.assert_allclose(s1["chi2_final"], s0["chi2_final"], rtol=1e-7, atol=1e-18 * max(s0["chi2_initial"], 1.0))
     d0, d1 = r0["points"] - w["points"], r1["points"] - w["points"]
     assert np.abs(d0 - d1).max() <= 1e-4 * max(np.abs(d0).max(), 1e-12), kw
     np.testing.assert_array_equal(r1["depth_positive"], r0["depth_positive"])
