@@ -51,11 +51,17 @@ public:
     int extract(const uint8_t* img, int w, int h, int stride, int lap0, int lap1,
                 std::vector<OrbxKeyPoint>& kps, std::vector<uint8_t>& desc)
     {
-        const int cap = orbx_max_keypoints(h_);
-        kps.resize(cap);
-        desc.resize((size_t)cap * 32);
-        int n = 0, mono = -1;
-        const int rc = orbx_extract(h_, img, w, h, stride, lap0, lap1, kps.data(), desc.data(), cap, &n, &mono);
+        int cap = orbx_max_keypoints(h_);
+        int n = 0, mono = -1, rc = ORBX_OK;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            kps.resize(cap);
+            desc.resize((size_t)cap * 32);
+            rc = orbx_extract(h_, img, w, h, stride, lap0, lap1, kps.data(), desc.data(), cap, &n, &mono);
+            // orbx_max_keypoints() bounds what an image of up to 8.5 : 1 returns; a wider one with a tiny per-level budget returns 4 key
+            // points per octree root (src/ORBextractor.cc:606-672) and reports the count it needs: once more with that
+            if (rc != ORBX_ERR_CAPACITY || n <= cap) break;
+            cap = n;
+        }
         if (rc == ORBX_ERR_EMPTY) { kps.clear(); desc.clear(); return -1; }
         check(rc);
         kps.resize(n);

@@ -296,8 +296,12 @@ class OracleExtractor:
         img = np.ascontiguousarray(img)
         h, w = img.shape
         cap = self.nfeatures + 4 * self.nlevels + 64
-        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
-        r = self.L.orb_oracle_extract(self.h, _p(img), w, h, w, lap[0], lap[1], _p(kps), _p(desc), cap, C.byref(n))
+        for _ in range(2):      # (-2: more key points than `cap` -- tiny budgets on wide images return 4 nodes per root and level; n = the count needed)
+            kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+            r = self.L.orb_oracle_extract(self.h, _p(img), w, h, w, lap[0], lap[1], _p(kps), _p(desc), cap, C.byref(n))
+            if r != -2:
+                break
+            cap = n.value
         return r, kps[:n.value].copy(), desc[:n.value].copy()
 
     def level_size(self, l):

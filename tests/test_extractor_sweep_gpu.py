@@ -105,3 +105,31 @@ def test_tiny_per_level_budgets_return_what_the_first_pass_makes(pkg, oracle, sy
         np.testing.assert_array_equal(desc[b, :n[b]], d0)
         over = over or bool((np.bincount(k0["octave"], minlength=nlev) > per_level + 3).any())
     assert over == expect_over, "the case should%s exercise a level that returns more than N + 3 key points" % ("" if expect_over else " not")
+
+
+def test_capacity_contract_on_very_wide_images(pkg, oracle, synth):
+    """found by tools/soak_extractor.py (extreme): orbx_max_keypoints() covers images of up to 8.5 : 1; a 700 x 98 image has 10 octree roots,
+    and with a budget of ONE feature the level still returns 4 key points per root.  The contract for that: ORBX_ERR_CAPACITY with *n = the
+    count needed, and the same call with that capacity gives the oracle's key points (the shim's Extractor::extract does exactly this)."""
+    import ctypes as C
+    img = synth.make_frame(3000 + 10 * 134, 700, 98)
+    r0, k0, d0 = oracle.extractor(1, 1.1, 1, 20, 20).extract(img, (0, 1000))
+    ex = pkg.Extractor(1, 1.1, 1, 20, 20)
+    try:
+        cap = ex.max_keypoints
+        assert len(k0) > cap
+        n, mono = C.c_int(), C.c_int()
+        kps = np.zeros(cap, pkg.KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        rc = pkg.lib.orbx_extract(ex._h, img.ctypes.data_as(C.c_void_p), 700, 98, 700, 0, 1000, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                                  C.byref(n), C.byref(mono))
+        assert rc == -2 and n.value == len(k0)          # ORBX_ERR_CAPACITY, the count needed
+        cap = n.value
+        kps = np.zeros(cap, pkg.KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        rc = pkg.lib.orbx_extract(ex._h, img.ctypes.data_as(C.c_void_p), 700, 98, 700, 0, 1000, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                                  C.byref(n), C.byref(mono))
+        assert rc == 0 and mono.value == r0 and n.value == len(k0)
+        for f in k0.dtype.names:
+            np.testing.assert_array_equal(kps[f], k0[f], err_msg=f)
+        np.testing.assert_array_equal(desc, d0)
+    finally:
+        ex.close()

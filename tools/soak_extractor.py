@@ -2,7 +2,7 @@
 """Soak of the extractor (GPU box; not part of the test suite): random configurations (image size, feature budget, pyramid depth, scale
 factor, FAST thresholds, lapping area) x random BATCH sizes (1 .. 80: single-stream path, k_octree_dyn with and without side streams,
 the large-batch schedule with the resize chain beside FAST) through the host-batch and the device-resident entry points, every frame
-against the CPU oracle bit for bit (key points, order, angles, responses, descriptors).  usage: soak_extractor.py [n_configs]"""
+against the CPU oracle bit for bit (key points, order, angles, responses, descriptors).  usage: soak_extractor.py [n_configs] [extreme]"""
 import importlib
 import os
 import sys
@@ -20,20 +20,30 @@ synth = importlib.import_module("orb_slam3-1_amd.synth")
 o = Oracle()
 dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rs = np.random.RandomState(777)
+EXTREME = len(sys.argv) > 2 and sys.argv[2] == "extreme"
+rs = np.random.RandomState(778 if EXTREME else 777)
 bad = 0; frames = 0; scheds = {}
 t0 = time.time()
 for ci in range(N):
-    w = int(rs.randint(96, 900)) & ~3 if rs.uniform() < 0.5 else int(rs.randint(96, 900))
-    h = int(rs.randint(80, 620))
-    nfeat = int(rs.choice([100, 300, 700, 1000, 1000, 1500, 2500]))
-    scale = float(rs.choice([1.1, 1.2, 1.2, 1.25, 1.33, 1.5, 2.0]))
-    nlev = int(rs.randint(1, 11))
-    while nlev > 1 and min(w, h) / scale ** (nlev - 1) < 60:
-        nlev -= 1
-    ini = int(rs.choice([20, 20, 12, 30])); mn = min(int(rs.choice([7, 7, 5, 10])), ini)
+    if EXTREME:         # far corners of the parameter space: tiny and large images, extreme aspect ratios, 1 .. 12 000 features, scale 1.05 .. 3
+        w = int(rs.choice([rs.randint(60, 200), rs.randint(200, 1400)])); h = int(rs.choice([rs.randint(60, 200), rs.randint(200, 1000)]))
+        nfeat = int(rs.choice([1, 10, 50, 100, 1000, 5000, 12000]))
+        scale = float(rs.choice([1.05, 1.1, 1.2, 1.5, 2.0, 2.5, 3.0]))
+        nlev = int(rs.randint(1, 13))
+        while nlev > 1 and min(w, h) / scale ** (nlev - 1) < 45:
+            nlev -= 1
+        ini = int(rs.choice([5, 20, 40, 80])); mn = min(int(rs.choice([2, 7, 20, 80])), ini)
+    else:
+        w = int(rs.randint(96, 900)) & ~3 if rs.uniform() < 0.5 else int(rs.randint(96, 900))
+        h = int(rs.randint(80, 620))
+        nfeat = int(rs.choice([100, 300, 700, 1000, 1000, 1500, 2500]))
+        scale = float(rs.choice([1.1, 1.2, 1.2, 1.25, 1.33, 1.5, 2.0]))
+        nlev = int(rs.randint(1, 11))
+        while nlev > 1 and min(w, h) / scale ** (nlev - 1) < 60:
+            nlev -= 1
+        ini = int(rs.choice([20, 20, 12, 30])); mn = min(int(rs.choice([7, 7, 5, 10])), ini)
     lap = (0, 1000) if rs.uniform() < 0.5 else ((0, 0) if rs.uniform() < 0.5 else (int(w * 0.3), int(w * 0.6)))
-    B = int(rs.choice([1, 1, 2, 5, 16, 31, 32, 40, 64, 65, 80]))
+    B = int(rs.choice([1, 1, 2, 5, 16, 31, 32, 40, 64, 65, 80])) if w * h < 700000 else int(rs.choice([1, 2, 33, 65]))
     n_img = min(B, 6)
     imgs = np.stack([synth.make_frame(3000 + 10 * ci + k, w, h) for k in range(n_img)])
     oex = o.extractor(nfeat, scale, nlev, ini, mn)
