@@ -55,12 +55,17 @@ for ci in range(N):
         results = []
         mono, n, kps, desc = ex.extract_batch(batch, lap)
         results.append(("host", mono, n, kps, desc, ex.debug_last_schedule()))
-        if w % 16 == 0 or rs.uniform() < 0.5:           # device entry: in place when the rows are 16-byte aligned, copied otherwise
-            d_img = torch.from_numpy(batch.copy()).to(dev)
+        if True:                                        # device entry: read in place when base, row stride and frame stride are 16-byte multiples, copied otherwise
+            # the caller's frames with a random row stride, frame stride and base offset (in place only when all three are 16-byte multiples)
+            rstride = w + int(rs.choice([0, 0, 1, 3, 16, 64])); fstride = rstride * h + int(rs.choice([0, 0, 5, 16, 256])); boff = int(rs.choice([0, 0, 1, 4, 16]))
+            host_buf = rs.randint(0, 256, boff + B * fstride + 64).astype(np.uint8)         # (noise in the padding: it must never be read as pixels)
+            view = np.lib.stride_tricks.as_strided(host_buf[boff:], shape=(B, h, w), strides=(fstride, rstride, 1))
+            view[...] = batch
+            d_buf = torch.from_numpy(host_buf).to(dev)
             d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev); d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
             d_n = torch.zeros(B, dtype=torch.int32, device=dev); d_mono = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
             for _ in range(2):
-                ex.extract_batch_device(d_img.data_ptr(), B, w, h, w, w * h, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), d_mono.data_ptr(), d_st.data_ptr(),
+                ex.extract_batch_device(d_buf.data_ptr() + boff, B, w, h, rstride, fstride, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), d_mono.data_ptr(), d_st.data_ptr(),
                                         lap, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert int(d_st.abs().sum().item()) == 0
