@@ -2,7 +2,7 @@
 """Soak of the extractor (GPU box; not part of the test suite): random configurations (image size, feature budget, pyramid depth, scale
 factor, FAST thresholds, lapping area) x random BATCH sizes (1 .. 80: single-stream path, k_octree_dyn with and without side streams,
 the large-batch schedule with the resize chain beside FAST) through the host-batch and the device-resident entry points, every frame
-against the CPU oracle bit for bit (key points, order, angles, responses, descriptors).  usage: soak_extractor.py [n_configs] [extreme]"""
+against the CPU oracle bit for bit (key points, order, angles, responses, descriptors).  usage: soak_extractor.py [n_configs] [extreme] [images]"""
 import importlib
 import os
 import sys
@@ -20,8 +20,9 @@ synth = importlib.import_module("orb_slam3-1_amd.synth")
 o = Oracle()
 dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-EXTREME = len(sys.argv) > 2 and sys.argv[2] == "extreme"
-rs = np.random.RandomState(778 if EXTREME else 777)
+EXTREME = len(sys.argv) > 2 and "extreme" in sys.argv[2:]
+IMAGES = len(sys.argv) > 2 and "images" in sys.argv[2:]       # adversarial image statistics (noise, flat, checkerboards, stripes, salt and pepper, blocks, ramps)
+rs = np.random.RandomState((778 if EXTREME else 777) + (10 if IMAGES else 0))
 bad = 0; frames = 0; scheds = {}
 t0 = time.time()
 for ci in range(N):
@@ -45,7 +46,31 @@ for ci in range(N):
     lap = (0, 1000) if rs.uniform() < 0.5 else ((0, 0) if rs.uniform() < 0.5 else (int(w * 0.3), int(w * 0.6)))
     B = int(rs.choice([1, 1, 2, 5, 16, 31, 32, 40, 64, 65, 80])) if w * h < 700000 else int(rs.choice([1, 2, 33, 65]))
     n_img = min(B, 6)
-    imgs = np.stack([synth.make_frame(3000 + 10 * ci + k, w, h) for k in range(n_img)])
+    kind = IMAGES and ["synth", "noise", "zeros", "checker", "stripes", "salt", "blocks", "gradient"][int(rs.randint(0, 8))] or "synth"
+
+    def make(k_):
+        r2 = np.random.RandomState(91000 + 10 * ci + k_)
+        if kind == "noise":         # a corner at almost every pixel: candidate slots, corner lists and the octree at their limits
+            return r2.randint(0, 256, (h, w)).astype(np.uint8)
+        if kind == "zeros":
+            return np.full((h, w), int(r2.randint(0, 256)), np.uint8)
+        if kind == "checker":
+            c = int(r2.choice([1, 2, 3, 8, 31]))
+            yy, xx = np.mgrid[0:h, 0:w]
+            return (((yy // c + xx // c) & 1) * int(r2.randint(40, 256))).astype(np.uint8)
+        if kind == "stripes":
+            c = int(r2.choice([1, 2, 5, 16])); a = np.zeros((h, w), np.uint8); a[:, (np.arange(w) // c) % 2 == 0] = 200
+            return a if r2.randint(0, 2) else np.ascontiguousarray(np.where((np.arange(h)[:, None] // c) % 2 == 0, 200, 0).astype(np.uint8) + np.zeros((1, w), np.uint8))
+        if kind == "salt":
+            a = np.full((h, w), 100, np.uint8); m_ = r2.uniform(size=(h, w)) < float(r2.choice([0.001, 0.02, 0.2])); a[m_] = r2.choice([0, 255], int(m_.sum()))
+            return a
+        if kind == "blocks":
+            b_ = int(r2.choice([4, 8, 16])); blk = r2.randint(0, 256, (h // b_ + 2, w // b_ + 2)).astype(np.uint8)
+            return np.ascontiguousarray(np.kron(blk, np.ones((b_, b_), np.uint8))[:h, :w])
+        if kind == "gradient":
+            return np.ascontiguousarray(((np.arange(w)[None, :] * 255 // max(w - 1, 1)) + np.zeros((h, 1), np.int64)).astype(np.uint8))
+        return synth.make_frame(3000 + 10 * ci + k_, w, h)
+    imgs = np.stack([make(k) for k in range(n_img)])
     oex = o.extractor(nfeat, scale, nlev, ini, mn)
     ref = [oex.extract(im, lap) for im in imgs]
     batch = np.ascontiguousarray(imgs[np.arange(B) % n_img])
@@ -79,11 +104,11 @@ for ci in range(N):
                 ok = mono[b] == r0 and n[b] == len(k0) and all(np.array_equal(kps[b, :n[b]][f], k0[f]) for f in k0.dtype.names) and np.array_equal(desc[b, :n[b]], d0)
                 if not ok:
                     bad += 1
-                    print("MISMATCH config %d (%dx%d nfeat %d scale %.2f levels %d th %d/%d lap %s B %d) entry %s frame %d schedule %d" %
-                          (ci, w, h, nfeat, scale, nlev, ini, mn, lap, B, name, b, sched), flush=True)
+                    print("MISMATCH config %d (%s %dx%d nfeat %d scale %.2f levels %d th %d/%d lap %s B %d) entry %s frame %d schedule %d" %
+                          (ci, kind, w, h, nfeat, scale, nlev, ini, mn, lap, B, name, b, sched), flush=True)
     except pkg.OrbxError as e_:
         bad += 1
-        print("ERROR config %d (%dx%d nfeat %d scale %.2f levels %d th %d/%d lap %s B %d): %s" % (ci, w, h, nfeat, scale, nlev, ini, mn, lap, B, e_), flush=True)
+        print("ERROR config %d (%s %dx%d nfeat %d scale %.2f levels %d th %d/%d lap %s B %d): %s" % (ci, kind, w, h, nfeat, scale, nlev, ini, mn, lap, B, e_), flush=True)
     finally:
         ex.close()
     if ci % 10 == 9:
