@@ -72,8 +72,13 @@ int orbx_extract_batch_device(orbx_extractor* h, const uint8_t* d_imgs, int batc
                               OrbxKeyPoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n, int32_t* d_mono,
                               int32_t* d_status, void* stream);
 
-/* Upper bound on keypoints per frame: sum over levels of (mnFeaturesPerLevel + 3) (octree overshoot). */
+/* Upper bound on keypoints per frame: per level max(mnFeaturesPerLevel + 3, 32).  N + 3 is the octree's overshoot;
+ * its first pass, however, divides every root without looking at N (src/ORBextractor.cc:606-672), so a level with a tiny budget
+ * still returns up to 4 key points per root (nIni = round(width / height) of the level's bordered area).  The bound covers 8 roots;
+ * orbx_max_keypoints_for() gives the bound for one image size (very wide images with tiny budgets need it: otherwise the calls
+ * report ORBX_ERR_CAPACITY with *n = the count needed). */
 int orbx_max_keypoints(const orbx_extractor* h);
+int orbx_max_keypoints_for(const orbx_extractor* h, int width, int height);
 
 /* Getters (include/ORBextractor.h:61-81).  Arrays of nlevels floats; NULL pointers are skipped. */
 int orbx_levels(const orbx_extractor* h);

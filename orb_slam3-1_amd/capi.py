@@ -71,6 +71,7 @@ lib.orbx_extract_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C
 lib.orbx_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 lib.orbx_max_keypoints.argtypes = [C.c_void_p]
+lib.orbx_max_keypoints_for.argtypes = [C.c_void_p, C.c_int, C.c_int]
 lib.orbx_levels.argtypes = [C.c_void_p]
 lib.orbx_scale_factor.argtypes = [C.c_void_p]
 lib.orbx_scale_factor.restype = C.c_float
@@ -170,11 +171,15 @@ class Extractor:
                                 _p(kps), _p(desc), cap, C.byref(n), C.byref(mono)))
         return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
 
+    def max_keypoints_for(self, width, height):
+        """orbx_max_keypoints_for: the key-point bound for one image size (very wide images with tiny per-level budgets)"""
+        return int(lib.orbx_max_keypoints_for(self._h, int(width), int(height)))
+
     def extract_batch(self, images, lapping_area=(0, 1000)):
         """images: uint8 array [B, H, W] (host).  Returns (mono[B], n[B], kps[B,cap], desc[B,cap,32])."""
         imgs = np.ascontiguousarray(images)
         B, h, w = imgs.shape
-        cap = self.max_keypoints
+        cap = max(self.max_keypoints, self.max_keypoints_for(w, h))
         kps = np.zeros((B, cap), KP_DTYPE)
         desc = np.zeros((B, cap, 32), np.uint8)
         n = np.zeros(B, np.int32)

@@ -828,6 +828,21 @@ void orbx_destroy(orbx_extractor* e)
 }
 
 int orbx_max_keypoints(const orbx_extractor* e) { return e ? e->max_kp : 0; }
+
+// the same bound for ONE image geometry: per level max(N + 3, 32, 4 x nIni) with the level's own nIni (the bordered area of the upper
+// levels of a wide image is relatively wider still: the 2 x 16-px border does not shrink with the level)
+int orbx_max_keypoints_for(const orbx_extractor* e, int width, int height)
+{
+    if (!e || width < 1 || height < 1) return 0;
+    int total = 0;
+    for (int l = 0; l < e->nlevels; l++) {
+        const int lw = (int)std::nearbyintf((float)width * e->inv_scale[l]), lh = (int)std::nearbyintf((float)height * e->inv_scale[l]);
+        const int bw = (lw - kEdge + 3) - (kEdge - 3), bh = (lh - kEdge + 3) - (kEdge - 3);
+        const int n_ini = bh > 0 ? (int)std::roundf((float)bw / (float)bh) : 0;
+        total += std::max({e->nfeat[l] + 3, 32, 4 * std::max(n_ini, 0)});
+    }
+    return total;
+}
 int orbx_levels(const orbx_extractor* e) { return e ? e->nlevels : 0; }
 float orbx_scale_factor(const orbx_extractor* e) { return e ? e->scale_factor_f : 0.f; }
 

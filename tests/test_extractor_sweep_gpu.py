@@ -133,3 +133,21 @@ def test_capacity_contract_on_very_wide_images(pkg, oracle, synth):
         np.testing.assert_array_equal(desc, d0)
     finally:
         ex.close()
+
+
+def test_max_keypoints_for_covers_wide_images(pkg, oracle, synth):
+    """orbx_max_keypoints_for(): 888 x 141, 100 features over 4 levels at 1.25 -- the bordered area of the upper levels is 9 : 1, each
+    level returns up to 36 key points, 146 in all against orbx_max_keypoints() = 133 -- sized with it the batch call succeeds"""
+    img = synth.make_frame(5, 888, 141)
+    r0, k0, d0 = oracle.extractor(100, 1.25, 4, 12, 10).extract(img, (0, 1000))
+    ex = pkg.Extractor(100, 1.25, 4, 12, 10)
+    try:
+        assert ex.max_keypoints_for(888, 141) >= len(k0) and ex.max_keypoints_for(640, 480) == ex.max_keypoints
+        mono, n, kps, desc = ex.extract_batch(np.stack([img] * 3))
+    finally:
+        ex.close()
+    for b in range(3):
+        assert mono[b] == r0 and n[b] == len(k0)
+        for f in k0.dtype.names:
+            np.testing.assert_array_equal(kps[b, :n[b]][f], k0[f], err_msg=f)
+        np.testing.assert_array_equal(desc[b, :n[b]], d0)
