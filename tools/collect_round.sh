@@ -20,7 +20,7 @@ cp $(ls $S/libaprof/*/*kernel_stats.csv | head -1) ${P}_inertial_ba_kernel_stats
 cp $(ls $S/lbabatchprof/*/*kernel_stats.csv | head -1) ${P}_lba_batch32_kernel_stats.csv
 cp $(ls $S/projprof/*/*kernel_stats.csv | head -1) ${P}_proj_kernel_stats.csv
 cp $(ls $S/projprof_seq/*/*kernel_stats.csv | head -1) ${P}_proj_sequential_kernel_stats.csv
-cat $S/latency_b1.log $S/pi_latency.log > ${P}_latencies.txt
+cat $S/latency_b1.log $S/pi_latency.log $S/latency_matcher.log 2>/dev/null | grep -v amdgpu.ids > ${P}_latencies.txt
 cp $S/lba_pmc.log ${P}_lba_mfma_counters.txt
 tail -3 $S/pytest_gpu.log > ${P}_pytest_gpu.txt
 ls -la ${P}_*

@@ -31,6 +31,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/l
 # single-call latencies (what Tracking / LocalMapping make): extract for small batches, per-frame inertial optimisation, LocalInertialBA
 timeout -k 10 200 python tools/latency_b1.py > $OUT/latency_b1.log 2>&1 || echo "latency_b1 failed"
 timeout -k 10 200 python tools/pi_latency.py > $OUT/pi_latency.log 2>&1 || echo "pi_latency failed"
+timeout -k 10 200 python tools/latency_matcher.py > $OUT/latency_matcher.log 2>&1 || echo "latency_matcher failed"
 bash tools/pmc_lba.sh $TAG/lba_pmc > $OUT/lba_pmc.log 2>&1 || echo "lba mfma counter pass failed"
 # the probes behind the issue-cost figures
 (/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/valu_rates.hip -o /tmp/valu_rates && timeout -k 10 120 /tmp/valu_rates > $OUT/valu_rates.txt 2>&1) || echo "valu_rates probe failed"
