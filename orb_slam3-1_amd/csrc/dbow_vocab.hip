@@ -111,19 +111,40 @@ __global__ __launch_bounds__(256) void k_vocab_descend(VocabDev V, const uint8_t
 }
 
 // ---- per-frame assembly of BowVector and FeatureVector ----
+// Bitonic sort of n_pow2 64-bit keys in LDS by the 4 waves of the workgroup.  Wave w owns the pairs [w n/8, (w+1) n/8), i.e. the elements
+// of chunk w (n/4 elements): every exchange with a stride below the chunk size stays inside the chunk, whose LDS accesses are the
+// owning wave's own and therefore ordered (a wave-level fence keeps the compiler from reordering them) -- only the three passes whose
+// stride reaches across chunks need a workgroup barrier (it was 55 barriers for 1024 keys).
 __device__ __forceinline__ void bitonic_sort(unsigned long long* s, int n_pow2)
 {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = n_pow2 >> 2, pairs = n_pow2 >> 3;               // elements / pairs per wave (n_pow2 >= 8: a lane may idle)
+    bool need_block = true;                                           // the keys were written by other waves
     for (int k = 2; k <= n_pow2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (n_pow2 >> 1); t += blockDim.x) {
-                const int lo = 2 * t - (t & (j - 1));          // index with bit j clear
-                const int hi = lo + j;
-                const bool up = (lo & k) == 0;
-                const unsigned long long a = s[lo], b = s[hi];
-                if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+            const bool cross = j >= chunk || n_pow2 < 8;
+            if (cross || need_block) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+            need_block = cross;                                       // after a cross-chunk pass the next pass reads other waves' writes
+            if (n_pow2 >= 8) {
+                for (int tw = lane; tw < pairs; tw += 64) {
+                    const int t = wave * pairs + tw;
+                    const int lo = 2 * t - (t & (j - 1));             // index with bit j clear
+                    const int hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const unsigned long long a = s[lo], b = s[hi];
+                    if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+                }
+            } else {
+                for (int t = threadIdx.x; t < (n_pow2 >> 1); t += blockDim.x) {
+                    const int lo = 2 * t - (t & (j - 1)), hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const unsigned long long a = s[lo], b = s[hi];
+                    if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+                }
             }
-            __syncthreads();
         }
+    __syncthreads();
 }
 
 // exclusive prefix sum of one flag per element (n <= 8192) -> ranks; returns the total.  s_cnt: [blockDim.x] ints.
@@ -137,16 +158,15 @@ __device__ __forceinline__ int block_rank(const unsigned long long* s, int n, bo
         const bool head = (s[i] != ~0ull) && (i == 0 || (s[i] >> 32) != (s[i - 1] >> 32));
         c += (by_high32_change ? head : (s[i] != ~0ull)) ? 1 : 0;
     }
-    s_cnt[t] = c;
+    // scan inside the wave by shuffles, the four wave totals through LDS: two barriers (it was a 16-barrier Hillis-Steele scan)
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((t & 63) >= o) incl += v; }
+    if ((t & 63) == 63) s_cnt[t >> 6] = incl;
     __syncthreads();
-    for (int o = 1; o < (int)blockDim.x; o <<= 1) {
-        const int v = (t >= o) ? s_cnt[t - o] : 0;
-        __syncthreads();
-        s_cnt[t] += v;
-        __syncthreads();
-    }
-    *my_base_out = s_cnt[t] - c;
-    const int total = s_cnt[blockDim.x - 1];
+    int base = 0;
+    for (int w = 0; w < (t >> 6); w++) base += s_cnt[w];
+    const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    *my_base_out = base + incl - c;
     __syncthreads();
     return total;
 }
@@ -158,7 +178,8 @@ __global__ __launch_bounds__(256) void k_vocab_assemble(const int32_t* __restric
                                                        uint32_t* __restrict__ fv_node, int32_t* __restrict__ fv_off, uint32_t* __restrict__ fv_feat,
                                                        int32_t* __restrict__ n_fv)
 {
-    extern __shared__ __align__(16) unsigned long long s_key[];        // n_pow2 keys
+    extern __shared__ __align__(16) unsigned long long s_key[];        // n_pow2 keys, then n_pow2 doubles: the BowVector values (for the norm)
+    double* const s_val = (double*)(s_key + n_pow2);
     __shared__ int s_cnt[256];
     __shared__ double s_norm;
     const int frame = blockIdx.x, tid = threadIdx.x;
@@ -209,23 +230,30 @@ __global__ __launch_bounds__(256) void k_vocab_assemble(const int32_t* __restric
                 for (int j = i + 1; j < n_pow2 && (s_key[j] >> 32) == w_id; j++) acc += weight[fo + (s_key[j] & 0xFFFFFFFFull)];
                 bow_id[fo + r] = (uint32_t)w_id;
                 bow_val[fo + r] = acc;
+                s_val[r] = acc;
                 r++;
             }
         }
     }
-    __threadfence_block();
     __syncthreads();
-    // normalize(L1) (BowVector.cpp:62-84): the sum runs in word-id order, sequentially, to reproduce the reference's rounding
+    // normalize(L1) (BowVector.cpp:62-84): the sum runs in word-id order, sequentially, to reproduce the reference's rounding -- one lane,
+    // the values from LDS eight at a time (the additions are the dependent chain; reading them back from global memory one by one
+    // was a third of this kernel)
     if (tid == 0) {
         double norm = 0.0;
-        for (int k = 0; k < n_words; k++) norm += fabs(bow_val[fo + k]);
+        int k = 0;
+        for (; k + 8 <= n_words; k += 8) {
+            const double v0 = s_val[k], v1 = s_val[k + 1], v2 = s_val[k + 2], v3 = s_val[k + 3], v4 = s_val[k + 4], v5 = s_val[k + 5], v6 = s_val[k + 6], v7 = s_val[k + 7];
+            norm += fabs(v0); norm += fabs(v1); norm += fabs(v2); norm += fabs(v3); norm += fabs(v4); norm += fabs(v5); norm += fabs(v6); norm += fabs(v7);
+        }
+        for (; k < n_words; k++) norm += fabs(s_val[k]);
         s_norm = norm;
         n_bow[frame] = n_words;
     }
     __syncthreads();
     const double norm = s_norm;
     if (norm > 0.0)
-        for (int k = tid; k < n_words; k += 256) bow_val[fo + k] /= norm;
+        for (int k = tid; k < n_words; k += 256) bow_val[fo + k] = s_val[k] / norm;
 }
 
 }  // namespace orbv
@@ -270,7 +298,7 @@ int enqueue_transform(orbv_vocab* v, const uint8_t* d_desc, const int32_t* d_n, 
     if (assemble) {
         const int n_pow2 = pow2_at_least(cap);
         if (n_pow2 > 8192) return fail(ORBX_ERR_ARG, "more than 8192 features per frame are not supported by the assembly kernel");
-        hipLaunchKernelGGL(orbv::k_vocab_assemble, dim3(batch), dim3(256), (size_t)n_pow2 * 8, st, d_n, n_fixed, cap, n_pow2, d_word, d_weight, d_node,
+        hipLaunchKernelGGL(orbv::k_vocab_assemble, dim3(batch), dim3(256), (size_t)n_pow2 * 16, st, d_n, n_fixed, cap, n_pow2, d_word, d_weight, d_node,
                            d_bow_id, d_bow_val, d_n_bow, d_fv_node, d_fv_off, d_fv_feat, d_n_fv);
     }
     ORBV_HIP(hipGetLastError());
@@ -325,7 +353,7 @@ int orbv_create(int device, const OrbvVocabulary* voc, orbv_vocab** out)
               hipMemcpy(v->d_tree + o_sdesc, sdesc.data(), sdesc.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(v->d_tree + o_srange, srange.data(), sizeof(int2) * srange.size(), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { orbv_destroy(v); return fail(ORBX_ERR_HIP, "vocabulary upload failed"); }
-    if (hipFuncSetAttribute((const void*)orbv::k_vocab_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)orbv::k_vocab_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16) != hipSuccess) {
         orbv_destroy(v);
         return fail(ORBX_ERR_HIP, "hipFuncSetAttribute failed");
     }
