@@ -519,17 +519,28 @@ __global__ __launch_bounds__(256) void k_grid(const ProjArgs* __restrict__ jobs,
         }
         s_gkey[i] = key;
     }
-    __syncthreads();
-    for (int k = 2; k <= n_pow2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n_pow2 >> 1); t += 256) {
-                const int lo = 2 * t - (t & (j - 1)), hi = lo + j;
-                const bool up = (lo & k) == 0;
-                const unsigned long long a = s_gkey[lo], b = s_gkey[hi];
-                if ((a > b) == up) { s_gkey[lo] = b; s_gkey[hi] = a; }
+    // bitonic sort by the 4 waves: wave w owns chunk w (n_pow2 / 4 keys); an exchange with a stride below the chunk size stays inside
+    // it and needs only the wave's own program order, the three passes that reach across chunks a workgroup barrier (it was one per pass)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int chunk = n_pow2 >> 2, pairs = n_pow2 >> 3;
+        bool need_block = true;
+        for (int k = 2; k <= n_pow2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const bool cross = j >= chunk || n_pow2 < 8;
+                if (cross || need_block) __syncthreads();
+                else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+                need_block = cross;
+                const int t0 = n_pow2 >= 8 ? wave * pairs + lane : tid, t1 = n_pow2 >= 8 ? (wave + 1) * pairs : (n_pow2 >> 1), ts = n_pow2 >= 8 ? 64 : 256;
+                for (int t = t0; t < t1; t += ts) {
+                    const int lo = 2 * t - (t & (j - 1)), hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const unsigned long long a = s_gkey[lo], b = s_gkey[hi];
+                    if ((a > b) == up) { s_gkey[lo] = b; s_gkey[hi] = a; }
+                }
             }
-            __syncthreads();
-        }
+        __syncthreads();
+    }
     for (int i = tid; i < n; i += 256) if (s_gkey[i] != ~0ull) cell_feat[i] = (int32_t)(s_gkey[i] & 0xFFFFFFFFull);
     for (int c = tid; c <= ncell; c += 256) {            // cell_off[c] = number of keys with cell < c
         int lo = 0, hi = n_pow2;

@@ -1108,16 +1108,28 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
     }
     if (local) atomicAdd(&s_cnt, local);
     __syncthreads();
-    for (int k = 2; k <= n_pow2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n_pow2 >> 1); t += 256) {
-                const int lo = 2 * t - (t & (j - 1)), hi = lo + j;
-                const bool up = (lo & k) == 0;
-                const int a = s_sad[lo], b = s_sad[hi];
-                if ((a > b) == up) { s_sad[lo] = b; s_sad[hi] = a; }
+    // bitonic sort by the 4 waves: wave w owns chunk w (n_pow2 / 4 values); exchanges with a stride below the chunk size stay inside it
+    // (the wave's own program order), only the three passes across chunks take a workgroup barrier
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int chunk = n_pow2 >> 2, pairs = n_pow2 >> 3;
+        bool need_block = false;             // (the barrier above made the values visible)
+        for (int k = 2; k <= n_pow2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const bool cross = j >= chunk || n_pow2 < 8;
+                if (cross || need_block) __syncthreads();
+                else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+                need_block = cross;
+                const int t0 = n_pow2 >= 8 ? wave * pairs + lane : tid, t1 = n_pow2 >= 8 ? (wave + 1) * pairs : (n_pow2 >> 1), ts = n_pow2 >= 8 ? 64 : 256;
+                for (int t = t0; t < t1; t += ts) {
+                    const int lo = 2 * t - (t & (j - 1)), hi = lo + j;
+                    const bool up = (lo & k) == 0;
+                    const int a = s_sad[lo], b = s_sad[hi];
+                    if ((a > b) == up) { s_sad[lo] = b; s_sad[hi] = a; }
+                }
             }
-            __syncthreads();
-        }
+        __syncthreads();
+    }
     const int m = s_cnt;
     if (m == 0) return;
     const float median = (float)s_sad[m / 2];
