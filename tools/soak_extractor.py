@@ -76,7 +76,7 @@ for ci in range(N):
     batch = np.ascontiguousarray(imgs[np.arange(B) % n_img])
     ex = pkg.Extractor(nfeat, scale, nlev, ini, mn)
     try:
-        cap = ex.max_keypoints
+        cap = max(ex.max_keypoints, ex.max_keypoints_for(w, h))       # (very wide images with tiny budgets: the bound for THIS image size)
         results = []
         mono, n, kps, desc = ex.extract_batch(batch, lap)
         results.append(("host", mono, n, kps, desc, ex.debug_last_schedule()))
@@ -93,7 +93,8 @@ for ci in range(N):
                 ex.extract_batch_device(d_buf.data_ptr() + boff, B, w, h, rstride, fstride, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr(), d_mono.data_ptr(), d_st.data_ptr(),
                                         lap, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert int(d_st.abs().sum().item()) == 0
+            if int(d_st.abs().sum().item()) != 0:
+                raise pkg.OrbxError(int(d_st.min().item()), "device entry: per-frame status %r" % d_st.cpu().numpy()[:4])
             results.append(("device", d_mono.cpu().numpy(), d_n.cpu().numpy(), d_kps.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, cap),
                             d_desc.cpu().numpy().reshape(B, cap, 32), ex.debug_last_schedule()))
         for name, mono, n, kps, desc, sched in results:
