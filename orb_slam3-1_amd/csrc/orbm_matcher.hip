@@ -759,7 +759,7 @@ __device__ __forceinline__ int block_runs(const ProjFrameDev& F, ProjBlockLds& B
     return cnt;
 }
 // phase 2 (every wave, thread = an equal, contiguous share of the item list)
-__device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* __restrict__ recs, const uint8_t* s_occ, ProjBlockLds& B, int tid)
+__device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* __restrict__ recs, const uint8_t* s_occ, ProjBlockLds& B, int tid, int nthreads)
 {
     const int total = B.pt_cum[64];
     if (total == 0) return;
@@ -769,7 +769,7 @@ __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* 
         const int idx = F.cell_feat[e];
         return make_uint4(__float_as_uint(F.x[idx]), __float_as_uint(F.y[idx]), (unsigned)F.octave[idx], (unsigned)idx);
     };
-    const int chunk = (total + kProjThreads - 1) / kProjThreads;
+    const int chunk = (total + nthreads - 1) / nthreads;     // (nthreads: the threads that walk this block's list -- all 8 waves for the first block, 7 afterwards)
     const int t0 = lane * chunk, t1 = min(total, t0 + chunk);
     if (t0 < t1) {
         int p = 0;                                      // last point with pt_cum[p] <= t0
@@ -830,11 +830,11 @@ __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* 
     }
 }
 // phase 3 (wave 0, lane = point again): the two smallest keys over the threads that walked a part of its items
-__device__ __forceinline__ void block_merge(ProjBlockLds& B, int lane, int cnt, bool want_second)
+__device__ __forceinline__ void block_merge(ProjBlockLds& B, int lane, int cnt, bool want_second, int nthreads)
 {
     if (cnt > 0) {
         const int total = B.pt_cum[64];
-        const int chunk = (total + kProjThreads - 1) / kProjThreads;
+        const int chunk = (total + nthreads - 1) / nthreads;
         const int start = B.pt_cum[lane];
         const int l0 = start / chunk, l1 = (start + cnt - 1) / chunk;
         unsigned long long k1 = kNoKey, k2 = kNoKey;
@@ -925,51 +925,77 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
 #ifdef ORBM_PROJ_TIMING
     long long t_blk = clock64();
 #endif
+    // Software pipeline over the blocks: while wave 0 RESOLVES block b, the other seven waves already walk the item list of block b + 1.
+    // That is sound because the speculation never needed an exact snapshot: occupancy only grows while the blocks run, a feature the
+    // search sees occupied stays so, and one it sees free but that is taken meanwhile turns up in the resolution as "best / second best
+    // candidate occupied" -- the dirty rule -- and is searched again against the exact occupancy.  (0.57 M -> see DESIGN: the resolution
+    // used to run with seven waves idle.)
+    struct PointRegs { bool live, irregular; float x, y, r, pur; int minLevel, maxLevel, occval, cnt; unsigned long long dq[4]; };
+    auto setup_block = [&](const int base, PointRegs& P) __attribute__((always_inline)) {       // wave 0: the points of a block -> runs (block_runs)
+        const int i = base + lane;
+        P.live = false; P.irregular = false; P.x = 0.f; P.y = 0.f; P.r = 0.f; P.pur = 0.f; P.minLevel = 0; P.maxLevel = 0; P.occval = 1; P.cnt = 0;
+        P.dq[0] = 0; P.dq[1] = 0; P.dq[2] = 0; P.dq[3] = 0;
+        P.live = i < A.n_pts && A.valid[i] != 0;
+        if (P.live) {
+            P.x = A.u[i]; P.y = A.v[i];
+            const int lvl = A.level[i];
+            P.pur = A.F.u_right ? A.ur[i] : 0.f;
+            if (!mode) {
+                if ((A.far_points && A.depth[i] > A.th_far) || A.bad[i]) P.live = false;
+                P.r = ((double)A.view_cos[i] > 0.998) ? 2.5f : 4.0f;             // RadiusByViewingCos (:215-221)
+                if (bFactor) P.r *= A.th;
+                P.r = P.r * F.scale_factors[lvl];
+                P.minLevel = lvl - 1; P.maxLevel = lvl;
+            } else if (mode == 1) {
+                if (P.x < F.min_x || P.x > F.max_x || P.y < F.min_y || P.y > F.max_y) P.live = false;      // :1711-1714, :1917-1920
+                P.r = A.th * F.scale_factors[lvl];
+                if (A.level_window == ORBM_LEVELS_FORWARD) { P.minLevel = lvl; P.maxLevel = -1; }          // :1729
+                else if (A.level_window == ORBM_LEVELS_BACKWARD) { P.minLevel = 0; P.maxLevel = lvl; }     // :1731
+                else { P.minLevel = lvl - 1; P.maxLevel = lvl + 1; }                                        // :1733, :1938
+            } else {
+                P.r = A.th * F.scale_factors[lvl];                          // :489
+                P.minLevel = lvl - 1; P.maxLevel = lvl;                        // :509
+            }
+            const unsigned long long* dp = (const unsigned long long*)(A.desc + (size_t)i * 32);
+            P.dq[0] = dp[0]; P.dq[1] = dp[1]; P.dq[2] = dp[2]; P.dq[3] = dp[3];
+            if (A.has_obs) P.occval = A.has_obs[i];
+        }
+        s_blk.dq[lane][0] = P.dq[0]; s_blk.dq[lane][1] = P.dq[1]; s_blk.dq[lane][2] = P.dq[2]; s_blk.dq[lane][3] = P.dq[3];
+        P.cnt = block_runs(F, s_blk, lane, P.live, P.x, P.y, P.r, P.minLevel, P.maxLevel, P.pur, P.irregular);
+    };
+    PointRegs cur;
+    cur.live = false; cur.irregular = false; cur.cnt = 0;
+    int search_threads = kProjThreads;          // block 0 is walked by all eight waves, the later ones by seven (wave 0 resolves beside them)
+    if (A.n_pts > 0) {
+        if (w0) setup_block(0, cur);
+        __syncthreads();
+        block_items(F, s_recs, s_occ, s_blk, tid, kProjThreads);
+        __syncthreads();
+    }
     for (int base = 0; base < A.n_pts; base += 64) {
         const int i = base + lane;
-        bool live = false, irregular = false;
-        float x = 0.f, y = 0.f, r = 0.f, pur = 0.f;
-        int minLevel = 0, maxLevel = 0, occval = 1, cnt = 0;
-        unsigned long long dq[4] = {0, 0, 0, 0};
+        const bool has_next = base + 64 < A.n_pts;
+        PointRegs nxt;
+        nxt.live = false; nxt.irregular = false; nxt.cnt = 0;
+        unsigned long long kb = kNoKey, ks = kNoKey;
         if (w0) {
-            live = i < A.n_pts && A.valid[i] != 0;
-            if (live) {
-                x = A.u[i]; y = A.v[i];
-                const int lvl = A.level[i];
-                pur = A.F.u_right ? A.ur[i] : 0.f;
-                if (!mode) {
-                    if ((A.far_points && A.depth[i] > A.th_far) || A.bad[i]) live = false;
-                    r = ((double)A.view_cos[i] > 0.998) ? 2.5f : 4.0f;             // RadiusByViewingCos (:215-221)
-                    if (bFactor) r *= A.th;
-                    r = r * F.scale_factors[lvl];
-                    minLevel = lvl - 1; maxLevel = lvl;
-                } else if (mode == 1) {
-                    if (x < F.min_x || x > F.max_x || y < F.min_y || y > F.max_y) live = false;      // :1711-1714, :1917-1920
-                    r = A.th * F.scale_factors[lvl];
-                    if (A.level_window == ORBM_LEVELS_FORWARD) { minLevel = lvl; maxLevel = -1; }          // :1729
-                    else if (A.level_window == ORBM_LEVELS_BACKWARD) { minLevel = 0; maxLevel = lvl; }     // :1731
-                    else { minLevel = lvl - 1; maxLevel = lvl + 1; }                                        // :1733, :1938
-                } else {
-                    r = A.th * F.scale_factors[lvl];                          // :489
-                    minLevel = lvl - 1; maxLevel = lvl;                        // :509
-                }
-                const unsigned long long* dp = (const unsigned long long*)(A.desc + (size_t)i * 32);
-                dq[0] = dp[0]; dq[1] = dp[1]; dq[2] = dp[2]; dq[3] = dp[3];
-                if (A.has_obs) occval = A.has_obs[i];
-            }
-            s_blk.dq[lane][0] = dq[0]; s_blk.dq[lane][1] = dq[1]; s_blk.dq[lane][2] = dq[2]; s_blk.dq[lane][3] = dq[3];
-            cnt = block_runs(F, s_blk, lane, live, x, y, r, minLevel, maxLevel, pur, irregular);
+            block_merge(s_blk, lane, cur.cnt, !mode, search_threads);      // (reads the block's slots and pt_cum: before the next block's set-up overwrites them)
+            kb = s_blk.best[lane]; ks = s_blk.second[lane];
+            wave_lds_sync();
+            if (has_next) setup_block(base + 64, nxt);
         }
-        __syncthreads();
-        // ---- speculative search of the block (every wave), occupancy as of its start ----
-        block_items(F, s_recs, s_occ, s_blk, tid);
         __syncthreads();
 #ifdef ORBM_PROJ_TIMING
         if (blockIdx.x == 0 && tid == 0) { const long long t_now = clock64(); d_proj_prof[5] += (unsigned long long)(t_now - t_blk); t_blk = t_now; d_proj_prof[7] += 64; }
 #endif
-        if (w0) {
-            block_merge(s_blk, lane, cnt, !mode);
-            const unsigned long long kb = s_blk.best[lane], ks = s_blk.second[lane];
+        if (!w0) {
+            // ---- speculative search of the NEXT block (waves 1-7), occupancy as it stands while wave 0 resolves this one ----
+            if (has_next) block_items(F, s_recs, s_occ, s_blk, tid - 64, kProjThreads - 64);
+        } else {
+            const bool live = cur.live, irregular = cur.irregular;
+            const float x = cur.x, y = cur.y, r = cur.r, pur = cur.pur;
+            const int minLevel = cur.minLevel, maxLevel = cur.maxLevel, occval = cur.occval;
+            const unsigned long long dq[4] = {cur.dq[0], cur.dq[1], cur.dq[2], cur.dq[3]};
             bool acc = live && accept(kb, ks);
             int bf = acc ? key_idx(kb) : -1;
             // ---- resolution in point order (this wave alone: its LDS traffic executes in order) ----
@@ -1036,10 +1062,12 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                 committed = d + 1;
             }
         }
-        __syncthreads();            // the block's occupancy is final for everybody
+        __syncthreads();            // the block's occupancy is final for everybody, the next block's list has been walked
 #ifdef ORBM_PROJ_TIMING
         if (blockIdx.x == 0 && tid == 0) { const long long t_now = clock64(); d_proj_prof[6] += (unsigned long long)(t_now - t_blk); t_blk = t_now; }
 #endif
+        cur = nxt;
+        search_threads = kProjThreads - 64;
     }
     if (ori && tid == 0) {
         int i1, i2, i3;
