@@ -1677,12 +1677,32 @@ struct ProjJob {
 };
 
 // Packs all jobs into one blob, ONE k_proj launch with a wave per job, copies assign / occupied / counts back.
+// Dynamic LDS a search kernel may ask for: the CU's 160 KB minus the kernel's own static LDS (block tables, histogram ...) and a
+// margin.  (A fixed 150 KB ignored the static part: frames of about 1 700 .. 1 900 features -- staged size between the true budget and
+// 150 KB -- made hipFuncSetAttribute fail; found by probing the feature counts around the limit.)
+static size_t proj_dynamic_lds_budget()
+{
+    static size_t budget = 0;
+    if (budget == 0) {
+        size_t st = 0;
+        const void* ks[4] = {(const void*)orbm::k_proj_par<true>, (const void*)orbm::k_proj_par<false>, (const void*)orbm::k_proj<true>, (const void*)orbm::k_proj<false>};
+        for (const void* k : ks) {
+            hipFuncAttributes fa;
+            if (hipFuncGetAttributes(&fa, k) == hipSuccess) st = std::max(st, (size_t)fa.sharedSizeBytes);
+        }
+        (void)hipGetLastError();
+        budget = 160 * 1024 - std::max(st, (size_t)4096) - 1024;
+    }
+    return budget;
+}
+
 static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int last_mode,
                                float th, int far_points, float th_far, float nnratio, int check_ori, float dist_th)
 {
     if (!m) return fail(ORBX_ERR_ARG, "NULL matcher");
     if (!jobs || n_jobs < 1) return fail(ORBX_ERR_ARG, "no jobs");
     ORBM_HIP(hipSetDevice(m->device));
+    (void)hipGetLastError();            // (an error an earlier, failed call left behind must not fail this one)
     Blob blob(m->h_blob);
     const size_t oargs = blob.reserve(sizeof(orbm::ProjArgs) * (size_t)n_jobs);
     struct Off { size_t x, y, oct, ang, desc, coff, cfeat, sf, uright, ur, valid, u, v, level, vc, dep, bad, angl, dmp, obs, assign, occ, logf, logb, nm; float winv, hinv; };
@@ -1775,10 +1795,11 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
     // k_proj_par (64 points at a time) keeps two int tables per feature in LDS; frames too large for them keep the sequential k_proj
     static const bool force_seq = std::getenv("ORBM_PROJ_SEQUENTIAL") != nullptr;      // measurement knob (tools/proj_timing.py)
     const size_t tabs = 8 * ((max_n + 15) & ~(size_t)15);
-    const bool par = !force_seq && tabs + ((max_n + 63) & ~(size_t)63) + 1024 <= 150 * 1024;
+    const size_t lds_budget = proj_dynamic_lds_budget();
+    const bool par = !force_seq && tabs + ((max_n + 63) & ~(size_t)63) + 1024 <= lds_budget;
     const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64) + (par ? tabs : 0);
     const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (max_cells + 1) * 4 + 64 + (par ? tabs + max_n * 16 + 32 : 0);     // 52: with u_right staged; k_proj_par: + the records in grid order
-    const bool stage = lds_full <= 150 * 1024;
+    const bool stage = lds_full <= lds_budget;
     const size_t lds = stage ? lds_full : lds_occ;
     for (int j = 0; j < n_jobs; j++) args[j].lds_frame = stage ? 1 : 0;
     ORBM_HIP(hipMemcpyAsync(base, m->h_blob.data(), m->h_blob.size(), hipMemcpyHostToDevice, m->stream));
@@ -2143,10 +2164,11 @@ static int projection_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur,
     // LDS of the search kernel, as in run_projection_jobs
     const size_t max_n = cap;
     const size_t tabs = 8 * ((max_n + 15) & ~(size_t)15);
-    if (tabs + ((max_n + 63) & ~(size_t)63) + 1024 > 150 * 1024) return fail(ORBX_ERR_CAPACITY, "frames of %zu features exceed the search kernel's LDS tables", max_n);
+    const size_t lds_budget = proj_dynamic_lds_budget();
+    if (tabs + ((max_n + 63) & ~(size_t)63) + 1024 > lds_budget) return fail(ORBX_ERR_CAPACITY, "frames of %zu features exceed the search kernel's LDS tables", max_n);
     const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64) + tabs;
     const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (cells + 1) * 4 + 64 + tabs + max_n * 16 + 32;
-    const bool stage = lds_full <= 150 * 1024;
+    const bool stage = lds_full <= lds_budget;
     const size_t lds = stage ? lds_full : lds_occ;
     orbm::ProjDevSetup P;
     P.kps = cur->d_kps; P.desc = cur->d_desc; P.n = cur->d_n; P.cap = cur->cap;

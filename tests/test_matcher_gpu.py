@@ -391,3 +391,47 @@ def test_search_by_projection_batch_device(pkg, oracle, sm):
         n = len(g["x"])
         assert nm[b] == n0 > 100, "frame %d" % b
         np.testing.assert_array_equal(a1[b, :n], a0); np.testing.assert_array_equal(o1[b, :n], o0)
+
+
+@pytest.mark.parametrize("n", [1600, 1700, 1750, 1850, 1950, 2100])
+def test_projection_searches_around_the_lds_staging_limit(pkg, oracle, sm, n):
+    """found by probing: the decision whether a frame is staged in LDS compared its size with a fixed 150 KB and ignored the search kernel's
+    own static LDS, so frames of about 1 700 .. 1 900 features (staged size between the true budget and 150 KB) failed with ORBX_ERR_HIP --
+    and left an error behind that failed the next call too.  The budget now comes from the kernels' attributes: both tracking searches,
+    host entry and device-resident entry, equal the oracle across the limit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g, dF, aF, sc, last, a, oc = sm.make_last_frame_case(11, n=n, n_last=900)
+    a0, o0 = a.copy(), oc.copy()
+    n0 = oracle.search_by_projection_last(g, dF, aF, sc, last, 15.0, True, a0, o0)
+    g2, dF2, aF2, sc2, mp, a2, oc2 = sm.make_projection_case(11, n=n, n_mp=1500)
+    b0, p0 = a2.copy(), oc2.copy()
+    k0 = oracle.search_by_projection(g2, dF2, sc2, mp, 3.0, 0.8, b0, p0)
+    m = pkg.Matcher(0.8, True)
+    try:
+        a1, o1 = a.copy(), oc.copy()
+        n1 = m.SearchByProjection_last(g, dF, aF, sc, last, 15.0, a1, o1)
+        b1, p1 = a2.copy(), oc2.copy()
+        k1 = m.SearchByProjection(g2, dF2, sc2, mp, 3.0, b1, p1)
+        # the device-resident entry on the same frame (cap = n)
+        kps = np.zeros((1, n), pkg.KP_DTYPE)
+        kps[0]["x"] = g["x"]; kps[0]["y"] = g["y"]; kps[0]["octave"] = g["octave"]; kps[0]["angle"] = aF
+        tt = lambda x_: torch.from_numpy(np.ascontiguousarray(x_).view(np.uint8).reshape(-1)).to(dev)
+        d = {k_: tt(v_) for k_, v_ in dict(kps=kps, desc=dF, n=np.array([n], np.int32), pv=last["valid"], pu=last["u"], pw=last["v"], po=last["octave"], pa=last["angle"],
+                                           pd=last["desc"], pn=np.array([len(last["u"])], np.int32), ph=last["has_obs"], assign=a.copy(), occ=oc.copy()).items()}
+        d_nm = torch.zeros(1, dtype=torch.int32, device=dev)
+        m2 = pkg.Matcher(0.9, True)
+        m2.SearchByProjection_last_batch_device((d["kps"].data_ptr(), d["desc"].data_ptr(), d["n"].data_ptr(), n),
+                                                (d["pv"].data_ptr(), d["pu"].data_ptr(), d["pw"].data_ptr(), d["po"].data_ptr(), d["pa"].data_ptr(), d["pd"].data_ptr(), d["pn"].data_ptr(), len(last["u"]), d["ph"].data_ptr()),
+                                                1, 15.0, d["assign"].data_ptr(), d["occ"].data_ptr(), d_nm.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                                                bounds=(g["min_x"], g["min_y"], g["max_x"], g["max_y"]), scale_factors=sc)
+        torch.cuda.synchronize()
+        m2.close()
+        a3 = d["assign"].cpu().numpy().view(np.int32); o3 = d["occ"].cpu().numpy()
+    finally:
+        m.close()
+    assert (n1, k1) == (n0, k0)
+    np.testing.assert_array_equal(a1, a0); np.testing.assert_array_equal(o1, o0)
+    np.testing.assert_array_equal(b1, b0); np.testing.assert_array_equal(p1, p0)
+    assert int(d_nm.item()) == n0
+    np.testing.assert_array_equal(a3, a0); np.testing.assert_array_equal(o3, o0)
