@@ -701,23 +701,25 @@ __global__ __launch_bounds__(64) void k_proj(const ProjArgs* __restrict__ jobs)
 // keeps the two best keys of the point it is walking in registers and merges them into the point's LDS slots when it moves on.
 constexpr int kBlkRuns = 16;
 constexpr int kBlkSlots = 64 * 8 + 64;   // threads of a k_proj_par workgroup + points of a block
-struct ProjBlockLds {
+struct ProjBlockTab {                   // the points of a block and their windows (two in LDS: one is searched / resolved while the next but one is set up)
     int run_start[64][kBlkRuns];        // CSR position of the first feature of a run
     int run_cum[64][kBlkRuns + 1];      // items of the point in front of the run
     int pt_cum[65];                     // items in front of the point
     float prm[64][4];                   // x, y, r, predicted right column
     int lvl[64][2];                     // minLevel, maxLevel
     unsigned long long dq[64][4];
-    unsigned long long best[64], second[64];
-    unsigned long long part1[kBlkSlots], part2[kBlkSlots];  // (best, second) a thread found for a point, slot = thread + point (unique: both only grow along the list)
+    int flags[64];                      // bit 0 live, bit 1 irregular window, bits 8..15 the occupancy value a match writes
 };
+struct ProjBlockPart {                  // (best, second) a thread found for a point, slot = thread + point (unique: both only grow along the list).  Every slot
+    unsigned long long part1[kBlkSlots], part2[kBlkSlots];  // block_merge reads was written by block_items for the same block (a thread stores a slot for every
+};                                      // point it walked an item of, and block_merge reads exactly those threads): the slots need no initialisation.
 // recs: the frame's key points in CSR (grid) order, 16 bytes each {x, y, octave, feature index}: one LDS read per item whose
 // address does not depend on a previous read, so the record of item t + 1 is in flight while item t is examined (nullptr: built
 // from the separate arrays, the path of frames too large to stage).
-constexpr int kProjWaves = 8;           // waves of a k_proj_par workgroup: all of them walk the item list, wave 0 resolves the block
+constexpr int kProjWaves = 8;           // waves of a k_proj_par workgroup: wave 0 resolves a block, wave 1 sets up the next but one, waves 2-7 walk the next one's item list
 constexpr int kProjThreads = 64 * kProjWaves;
-// phase 1 (wave 0, lane = point): window -> runs; returns the point's item count
-__device__ __forceinline__ int block_runs(const ProjFrameDev& F, ProjBlockLds& B, int lane, bool live,
+// phase 1 (one wave, lane = point): window -> runs; returns the point's item count
+__device__ __forceinline__ int block_runs(const ProjFrameDev& F, ProjBlockTab& B, int lane, bool live,
                                           float x, float y, float r, int minLevel, int maxLevel, float pt_ur, bool& irregular)
 {
     irregular = false;
@@ -744,8 +746,6 @@ __device__ __forceinline__ int block_runs(const ProjFrameDev& F, ProjBlockLds& B
     for (int k = nx + 1; k <= kBlkRuns; k++) B.run_cum[lane][k] = 0x7FFFFFFF;
     B.prm[lane][0] = x; B.prm[lane][1] = y; B.prm[lane][2] = r; B.prm[lane][3] = pt_ur;
     B.lvl[lane][0] = minLevel; B.lvl[lane][1] = maxLevel;
-    B.best[lane] = kNoKey; B.second[lane] = kNoKey;
-    for (int q = lane; q < kProjThreads + 64; q += 64) { B.part1[q] = kNoKey; B.part2[q] = kNoKey; }
     int incl = cnt;                                      // inclusive prefix over the 64 lanes (DPP ladder)
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
@@ -759,7 +759,7 @@ __device__ __forceinline__ int block_runs(const ProjFrameDev& F, ProjBlockLds& B
     return cnt;
 }
 // phase 2 (every wave, thread = an equal, contiguous share of the item list)
-__device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* __restrict__ recs, const uint8_t* s_occ, ProjBlockLds& B, int tid, int nthreads)
+__device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* __restrict__ recs, const uint8_t* s_occ, const ProjBlockTab& B, ProjBlockPart& S, int tid, int nthreads)
 {
     const int total = B.pt_cum[64];
     if (total == 0) return;
@@ -802,7 +802,7 @@ __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* 
                 rec = load_rec(e);
             }
             if (ip != cp) {
-                if (cp >= 0) { B.part1[lane + cp] = k1; B.part2[lane + cp] = k2; }     // plain stores: no atomic round trips in the loop
+                if (cp >= 0) { S.part1[lane + cp] = k1; S.part2[lane + cp] = k2; }     // plain stores: no atomic round trips in the loop
                 k1 = k2 = kNoKey;
                 cp = ip;
                 px = B.prm[cp][0]; py = B.prm[cp][1]; pr = B.prm[cp][2]; pur = B.prm[cp][3];
@@ -826,24 +826,30 @@ __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* 
             const unsigned long long key = ((unsigned long long)dist << 55) | ((unsigned long long)ord << 21) | (unsigned long long)idx;
             if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
         }
-        if (cp >= 0) { B.part1[lane + cp] = k1; B.part2[lane + cp] = k2; }
+        if (cp >= 0) { S.part1[lane + cp] = k1; S.part2[lane + cp] = k2; }
     }
 }
 // phase 3 (wave 0, lane = point again): the two smallest keys over the threads that walked a part of its items
-__device__ __forceinline__ void block_merge(ProjBlockLds& B, int lane, int cnt, bool want_second, int nthreads)
+__device__ __forceinline__ void block_merge(const ProjBlockTab& B, const ProjBlockPart& S, int lane, int cnt, int nthreads, unsigned long long& best, unsigned long long& second)
 {
+    best = kNoKey; second = kNoKey;
     if (cnt > 0) {
         const int total = B.pt_cum[64];
         const int chunk = (total + nthreads - 1) / nthreads;
         const int start = B.pt_cum[lane];
         const int l0 = start / chunk, l1 = (start + cnt - 1) / chunk;
         unsigned long long k1 = kNoKey, k2 = kNoKey;
-        for (int l = l0; l <= l1; l++) {
-            const unsigned long long a1 = B.part1[l + lane], a2 = B.part2[l + lane];
-            if (a1 < k1) { k2 = min(k1, a2); k1 = a1; } else { k2 = min(k2, a1); }
+        for (int l = l0; l <= l1; l += 4) {         // four slots at a time: their LDS reads are in flight together (this loop is on wave 0's serial path)
+            unsigned long long a1[4], a2[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int q = min(l + j, l1) + lane; a1[j] = S.part1[q]; a2[j] = S.part2[q]; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (l + j > l1) { a1[j] = kNoKey; a2[j] = kNoKey; }
+                if (a1[j] < k1) { k2 = min(k1, a2[j]); k1 = a1[j]; } else { k2 = min(k2, a1[j]); }
+            }
         }
-        B.best[lane] = k1;
-        if (want_second) B.second[lane] = k2;
+        best = k1; second = k2;
     }
 }
 
@@ -861,7 +867,8 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     extern __shared__ __align__(16) uint8_t s_dyn[];
     __shared__ int s_hist[HISTO_LENGTH];
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool w0 = tid < 64;                   // wave 0 owns the points of a block and resolves it
+    const int wv = tid >> 6;                    // wave 0 resolves a block, wave 1 sets up the next but one, waves 2-7 walk the next one's item list
+    const bool w0 = wv == 0;
     ProjFrameDev F = A.F;
     const int n = F.n;
     const size_t tab = ((size_t)n + 15) & ~(size_t)15;
@@ -897,7 +904,8 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     }
     __shared__ float s_scale[32];
     __shared__ int s_col[32];
-    __shared__ ProjBlockLds s_blk;
+    __shared__ ProjBlockTab s_tab[2];
+    __shared__ ProjBlockPart s_part;
     if (F.n_levels > 0 && F.n_levels <= 32) {
         if (tid < F.n_levels) s_scale[tid] = F.scale_factors[tid];
         F.scale_factors = s_scale;
@@ -922,18 +930,21 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
         }
         return true;
     };
-#ifdef ORBM_PROJ_TIMING
-    long long t_blk = clock64();
+#ifdef ORBM_PROJ_TIMING      // (sums in registers, written once at the end: a global read-modify-write per tick would be most of what it measures)
+    long long t_blk = clock64(), c_a = 0, c_b = 0, c_merge = 0, c_work = 0;
+    int c_pass = 0, c_again = 0;
 #endif
-    // Software pipeline over the blocks: while wave 0 RESOLVES block b, the other seven waves already walk the item list of block b + 1.
-    // That is sound because the speculation never needed an exact snapshot: occupancy only grows while the blocks run, a feature the
-    // search sees occupied stays so, and one it sees free but that is taken meanwhile turns up in the resolution as "best / second best
-    // candidate occupied" -- the dirty rule -- and is searched again against the exact occupancy.  (0.57 M -> see DESIGN: the resolution
-    // used to run with seven waves idle.)
+    // Software pipeline over the blocks, three stages deep: while wave 0 RESOLVES block b, waves 2-7 already walk the item list of block
+    // b + 1 and wave 1 SETS UP block b + 2 (its points' global loads and window -> runs tables, into the table block b just left).
+    // The early search is sound because the speculation never needed an exact snapshot: occupancy only grows while the blocks run, a
+    // feature the search sees occupied stays so, and one it sees free but that is taken meanwhile turns up in the resolution as "best /
+    // second best candidate occupied" -- the dirty rule -- and is searched again against the exact occupancy.  Only the merge of a block's
+    // partial results (a few LDS reads per point) is left on wave 0's serial path between the two barriers of a block.
     struct PointRegs { bool live, irregular; float x, y, r, pur; int minLevel, maxLevel, occval, cnt; unsigned long long dq[4]; };
-    auto setup_block = [&](const int base, PointRegs& P) __attribute__((always_inline)) {       // wave 0: the points of a block -> runs (block_runs)
+    auto setup_block = [&](const int base, ProjBlockTab& T) __attribute__((always_inline)) {       // one wave: the points of a block -> runs (block_runs)
         const int i = base + lane;
-        P.live = false; P.irregular = false; P.x = 0.f; P.y = 0.f; P.r = 0.f; P.pur = 0.f; P.minLevel = 0; P.maxLevel = 0; P.occval = 1; P.cnt = 0;
+        PointRegs P;
+        P.irregular = false; P.x = 0.f; P.y = 0.f; P.r = 0.f; P.pur = 0.f; P.minLevel = 0; P.maxLevel = 0; P.occval = 1; P.cnt = 0;
         P.dq[0] = 0; P.dq[1] = 0; P.dq[2] = 0; P.dq[3] = 0;
         P.live = i < A.n_pts && A.valid[i] != 0;
         if (P.live) {
@@ -960,37 +971,51 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
             P.dq[0] = dp[0]; P.dq[1] = dp[1]; P.dq[2] = dp[2]; P.dq[3] = dp[3];
             if (A.has_obs) P.occval = A.has_obs[i];
         }
-        s_blk.dq[lane][0] = P.dq[0]; s_blk.dq[lane][1] = P.dq[1]; s_blk.dq[lane][2] = P.dq[2]; s_blk.dq[lane][3] = P.dq[3];
-        P.cnt = block_runs(F, s_blk, lane, P.live, P.x, P.y, P.r, P.minLevel, P.maxLevel, P.pur, P.irregular);
+        T.dq[lane][0] = P.dq[0]; T.dq[lane][1] = P.dq[1]; T.dq[lane][2] = P.dq[2]; T.dq[lane][3] = P.dq[3];
+        P.cnt = block_runs(F, T, lane, P.live, P.x, P.y, P.r, P.minLevel, P.maxLevel, P.pur, P.irregular);
+        T.flags[lane] = (P.live ? 1 : 0) | (P.irregular ? 2 : 0) | ((P.occval & 0xFF) << 8);
     };
-    PointRegs cur;
-    cur.live = false; cur.irregular = false; cur.cnt = 0;
-    int search_threads = kProjThreads;          // block 0 is walked by all eight waves, the later ones by seven (wave 0 resolves beside them)
+    int search_threads = kProjThreads;          // block 0 is walked by all eight waves, the later ones by six (wave 0 resolves, wave 1 sets up beside them)
     if (A.n_pts > 0) {
-        if (w0) setup_block(0, cur);
+        if (wv == 0) setup_block(0, s_tab[0]);
+        else if (wv == 1 && 64 < A.n_pts) setup_block(64, s_tab[1]);
         __syncthreads();
-        block_items(F, s_recs, s_occ, s_blk, tid, kProjThreads);
+        block_items(F, s_recs, s_occ, s_tab[0], s_part, tid, kProjThreads);
         __syncthreads();
     }
-    for (int base = 0; base < A.n_pts; base += 64) {
+    int bi = 0;
+    for (int base = 0; base < A.n_pts; base += 64, bi ^= 1) {
         const int i = base + lane;
-        const bool has_next = base + 64 < A.n_pts;
-        PointRegs nxt;
-        nxt.live = false; nxt.irregular = false; nxt.cnt = 0;
+        const bool has_next = base + 64 < A.n_pts, has_next2 = base + 128 < A.n_pts;
+        ProjBlockTab& T = s_tab[bi];
+        PointRegs cur;
+        cur.live = false; cur.irregular = false; cur.cnt = 0;
         unsigned long long kb = kNoKey, ks = kNoKey;
-        if (w0) {
-            block_merge(s_blk, lane, cur.cnt, !mode, search_threads);      // (reads the block's slots and pt_cum: before the next block's set-up overwrites them)
-            kb = s_blk.best[lane]; ks = s_blk.second[lane];
-            wave_lds_sync();
-            if (has_next) setup_block(base + 64, nxt);
-        }
-        __syncthreads();
 #ifdef ORBM_PROJ_TIMING
-        if (blockIdx.x == 0 && tid == 0) { const long long t_now = clock64(); d_proj_prof[5] += (unsigned long long)(t_now - t_blk); t_blk = t_now; d_proj_prof[7] += 64; }
+        const long long t_m0 = clock64();
 #endif
-        if (!w0) {
-            // ---- speculative search of the NEXT block (waves 1-7), occupancy as it stands while wave 0 resolves this one ----
-            if (has_next) block_items(F, s_recs, s_occ, s_blk, tid - 64, kProjThreads - 64);
+        if (w0) {               // the block's points back from its table (another wave set it up) and the merge of the partial results
+            const int fl = T.flags[lane];
+            cur.live = (fl & 1) != 0; cur.irregular = (fl & 2) != 0; cur.occval = (fl >> 8) & 0xFF;
+            cur.x = T.prm[lane][0]; cur.y = T.prm[lane][1]; cur.r = T.prm[lane][2]; cur.pur = T.prm[lane][3];
+            cur.minLevel = T.lvl[lane][0]; cur.maxLevel = T.lvl[lane][1];
+            cur.dq[0] = T.dq[lane][0]; cur.dq[1] = T.dq[lane][1]; cur.dq[2] = T.dq[lane][2]; cur.dq[3] = T.dq[lane][3];
+            cur.cnt = T.pt_cum[lane + 1] - T.pt_cum[lane];
+            block_merge(T, s_part, lane, cur.cnt, search_threads, kb, ks);
+            if (mode) ks = kNoKey;
+        }
+#ifdef ORBM_PROJ_TIMING
+        c_merge += clock64() - t_m0;
+#endif
+        __syncthreads();        // the table and the partial results have been read: both may be written again
+#ifdef ORBM_PROJ_TIMING
+        { const long long t_now = clock64(); c_a += t_now - t_blk; t_blk = t_now; }
+#endif
+        if (wv == 1) {
+            if (has_next2) setup_block(base + 128, T);
+        } else if (!w0) {
+            // ---- speculative search of the NEXT block (waves 2-7), occupancy as it stands while wave 0 resolves this one ----
+            if (has_next) block_items(F, s_recs, s_occ, s_tab[bi ^ 1], s_part, tid - 128, kProjThreads - 128);
         } else {
             const bool live = cur.live, irregular = cur.irregular;
             const float x = cur.x, y = cur.y, r = cur.r, pur = cur.pur;
@@ -1033,11 +1058,11 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                 const int ncm = __popcll(cmm);
                 nmatches += ncm; nlog += ncm;
 #ifdef ORBM_PROJ_TIMING
-                if (blockIdx.x == 0 && lane == 0) d_proj_prof[3] += 1;
+                c_pass++;
 #endif
                 if (d == 64) break;
 #ifdef ORBM_PROJ_TIMING
-                if (blockIdx.x == 0 && lane == 0) d_proj_prof[4] += 1;
+                c_again++;
 #endif
                 // ---- the first dirty point again, by the whole wave against the exact occupancy ----
                 const float xd = __shfl(x, d), yd = __shfl(y, d), rd = __shfl(r, d), purd = __shfl(pur, d);
@@ -1062,13 +1087,22 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                 committed = d + 1;
             }
         }
+#ifdef ORBM_PROJ_TIMING
+        c_work += clock64() - t_blk;        // this wave's own work of the overlapped phase (wave 0 resolution, wave 1 set-up, waves 2-7 item list)
+#endif
         __syncthreads();            // the block's occupancy is final for everybody, the next block's list has been walked
 #ifdef ORBM_PROJ_TIMING
-        if (blockIdx.x == 0 && tid == 0) { const long long t_now = clock64(); d_proj_prof[6] += (unsigned long long)(t_now - t_blk); t_blk = t_now; }
+        { const long long t_now = clock64(); c_b += t_now - t_blk; t_blk = t_now; }
 #endif
-        cur = nxt;
-        search_threads = kProjThreads - 64;
+        search_threads = kProjThreads - 128;
     }
+#ifdef ORBM_PROJ_TIMING
+    if (blockIdx.x == 0) {      // [0] wave 1 set-up, [1] wave 0 merge, [2] wave 0 resolution, [3] passes, [4] points searched again, [5] serial phase, [6] overlapped phase, [7] wave 2 item list
+        if (tid == 0) { d_proj_prof[1] = c_merge; d_proj_prof[2] = c_work; d_proj_prof[3] = c_pass; d_proj_prof[4] = c_again; d_proj_prof[5] = c_a; d_proj_prof[6] = c_b; }
+        if (tid == 64) d_proj_prof[0] = c_work;
+        if (tid == 128) d_proj_prof[7] = c_work;
+    }
+#endif
     if (ori && tid == 0) {
         int i1, i2, i3;
         three_maxima(s_hist, HISTO_LENGTH, i1, i2, i3);
