@@ -758,7 +758,13 @@ __device__ __forceinline__ int block_runs(const ProjFrameDev& F, ProjBlockTab& B
     if (lane == 0) B.pt_cum[64] = total;
     return cnt;
 }
-// phase 2 (every wave, thread = an equal, contiguous share of the item list)
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src)
+{
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// phase 2 (the searching waves, thread = an equal, contiguous share of the item list).  Whole waves only: it ends with wave-wide shuffles.
 __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* __restrict__ recs, const uint8_t* s_occ, const ProjBlockTab& B, ProjBlockPart& S, int tid, int nthreads)
 {
     const int total = B.pt_cum[64];
@@ -769,8 +775,10 @@ __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* 
         const int idx = F.cell_feat[e];
         return make_uint4(__float_as_uint(F.x[idx]), __float_as_uint(F.y[idx]), (unsigned)F.octave[idx], (unsigned)idx);
     };
-    const int chunk = (total + nthreads - 1) / nthreads;     // (nthreads: the threads that walk this block's list -- all 8 waves for the first block, 7 afterwards)
+    const int chunk = (total + nthreads - 1) / nthreads;     // (nthreads: the threads that walk this block's list -- all 8 waves for the first block, 6 afterwards)
     const int t0 = lane * chunk, t1 = min(total, t0 + chunk);
+    int cp = -1;                                        // point whose parameters are in registers
+    unsigned long long k1 = kNoKey, k2 = kNoKey;
     if (t0 < t1) {
         int p = 0;                                      // last point with pt_cum[p] <= t0
         for (int step = 32; step > 0; step >>= 1) if (p + step < 64 && B.pt_cum[p + step] <= t0) p += step;
@@ -782,11 +790,9 @@ __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* 
         int pt_end = B.pt_cum[p + 1];
         int fp = p, ford = local;                       // point and visiting-order position of the record in flight
         uint4 rec = load_rec(e);
-        int cp = -1;                                    // point whose parameters are in registers
         float px = 0.f, py = 0.f, pr = 0.f, pur = 0.f;
         int mnl = 0, mxl = 0;
         unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-        unsigned long long k1 = kNoKey, k2 = kNoKey;
         for (int t = t0; t < t1; t++) {
             const uint4 cur = rec;
             const int ip = fp, ord = ford;
@@ -826,7 +832,36 @@ __device__ __forceinline__ void block_items(const ProjFrameDev& F, const uint4* 
             const unsigned long long key = ((unsigned long long)dist << 55) | ((unsigned long long)ord << 21) | (unsigned long long)idx;
             if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
         }
-        if (cp >= 0) { S.part1[lane + cp] = k1; S.part2[lane + cp] = k2; }
+    }
+    // The threads whose share ENDS inside the same point are neighbours (a large window spans many of them): their results are combined
+    // in the wave -- a segmented suffix reduction over the lanes: four DPP row shifts inside each row of 16 lanes, then the first lanes
+    // of the up to three following rows (a run is contiguous: if the first lane of a later row belongs to it, so does everything in
+    // between), whose reads are independent and in flight together -- and only the first lane of such a run stores them, the others
+    // store "nothing", so that block_merge, which is on wave 0's serial path, reads a handful of slots per point instead of one per
+    // thread that walked it.
+    const int hl = threadIdx.x & 63;
+#define ORBM_ROW_SHL64(v, ctrl) (((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((v) >> 32), ctrl, 0xF, 0xF, false) << 32) | \
+                                 (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v), ctrl, 0xF, 0xF, false))
+#define ORBM_ROW_STEP(ctrl) { \
+        const int ocp = __builtin_amdgcn_update_dpp(-2, cp, ctrl, 0xF, 0xF, false);       /* lane + n of the same row, -2 beyond the row */ \
+        const unsigned long long o1 = ORBM_ROW_SHL64(k1, ctrl), o2 = ORBM_ROW_SHL64(k2, ctrl); \
+        if (cp >= 0 && ocp == cp) { if (o1 < k1) { k2 = min(k1, o2); k1 = o1; } else { k2 = min(k2, o1); } } }       /* (disjoint item sets: plain two-smallest merge) */
+    ORBM_ROW_STEP(0x101) ORBM_ROW_STEP(0x102) ORBM_ROW_STEP(0x104) ORBM_ROW_STEP(0x108)
+#undef ORBM_ROW_STEP
+#undef ORBM_ROW_SHL64
+    {
+        const int row0 = hl & ~15;
+        int ocp[3]; unsigned long long o1[3], o2[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int src = min(row0 + 16 * (j + 1), 63); ocp[j] = __shfl(cp, src); o1[j] = shfl64(k1, src); o2[j] = shfl64(k2, src); }
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (row0 + 16 * (j + 1) < 64 && cp >= 0 && ocp[j] == cp) { if (o1[j] < k1) { k2 = min(k1, o2[j]); k1 = o1[j]; } else { k2 = min(k2, o1[j]); } }
+    }
+    const int pcp = __shfl(cp, max(hl - 1, 0));
+    if (cp >= 0) {
+        const bool head = hl == 0 || pcp != cp;
+        S.part1[lane + cp] = head ? k1 : kNoKey; S.part2[lane + cp] = head ? k2 : kNoKey;
     }
 }
 // phase 3 (wave 0, lane = point again): the two smallest keys over the threads that walked a part of its items
@@ -838,25 +873,24 @@ __device__ __forceinline__ void block_merge(const ProjBlockTab& B, const ProjBlo
         const int chunk = (total + nthreads - 1) / nthreads;
         const int start = B.pt_cum[lane];
         const int l0 = start / chunk, l1 = (start + cnt - 1) / chunk;
+        // slots that can hold results of this point: its first and its last thread, and the first thread of every wave in between
+        // (block_items: the threads in between only walked this point and handed their results to the head of their run)
+        constexpr int kCand = 2 + kProjWaves - 1;
+        int cand[kCand];
+        cand[0] = l0; cand[1] = l1 > l0 ? l1 : -1;
+#pragma unroll
+        for (int j = 0; j < kProjWaves - 1; j++) { const int m_ = ((l0 >> 6) + 1 + j) << 6; cand[2 + j] = m_ < l1 ? m_ : -1; }
+        unsigned long long a1[kCand], a2[kCand];
+#pragma unroll
+        for (int j = 0; j < kCand; j++) { const int q = max(cand[j], 0) + lane; a1[j] = S.part1[q]; a2[j] = S.part2[q]; }      // (all reads in flight together)
         unsigned long long k1 = kNoKey, k2 = kNoKey;
-        for (int l = l0; l <= l1; l += 4) {         // four slots at a time: their LDS reads are in flight together (this loop is on wave 0's serial path)
-            unsigned long long a1[4], a2[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { const int q = min(l + j, l1) + lane; a1[j] = S.part1[q]; a2[j] = S.part2[q]; }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (l + j > l1) { a1[j] = kNoKey; a2[j] = kNoKey; }
-                if (a1[j] < k1) { k2 = min(k1, a2[j]); k1 = a1[j]; } else { k2 = min(k2, a1[j]); }
-            }
+        for (int j = 0; j < kCand; j++) {
+            if (cand[j] < 0) { a1[j] = kNoKey; a2[j] = kNoKey; }
+            if (a1[j] < k1) { k2 = min(k1, a2[j]); k1 = a1[j]; } else { k2 = min(k2, a1[j]); }
         }
         best = k1; second = k2;
     }
-}
-
-__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src)
-{
-    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
-    return ((unsigned long long)hi << 32) | lo;
 }
 
 template <bool STAGE>
