@@ -379,7 +379,8 @@ __device__ __forceinline__ void wave_lds_sync()
 // WAVE_ONLY: the calling wave is one of several in its workgroup and works alone (k_proj_par): no workgroup barrier
 template <bool WAVE_ONLY = false>
 __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8_t* s_occ, float x, float y, float r, int minLevel, int maxLevel,
-                              float pt_ur, const unsigned long long* dq, int lane, int* s_col, unsigned long long& best, unsigned long long& second)
+                              float pt_ur, const unsigned long long* dq, int lane, int* s_col, unsigned long long& best, unsigned long long& second,
+                              const uint4* __restrict__ recs = nullptr)     // recs: the key points in grid order {x, y, octave, feature} (k_proj_par's staged frames: they replace cell_feat / x / y / octave)
 {
     best = second = kNoKey;
     const int nMinCellX = max(0, (int)floorf((x - F.min_x - r) * F.winv));
@@ -420,13 +421,22 @@ __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8
             int cx = 0;
             for (int k = 1; k < nx; k++) cx += (t >= s_col[k]) ? 1 : 0;
             const int pos = t - s_col[cx];
-            const int idx = F.cell_feat[s_col[16 + cx] + pos];
-            if (bCheckLevels) {
-                const int oc = F.octave[idx];
-                if (oc < minLevel) continue;
-                if (maxLevel >= 0 && oc > maxLevel) continue;
+            int idx; float distx, disty;
+            if (recs) {
+                const uint4 rc = recs[s_col[16 + cx] + pos];
+                idx = (int)rc.w;
+                const int oc = (int)rc.z;
+                if (bCheckLevels && (oc < minLevel || (maxLevel >= 0 && oc > maxLevel))) continue;
+                distx = __uint_as_float(rc.x) - x; disty = __uint_as_float(rc.y) - y;
+            } else {
+                idx = F.cell_feat[s_col[16 + cx] + pos];
+                if (bCheckLevels) {
+                    const int oc = F.octave[idx];
+                    if (oc < minLevel) continue;
+                    if (maxLevel >= 0 && oc > maxLevel) continue;
+                }
+                distx = F.x[idx] - x; disty = F.y[idx] - y;
             }
-            const float distx = F.x[idx] - x, disty = F.y[idx] - y;
             if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
             if (s_occ[idx]) continue;                                        // mvpMapPoints[idx] && Observations()>0
             if (F.u_right) {                                                 // :92-98, :1751-1757
@@ -447,13 +457,22 @@ __device__ __forceinline__ void search_window(const ProjFrameDev& F, const uint8
         const int cell = ix * F.rows + iy;
         const int e0 = F.cell_off[cell], e1 = F.cell_off[cell + 1];
         for (int e = e0; e < e1; e++) {
-            const int idx = F.cell_feat[e];
-            if (bCheckLevels) {
-                const int oc = F.octave[idx];
-                if (oc < minLevel) continue;
-                if (maxLevel >= 0 && oc > maxLevel) continue;
+            int idx; float distx, disty;
+            if (recs) {
+                const uint4 rc = recs[e];
+                idx = (int)rc.w;
+                const int oc = (int)rc.z;
+                if (bCheckLevels && (oc < minLevel || (maxLevel >= 0 && oc > maxLevel))) continue;
+                distx = __uint_as_float(rc.x) - x; disty = __uint_as_float(rc.y) - y;
+            } else {
+                idx = F.cell_feat[e];
+                if (bCheckLevels) {
+                    const int oc = F.octave[idx];
+                    if (oc < minLevel) continue;
+                    if (maxLevel >= 0 && oc > maxLevel) continue;
+                }
+                distx = F.x[idx] - x; disty = F.y[idx] - y;
             }
-            const float distx = F.x[idx] - x, disty = F.y[idx] - y;
             if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
             if (s_occ[idx]) continue;                                        // mvpMapPoints[idx] && Observations()>0
             if (F.u_right) {
@@ -913,18 +932,15 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     if (STAGE) {
         const int ncell = F.cols * F.rows;
         size_t off = tab;
+        // (x, y and the CSR's feature list are NOT staged on their own: every search reads them from the 16-byte records in grid order)
         uint8_t* s_desc = s_occ + off; off += (size_t)n * 32;
-        float* s_x = (float*)(s_occ + off); off += (size_t)n * 4;
-        float* s_y = (float*)(s_occ + off); off += (size_t)n * 4;
         int32_t* s_oct = (int32_t*)(s_occ + off); off += (size_t)n * 4;
-        int32_t* s_cfeat = (int32_t*)(s_occ + off); off += (size_t)n * 4;
         float* s_ur = (float*)(s_occ + off); off += F.u_right ? (size_t)n * 4 : 0;
         int32_t* s_coff = (int32_t*)(s_occ + off);
         for (int i = tid; i < n * 8; i += kProjThreads) ((uint32_t*)s_desc)[i] = ((const uint32_t*)F.desc)[i];
-        for (int i = tid; i < n; i += kProjThreads) { s_x[i] = F.x[i]; s_y[i] = F.y[i]; s_oct[i] = F.octave[i]; }
+        for (int i = tid; i < n; i += kProjThreads) s_oct[i] = F.octave[i];
         if (F.u_right) { for (int i = tid; i < n; i += kProjThreads) s_ur[i] = F.u_right[i]; F.u_right = s_ur; }
         const int nfeat_cells = F.cell_off[ncell];
-        for (int i = tid; i < nfeat_cells; i += kProjThreads) s_cfeat[i] = F.cell_feat[i];
         for (int i = tid; i <= ncell; i += kProjThreads) s_coff[i] = F.cell_off[i];
         off += ((size_t)ncell + 1) * 4;
         off = (off + 15) & ~(size_t)15;
@@ -934,7 +950,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
             r4[e] = make_uint4(__float_as_uint(F.x[idx]), __float_as_uint(F.y[idx]), (unsigned)F.octave[idx], (unsigned)idx);
         }
         s_recs = r4;
-        F.desc = s_desc; F.x = s_x; F.y = s_y; F.octave = s_oct; F.cell_feat = s_cfeat; F.cell_off = s_coff;
+        F.desc = s_desc; F.octave = s_oct; F.cell_off = s_coff;
     }
     __shared__ float s_scale[32];
     __shared__ int s_col[32];
@@ -1103,7 +1119,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                 const int minLd = __shfl(minLevel, d), maxLd = __shfl(maxLevel, d), occd = __shfl(occval, d);
                 const unsigned long long dqd[4] = {shfl64(dq[0], d), shfl64(dq[1], d), shfl64(dq[2], d), shfl64(dq[3], d)};
                 unsigned long long kbd, ksd;
-                search_window<true>(F, s_occ, xd, yd, rd, minLd, maxLd, purd, dqd, lane, s_col, kbd, ksd);
+                search_window<true>(F, s_occ, xd, yd, rd, minLd, maxLd, purd, dqd, lane, s_col, kbd, ksd, s_recs);
                 if (accept(kbd, ksd)) {
                     const int f = key_idx(kbd);
                     if (lane == 0) {
@@ -1866,7 +1882,7 @@ static int run_projection_jobs(orbm_matcher* m, ProjJob* jobs, int n_jobs, int l
     const size_t lds_budget = proj_dynamic_lds_budget();
     const bool par = !force_seq && tabs + ((max_n + 63) & ~(size_t)63) + 1024 <= lds_budget;
     const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64) + (par ? tabs : 0);
-    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (max_cells + 1) * 4 + 64 + (par ? tabs + max_n * 16 + 32 : 0);     // 52: with u_right staged; k_proj_par: + the records in grid order
+    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * (par ? 40 : 52) + (max_cells + 1) * 4 + 64 + (par ? tabs + max_n * 16 + 32 : 0);     // k_proj: descriptor, x, y, octave, CSR entry, u_right; k_proj_par: descriptor, octave, u_right + the 16-byte records in grid order
     const bool stage = lds_full <= lds_budget;
     const size_t lds = stage ? lds_full : lds_occ;
     for (int j = 0; j < n_jobs; j++) args[j].lds_frame = stage ? 1 : 0;
@@ -2235,7 +2251,7 @@ static int projection_batch_device(orbm_matcher* m, const OrbmDeviceFrames* cur,
     const size_t lds_budget = proj_dynamic_lds_budget();
     if (tabs + ((max_n + 63) & ~(size_t)63) + 1024 > lds_budget) return fail(ORBX_ERR_CAPACITY, "frames of %zu features exceed the search kernel's LDS tables", max_n);
     const size_t lds_occ = std::max((max_n + 63) & ~(size_t)63, (size_t)64) + tabs;
-    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 52 + (cells + 1) * 4 + 64 + tabs + max_n * 16 + 32;
+    const size_t lds_full = ((max_n + 15) & ~(size_t)15) + max_n * 40 + (cells + 1) * 4 + 64 + tabs + max_n * 16 + 32;
     const bool stage = lds_full <= lds_budget;
     const size_t lds = stage ? lds_full : lds_occ;
     orbm::ProjDevSetup P;

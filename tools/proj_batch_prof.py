@@ -2,7 +2,7 @@
 """Batched SearchByProjection(CurrentFrame, LastFrame) and SearchByProjection(Frame, MapPoints) for rocprofv3 --kernel-trace --stats:
 256 frames x 1000 features, ~900 projected points each, one launch (a wave per frame).  ORBM_PROJ_SEQUENTIAL=1 selects the
 sequential kernel (one point after the other) for comparison.
-  python tools/proj_batch_prof.py [frames] [calls]"""
+  python tools/proj_batch_prof.py [frames] [calls] [features per frame] [points per frame]"""
 import importlib
 import os
 import sys
@@ -16,7 +16,9 @@ pkg = importlib.import_module("orb_slam3-1_amd")
 sm = importlib.import_module("orb_slam3-1_amd.synth_match")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-cases = [sm.make_last_frame_case(i) for i in range(16)]
+NF = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+NP = int(sys.argv[4]) if len(sys.argv) > 4 else 900
+cases = [sm.make_last_frame_case(i, n=NF, n_last=NP) for i in range(16)]
 cases = [(g, dF, aF, sc, last, a.copy(), o.copy()) for (g, dF, aF, sc, last, a, o) in cases * (B // 16)]
 m = pkg.Matcher(0.9, True)
 prep = m.prepare_last_batch(cases)
