@@ -1096,11 +1096,9 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                 const unsigned long long cmm = __ballot(cm);
                 if (cm) {
                     if (s_last[bf] == lane) { A.assign[bf] = i; s_occ[bf] = (uint8_t)occval; }     // same-feature writers: the last in point order
-                    if (ori) {
-                        const int bin = rot_bin(A.angle[i], F.angle[bf]);
-                        const int at = nlog + __popcll(cmm & ((1ull << lane) - 1ull));
-                        A.log_feat[at] = bf; A.log_bin[at] = bin;
-                        atomicAdd(&s_hist[bin], 1);
+                    if (ori) {          // the rotation log keeps (feature, point); bins and histogram follow after the blocks, by every thread
+                        const int at = nlog + __popcll(cmm & ((1ull << lane) - 1ull));      // (two angle loads from global memory per commit were a third of a resolution pass)
+                        A.log_feat[at] = bf; A.log_bin[at] = i;
                     }
                 }
                 wave_lds_sync();
@@ -1125,11 +1123,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                     if (lane == 0) {
                         A.assign[f] = base + d;
                         s_occ[f] = (uint8_t)occd;
-                        if (ori) {
-                            const int bin = rot_bin(A.angle[base + d], F.angle[f]);
-                            A.log_feat[nlog] = f; A.log_bin[nlog] = bin;
-                            s_hist[bin]++;
-                        }
+                        if (ori) { A.log_feat[nlog] = f; A.log_bin[nlog] = base + d; }
                     }
                     nmatches++; nlog++;
                 }
@@ -1153,17 +1147,34 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
         if (tid == 128) d_proj_prof[7] = c_work;
     }
 #endif
-    if (ori && tid == 0) {
-        int i1, i2, i3;
-        three_maxima(s_hist, HISTO_LENGTH, i1, i2, i3);
-        for (int k = 0; k < nlog; k++) {
-            const int b = A.log_bin[k];
-            if (b != i1 && b != i2 && b != i3) {
-                A.assign[A.log_feat[k]] = -1;           // CurrentFrame.mvpMapPoints[...] = NULL (:1878)
-                s_occ[A.log_feat[k]] = 0;
-                nmatches--;
+    if (ori) {
+        // rotation consistency (:1868-1884) by the whole workgroup: bins of the logged matches, histogram, the three maxima, and the
+        // matches outside them taken back (only -1 / 0 are written here, so the order of the log does not matter)
+        __shared__ int s_rot[5];                // log length, the three maxima, matches taken back
+        if (tid == 0) { s_rot[0] = nlog; s_rot[4] = 0; }
+        __threadfence_block();
+        __syncthreads();                        // (the log was written to global memory by wave 0: visible to the workgroup behind the barrier)
+        const int n_log = s_rot[0];
+        for (int k = tid; k < n_log; k += kProjThreads) {
+            const int bin = rot_bin(A.angle[A.log_bin[k]], F.angle[A.log_feat[k]]);
+            A.log_bin[k] = bin;                 // (the same thread reads it back below)
+            atomicAdd(&s_hist[bin], 1);
+        }
+        __syncthreads();
+        if (tid == 0) { int i1, i2, i3; three_maxima(s_hist, HISTO_LENGTH, i1, i2, i3); s_rot[1] = i1; s_rot[2] = i2; s_rot[3] = i3; }
+        __syncthreads();
+        const int i1 = s_rot[1], i2 = s_rot[2], i3 = s_rot[3];
+        for (int k = tid; k < n_log; k += kProjThreads) {
+            const int b_ = A.log_bin[k];
+            if (b_ != i1 && b_ != i2 && b_ != i3) {
+                const int f = A.log_feat[k];
+                A.assign[f] = -1;               // CurrentFrame.mvpMapPoints[...] = NULL (:1878)
+                s_occ[f] = 0;
+                atomicAdd(&s_rot[4], 1);
             }
         }
+        __syncthreads();
+        nmatches -= s_rot[4];
     }
     __syncthreads();
     for (int i = tid; i < n; i += kProjThreads) A.occupied[i] = s_occ[i];
