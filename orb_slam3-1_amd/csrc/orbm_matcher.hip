@@ -982,7 +982,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     };
 #ifdef ORBM_PROJ_TIMING      // (sums in registers, written once at the end: a global read-modify-write per tick would be most of what it measures)
     long long t_blk = clock64(), c_a = 0, c_b = 0, c_merge = 0, c_work = 0;
-    int c_pass = 0, c_again = 0;
+    int c_pass = 0, c_again = 0, c_walk = 0;
 #endif
     // Software pipeline over the blocks, three stages deep: while wave 0 RESOLVES block b, waves 2-7 already walk the item list of block
     // b + 1 and wave 1 SETS UP block b + 2 (its points' global loads and window -> runs tables, into the table block b just left).
@@ -1051,8 +1051,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
             cur.minLevel = T.lvl[lane][0]; cur.maxLevel = T.lvl[lane][1];
             cur.dq[0] = T.dq[lane][0]; cur.dq[1] = T.dq[lane][1]; cur.dq[2] = T.dq[lane][2]; cur.dq[3] = T.dq[lane][3];
             cur.cnt = T.pt_cum[lane + 1] - T.pt_cum[lane];
-            block_merge(T, s_part, lane, cur.cnt, search_threads, kb, ks);
-            if (mode) ks = kNoKey;
+            block_merge(T, s_part, lane, cur.cnt, search_threads, kb, ks);     // (ks: the ratio test's second best in mode 0, the stand-in for a taken best otherwise)
         }
 #ifdef ORBM_PROJ_TIMING
         c_merge += clock64() - t_m0;
@@ -1116,8 +1115,20 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                 const float xd = __shfl(x, d), yd = __shfl(y, d), rd = __shfl(r, d), purd = __shfl(pur, d);
                 const int minLd = __shfl(minLevel, d), maxLd = __shfl(maxLevel, d), occd = __shfl(occval, d);
                 const unsigned long long dqd[4] = {shfl64(dq[0], d), shfl64(dq[1], d), shfl64(dq[2], d), shfl64(dq[3], d)};
-                unsigned long long kbd, ksd;
-                search_window<true>(F, s_occ, xd, yd, rd, minLd, maxLd, purd, dqd, lane, s_col, kbd, ksd, s_recs);
+                unsigned long long kbd = kNoKey, ksd = kNoKey;
+                // Where only the best candidate counts (every mode but the map-point search with its ratio test) the speculative second
+                // best IS the answer when it is still free: the candidates a search sees only shrink (occupancy grows), the best one has
+                // been taken, so the smallest key of the rest is the second -- no window walk.  (No second at all: no candidate is left.)
+                bool again = true;
+                if (mode && !(__shfl((int)irregular, d) != 0)) {
+                    const unsigned long long k2 = shfl64(ks, d);
+                    if (k2 == kNoKey) again = false;
+                    else if (s_occ[key_idx(k2)] == 0) { kbd = k2; again = false; }
+                }
+                if (again) search_window<true>(F, s_occ, xd, yd, rd, minLd, maxLd, purd, dqd, lane, s_col, kbd, ksd, s_recs);
+#ifdef ORBM_PROJ_TIMING
+                if (again) c_walk++;
+#endif
                 if (accept(kbd, ksd)) {
                     const int f = key_idx(kbd);
                     if (lane == 0) {
@@ -1142,7 +1153,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     }
 #ifdef ORBM_PROJ_TIMING
     if (blockIdx.x == 0) {      // [0] wave 1 set-up, [1] wave 0 merge, [2] wave 0 resolution, [3] passes, [4] points searched again, [5] serial phase, [6] overlapped phase, [7] wave 2 item list
-        if (tid == 0) { d_proj_prof[1] = c_merge; d_proj_prof[2] = c_work; d_proj_prof[3] = c_pass; d_proj_prof[4] = c_again; d_proj_prof[5] = c_a; d_proj_prof[6] = c_b; }
+        if (tid == 0) { d_proj_prof[1] = c_merge; d_proj_prof[2] = c_work; d_proj_prof[3] = c_pass; d_proj_prof[4] = c_again | ((unsigned long long)c_walk << 32); d_proj_prof[5] = c_a; d_proj_prof[6] = c_b; }
         if (tid == 64) d_proj_prof[0] = c_work;
         if (tid == 128) d_proj_prof[7] = c_work;
     }
