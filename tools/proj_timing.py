@@ -12,7 +12,8 @@ import torch  # noqa: F401
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("orb_slam3-1_amd")
 sm = importlib.import_module("orb_slam3-1_amd.synth_match")
-if len(sys.argv) > 1 and sys.argv[1] == "chain":       # the tracking chain's workload: features the extractor finds on a frame and on the same frame 3 px to the right
+MODE = sys.argv[1] if len(sys.argv) > 1 else ""
+if MODE in ("chain", "tlm"):       # the tracking chain's workload: features the extractor finds on a frame and on the same frame 3 px to the right
     import numpy as np
     synth = importlib.import_module("orb_slam3-1_amd.synth")
     img = synth.make_frame(0, 640, 480)
@@ -30,11 +31,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "chain":       # the tracking chain's wo
     assign = np.full(len(k_cur), -1, np.int32); occ = np.zeros(len(k_cur), np.uint8)
 else:
     g, dF, angF, scale, last, assign, occ = sm.make_last_frame_case(0)
-m = pkg.Matcher(0.9, True)
 out = (C.c_ulonglong * 8)()
-m.SearchByProjection_last(g, dF, angF, scale, last, 15.0, assign.copy(), occ.copy())
+if MODE == "tlm":       # TrackLocalMap's search: SearchByProjection(Frame, MapPoints, th = 1) on the last frame's points + as many again a few pixels off
+    rs = np.random.RandomState(9)
+    off = rs.uniform(-4, 4, n_l).astype(np.float32)
+    mp = dict(in_view=np.ones(2 * n_l, np.uint8), u=np.concatenate([last["u"], last["u"] + off]), v=np.concatenate([last["v"], last["v"] + off[::-1]]),
+              level=np.concatenate([last["octave"], last["octave"]]), view_cos=np.full(2 * n_l, 0.999, np.float32), depth=np.full(2 * n_l, 5.0, np.float32),
+              desc=np.ascontiguousarray(np.concatenate([d_last, d_last])), has_obs=np.ones(2 * n_l, np.uint8), bad=np.zeros(2 * n_l, np.uint8))
+    m = pkg.Matcher(0.8, True)
+    run = lambda: m.SearchByProjection(g, dF, scale, mp, 1.0, assign.copy(), occ.copy())
+else:
+    m = pkg.Matcher(0.9, True)
+    run = lambda: m.SearchByProjection_last(g, dF, angF, scale, last, 15.0, assign.copy(), occ.copy())
+run()
 pkg.lib.orbm_debug_proj_prof(out)
-n = m.SearchByProjection_last(g, dF, angF, scale, last, 15.0, assign.copy(), occ.copy())
+n = run()
 pkg.lib.orbm_debug_proj_prof(out)
 v = list(out)
 print("matches %d, points %d, total cycles %d (%.0f per point): window walk %d, reduction %d" % (n, v[7], v[0], v[0] / max(v[7], 1), v[1], v[2]))
