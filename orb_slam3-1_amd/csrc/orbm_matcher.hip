@@ -991,19 +991,36 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     // second best candidate occupied" -- the dirty rule -- and is searched again against the exact occupancy.  Only the merge of a block's
     // partial results (a few LDS reads per point) is left on wave 0's serial path between the two barriers of a block.
     struct PointRegs { bool live, irregular; float x, y, r, pur; int minLevel, maxLevel, occval, cnt; unsigned long long dq[4]; };
-    auto setup_block = [&](const int base, ProjBlockTab& T) __attribute__((always_inline)) {       // one wave: the points of a block -> runs (block_runs)
-        const int i = base + lane;
+    // A block's set-up is two steps: load_block reads the points' arrays from global memory (unconditionally, at a clamped index: one
+    // round of independent loads, no load behind the `valid` test), build_block turns them into the block's table.  Wave 1 issues the
+    // loads of block b + 3 right after it has built block b + 2, so they are in flight across the barriers and no set-up waits for
+    // global memory (with the loads inside the set-up it was the LONGEST job of the overlapped phase on TrackLocalMap's 2 000 points).
+    struct RawPoint { bool in_range; unsigned char valid, bad, has_obs; float u, v, ur, view_cos, depth; int level; unsigned long long dq[4]; };
+    auto load_block = [&](const int base) __attribute__((always_inline)) -> RawPoint {
+        RawPoint R;
+        const int i = base + lane, ic = min(i, A.n_pts - 1);          // (only called with n_pts > 0)
+        R.in_range = i < A.n_pts;
+        R.valid = A.valid[ic]; R.u = A.u[ic]; R.v = A.v[ic]; R.level = A.level[ic];
+        R.ur = A.F.u_right ? A.ur[ic] : 0.f;
+        R.bad = 0; R.view_cos = 0.f; R.depth = 0.f;
+        if (!mode) { R.bad = A.bad[ic]; R.view_cos = A.view_cos[ic]; R.depth = A.far_points ? A.depth[ic] : 0.f; }
+        R.has_obs = A.has_obs ? A.has_obs[ic] : (unsigned char)1;
+        const unsigned long long* dp = (const unsigned long long*)(A.desc + (size_t)ic * 32);
+        R.dq[0] = dp[0]; R.dq[1] = dp[1]; R.dq[2] = dp[2]; R.dq[3] = dp[3];
+        return R;
+    };
+    auto build_block = [&](const RawPoint& R, ProjBlockTab& T) __attribute__((always_inline)) {       // one wave: the points of a block -> runs (block_runs)
         PointRegs P;
         P.irregular = false; P.x = 0.f; P.y = 0.f; P.r = 0.f; P.pur = 0.f; P.minLevel = 0; P.maxLevel = 0; P.occval = 1; P.cnt = 0;
         P.dq[0] = 0; P.dq[1] = 0; P.dq[2] = 0; P.dq[3] = 0;
-        P.live = i < A.n_pts && A.valid[i] != 0;
+        P.live = R.in_range && R.valid != 0;
         if (P.live) {
-            P.x = A.u[i]; P.y = A.v[i];
-            const int lvl = A.level[i];
-            P.pur = A.F.u_right ? A.ur[i] : 0.f;
+            P.x = R.u; P.y = R.v;
+            const int lvl = R.level;
+            P.pur = R.ur;
             if (!mode) {
-                if ((A.far_points && A.depth[i] > A.th_far) || A.bad[i]) P.live = false;
-                P.r = ((double)A.view_cos[i] > 0.998) ? 2.5f : 4.0f;             // RadiusByViewingCos (:215-221)
+                if ((A.far_points && R.depth > A.th_far) || R.bad) P.live = false;
+                P.r = ((double)R.view_cos > 0.998) ? 2.5f : 4.0f;             // RadiusByViewingCos (:215-221)
                 if (bFactor) P.r *= A.th;
                 P.r = P.r * F.scale_factors[lvl];
                 P.minLevel = lvl - 1; P.maxLevel = lvl;
@@ -1017,18 +1034,23 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
                 P.r = A.th * F.scale_factors[lvl];                          // :489
                 P.minLevel = lvl - 1; P.maxLevel = lvl;                        // :509
             }
-            const unsigned long long* dp = (const unsigned long long*)(A.desc + (size_t)i * 32);
-            P.dq[0] = dp[0]; P.dq[1] = dp[1]; P.dq[2] = dp[2]; P.dq[3] = dp[3];
-            if (A.has_obs) P.occval = A.has_obs[i];
+            P.dq[0] = R.dq[0]; P.dq[1] = R.dq[1]; P.dq[2] = R.dq[2]; P.dq[3] = R.dq[3];
+            P.occval = R.has_obs;
         }
         T.dq[lane][0] = P.dq[0]; T.dq[lane][1] = P.dq[1]; T.dq[lane][2] = P.dq[2]; T.dq[lane][3] = P.dq[3];
         P.cnt = block_runs(F, T, lane, P.live, P.x, P.y, P.r, P.minLevel, P.maxLevel, P.pur, P.irregular);
         T.flags[lane] = (P.live ? 1 : 0) | (P.irregular ? 2 : 0) | ((P.occval & 0xFF) << 8);
     };
+    RawPoint raw_next;          // wave 1: the loaded points of the block it builds next
+    raw_next.in_range = false; raw_next.valid = 0; raw_next.bad = 0; raw_next.has_obs = 1; raw_next.u = 0.f; raw_next.v = 0.f; raw_next.ur = 0.f;
+    raw_next.view_cos = 0.f; raw_next.depth = 0.f; raw_next.level = 0; raw_next.dq[0] = 0; raw_next.dq[1] = 0; raw_next.dq[2] = 0; raw_next.dq[3] = 0;
     int search_threads = kProjThreads;          // block 0 is walked by all eight waves, the later ones by six (wave 0 resolves, wave 1 sets up beside them)
     if (A.n_pts > 0) {
-        if (wv == 0) setup_block(0, s_tab[0]);
-        else if (wv == 1 && 64 < A.n_pts) setup_block(64, s_tab[1]);
+        if (wv == 0) build_block(load_block(0), s_tab[0]);
+        else if (wv == 1) {
+            if (64 < A.n_pts) build_block(load_block(64), s_tab[1]);
+            if (128 < A.n_pts) raw_next = load_block(128);
+        }
         __syncthreads();
         block_items(F, s_recs, s_occ, s_tab[0], s_part, tid, kProjThreads);
         __syncthreads();
@@ -1061,7 +1083,8 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
         { const long long t_now = clock64(); c_a += t_now - t_blk; t_blk = t_now; }
 #endif
         if (wv == 1) {
-            if (has_next2) setup_block(base + 128, T);
+            if (has_next2) build_block(raw_next, T);
+            if (base + 192 < A.n_pts) raw_next = load_block(base + 192);       // (in flight until the next block's turn)
         } else if (!w0) {
             // ---- speculative search of the NEXT block (waves 2-7), occupancy as it stands while wave 0 resolves this one ----
             if (has_next) block_items(F, s_recs, s_occ, s_tab[bi ^ 1], s_part, tid - 128, kProjThreads - 128);
@@ -1155,7 +1178,7 @@ __global__ __launch_bounds__(kProjThreads) void k_proj_par(const ProjArgs* __res
     if (blockIdx.x == 0) {      // [0] wave 1 set-up, [1] wave 0 merge, [2] wave 0 resolution, [3] passes, [4] points searched again, [5] serial phase, [6] overlapped phase, [7] wave 2 item list
         if (tid == 0) { d_proj_prof[1] = c_merge; d_proj_prof[2] = c_work; d_proj_prof[3] = c_pass; d_proj_prof[4] = c_again | ((unsigned long long)c_walk << 32); d_proj_prof[5] = c_a; d_proj_prof[6] = c_b; }
         if (tid == 64) d_proj_prof[0] = c_work;
-        if (tid == 128) d_proj_prof[7] = c_work;
+        if (tid >= 128 && lane == 0) atomicMax(&d_proj_prof[7], (unsigned long long)c_work);        // (the slowest of the searching waves; the slot is zeroed by the read-out)
     }
 #endif
     if (ori) {

@@ -50,4 +50,4 @@ pkg.lib.orbm_debug_proj_prof(out)
 v = list(out)
 print("matches %d, points %d, total cycles %d (%.0f per point): window walk %d, reduction %d" % (n, v[7], v[0], v[0] / max(v[7], 1), v[1], v[2]))
 print("block-parallel kernel (k_proj_par, the slots mean something else there): passes %d, points resolved again %d (%d of them by a window walk); cycles of the serial phase %d (wave 0 merge %d), "
-      "of the overlapped phase %d (wave 0 resolution %d, wave 1 set-up %d, wave 2 item list %d)" % (v[3], v[4] & 0xFFFFFFFF, v[4] >> 32, v[5], v[1], v[6], v[2], v[0], v[7]))
+      "of the overlapped phase %d (wave 0 resolution %d, wave 1 set-up %d, slowest item-list wave %d)" % (v[3], v[4] & 0xFFFFFFFF, v[4] >> 32, v[5], v[1], v[6], v[2], v[0], v[7]))
