@@ -894,19 +894,15 @@ __device__ __forceinline__ void block_merge(const ProjBlockTab& B, const ProjBlo
         const int l0 = start / chunk, l1 = (start + cnt - 1) / chunk;
         // slots that can hold results of this point: its first and its last thread, and the first thread of every wave in between
         // (block_items: the threads in between only walked this point and handed their results to the head of their run)
-        constexpr int kCand = 2 + kProjWaves - 1;
-        int cand[kCand];
-        cand[0] = l0; cand[1] = l1 > l0 ? l1 : -1;
-#pragma unroll
-        for (int j = 0; j < kProjWaves - 1; j++) { const int m_ = ((l0 >> 6) + 1 + j) << 6; cand[2 + j] = m_ < l1 ? m_ : -1; }
-        unsigned long long a1[kCand], a2[kCand];
-#pragma unroll
-        for (int j = 0; j < kCand; j++) { const int q = max(cand[j], 0) + lane; a1[j] = S.part1[q]; a2[j] = S.part2[q]; }      // (all reads in flight together)
-        unsigned long long k1 = kNoKey, k2 = kNoKey;
-#pragma unroll
-        for (int j = 0; j < kCand; j++) {
-            if (cand[j] < 0) { a1[j] = kNoKey; a2[j] = kNoKey; }
-            if (a1[j] < k1) { k2 = min(k1, a2[j]); k1 = a1[j]; } else { k2 = min(k2, a1[j]); }
+        // The first and the last thread always (two slots, in flight together); the wave starts in between only when the point spans
+        // a wave boundary -- rare with small windows, where this merge is most of what is left on wave 0's serial path.
+        const int q1 = max(l1, l0) + lane;
+        unsigned long long k1 = S.part1[l0 + lane], k2 = S.part2[l0 + lane];
+        unsigned long long b1 = S.part1[q1], b2 = S.part2[q1];
+        if (l1 > l0) { if (b1 < k1) { k2 = min(k1, b2); k1 = b1; } else { k2 = min(k2, b1); } }
+        for (int m_ = ((l0 >> 6) + 1) << 6; m_ < l1; m_ += 64) {
+            b1 = S.part1[m_ + lane]; b2 = S.part2[m_ + lane];
+            if (b1 < k1) { k2 = min(k1, b2); k1 = b1; } else { k2 = min(k2, b1); }
         }
         best = k1; second = k2;
     }
