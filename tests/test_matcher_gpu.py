@@ -435,3 +435,63 @@ def test_projection_searches_around_the_lds_staging_limit(pkg, oracle, sm, n):
     np.testing.assert_array_equal(b1, b0); np.testing.assert_array_equal(p1, p0)
     assert int(d_nm.item()) == n0
     np.testing.assert_array_equal(a3, a0); np.testing.assert_array_equal(o3, o0)
+
+
+def _crowd(rs, g, desc, targets, followers=7):
+    """`targets` features of the frame, each with `followers` other features moved next to it (same level, a few bits of its descriptor
+    flipped): points aimed at a target find a queue of acceptable candidates, so the later ones get what the earlier ones left."""
+    idx = rs.choice(len(desc), min(targets * (followers + 1), len(desc)), replace=False)
+    hot = idx[:targets]
+    for k, j in enumerate(idx[targets:]):
+        h = hot[k % targets]
+        g["x"][j] = g["x"][h] + rs.uniform(-2, 2); g["y"][j] = g["y"][h] + rs.uniform(-2, 2); g["octave"][j] = g["octave"][h]
+        desc[j] = desc[h] ^ np.packbits(rs.uniform(size=256) < 0.02 * (1 + k // targets))
+    g["x"][:] = np.clip(g["x"], 0, g["max_x"] - 1); g["y"][:] = np.clip(g["y"], 0, g["max_y"] - 1)
+    return hot
+
+
+@pytest.mark.parametrize("seed,targets,noise", [(0, 4, 0.02), (1, 40, 0.05), (2, 1, 0.0), (3, 120, 0.1)])
+def test_projection_searches_under_contention(pkg, oracle, sm, seed, targets, noise):
+    """Many points after the same few features: every point's best candidate has usually been taken by an earlier point, often its second
+    best as well -- the resolution's stand-in rule (a free speculative second best IS the best of the rest where only the best counts),
+    the window walk behind it, the map-point search's ratio test on a shrinking pool and same-feature writers inside one block of 64.
+    Point order decides everything here; the result must be the sequential loop's."""
+    rs = np.random.RandomState(40 + seed)
+    for n_pts in (64, 500, 1500):
+        # SearchByProjection(CurrentFrame, LastFrame) with and without the orientation check
+        g, dF, aF, sc, last, a, oc = sm.make_last_frame_case(20 + seed, n=1000, n_last=n_pts)
+        hot = _crowd(rs, g, dF, targets)
+        tgt = hot[rs.randint(0, targets, n_pts)]
+        last["u"] = (g["x"][tgt] + rs.normal(0, 1.0, n_pts)).astype(np.float32); last["v"] = (g["y"][tgt] + rs.normal(0, 1.0, n_pts)).astype(np.float32)
+        last["octave"] = g["octave"][tgt].astype(np.int32)
+        last["desc"] = np.ascontiguousarray(dF[tgt] ^ (np.packbits(rs.uniform(size=(n_pts, 256)) < noise, axis=1)))
+        last["valid"][:] = 1
+        for ori in (True, False):
+            a0, o0 = a.copy(), oc.copy()
+            n0 = oracle.search_by_projection_last(g, dF, aF, sc, last, 15.0, ori, a0, o0)
+            m = pkg.Matcher(0.9, ori)
+            try:
+                a1, o1 = a.copy(), oc.copy()
+                n1 = m.SearchByProjection_last(g, dF, aF, sc, last, 15.0, a1, o1)
+            finally:
+                m.close()
+            assert n1 == n0, (n_pts, ori)
+            np.testing.assert_array_equal(a1, a0); np.testing.assert_array_equal(o1, o0)
+        # SearchByProjection(Frame, MapPoints): best AND second best among the free features
+        g2, dF2, aF2, sc2, mp, a2, oc2 = sm.make_projection_case(20 + seed, n=1000, n_mp=n_pts)
+        hot = _crowd(rs, g2, dF2, targets)
+        tgt = hot[rs.randint(0, targets, n_pts)]
+        mp["u"] = (g2["x"][tgt] + rs.normal(0, 1.0, n_pts)).astype(np.float32); mp["v"] = (g2["y"][tgt] + rs.normal(0, 1.0, n_pts)).astype(np.float32)
+        mp["level"] = g2["octave"][tgt].astype(np.int32)
+        mp["desc"] = np.ascontiguousarray(dF2[tgt] ^ (np.packbits(rs.uniform(size=(n_pts, 256)) < noise, axis=1)))
+        mp["in_view"][:] = 1; mp["bad"][:] = 0
+        b0, p0 = a2.copy(), oc2.copy()
+        k0 = oracle.search_by_projection(g2, dF2, sc2, mp, 5.0, 0.9, b0, p0)
+        m = pkg.Matcher(0.9, True)
+        try:
+            b1, p1 = a2.copy(), oc2.copy()
+            k1 = m.SearchByProjection(g2, dF2, sc2, mp, 5.0, b1, p1)
+        finally:
+            m.close()
+        assert k1 == k0, n_pts
+        np.testing.assert_array_equal(b1, b0); np.testing.assert_array_equal(p1, p0)
