@@ -238,6 +238,8 @@ def main():
     plan = matcher.bow_plan([match_sets[i % n_sets] for i in range(B)])
     stream = torch.cuda.current_stream().cuda_stream
 
+    # (Measured and dropped: the step's SearchByBoW on a side stream behind its extraction, beside the NEXT step's extraction --
+    # 0.9863 against 0.9853 ms per step on one stream: the extraction keeps every SIMD issuing, a kernel beside it only takes its share.)
     def step():
         ex.extract_batch_device(d_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, d_kps.data_ptr(), d_desc.data_ptr(), cap,
                                 d_n.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
@@ -528,9 +530,9 @@ def main():
             v_bi, v_bv, v_nb = zb(torch.int32, cap), zb(torch.float64, cap), torch.zeros(B, dtype=torch.int32, device=dev)
             v_fn, v_fo, v_ff, v_nf = zb(torch.int32, cap), zb(torch.int32, cap + 1), zb(torch.int32, cap), torch.zeros(B, dtype=torch.int32, device=dev)
 
-            def vstep():
+            def vstep(on=None):
                 vv.transform_batch_device(d_desc.data_ptr(), d_n.data_ptr(), B, cap, 4, v_bi.data_ptr(), v_bv.data_ptr(), v_nb.data_ptr(),
-                                          v_fn.data_ptr(), v_fo.data_ptr(), v_ff.data_ptr(), v_nf.data_ptr(), stream)
+                                          v_fn.data_ptr(), v_fo.data_ptr(), v_ff.data_ptr(), v_nf.data_ptr(), stream if on is None else on)
             vstep(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
@@ -595,25 +597,66 @@ def main():
                 t_outl = torch.zeros(B * cap, dtype=torch.uint8, device=dev)
                 isig_t = (1.0 / np.asarray(sfac, np.float64) ** 2).astype(np.float32)
 
-                def tstep():
-                    ex.extract_batch_device(d_cur_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                            d_n.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
-                    vstep()
+                # Three schedules of the same four stages (all results identical, all measured):
+                #  "one":  everything in a row on the launch stream;
+                #  "side": the transform, which feeds neither the search nor PoseOptimization (the reference computes the BoW vector lazily, for
+                #          key-frame insertion and relocalisation), on a side stream beside them, ordered behind the extraction by an event;
+                #  "pipe": two batches in flight -- the extraction of batch k + 1 (its own stream, a second set of output arrays) beside the
+                #          transform / search / PoseOptimization of batch k, which leave most SIMDs idle (one workgroup per frame, latency
+                #          bound); a set of arrays is written again only when the batch that read it is done (events).  Throughput figure.
+                t_side = torch.cuda.Stream(device=dev); t_ev_v = torch.cuda.Event()
+                x_stream = torch.cuda.Stream(device=dev)
+                k2, de2, n2 = torch.zeros_like(d_kps), torch.zeros_like(d_desc), torch.zeros_like(d_n)
+                t_sets = [(d_kps, d_desc, d_n), (k2, de2, n2)]
+                t_ev_x = [torch.cuda.Event(), torch.cuda.Event()]; t_ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+                t_count = [0]
+
+                def tstep(mode="pipe"):
+                    k_ = t_count[0] & 1 if mode == "pipe" else 0
+                    t_count[0] += 1
+                    kp_, ds_, nn_ = t_sets[k_]
+                    cur_s = torch.cuda.current_stream()
+                    if mode == "pipe":
+                        x_stream.wait_event(t_ev_done[k_])          # (the batch that read this set of arrays two steps ago)
+                        ex.extract_batch_device(d_cur_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, kp_.data_ptr(), ds_.data_ptr(), cap,
+                                                nn_.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), x_stream.cuda_stream)
+                        t_ev_x[k_].record(x_stream)
+                        cur_s.wait_event(t_ev_x[k_])
+                    else:
+                        ex.extract_batch_device(d_cur_imgs.data_ptr(), B, Ww, Hh, Ww, Ww * Hh, kp_.data_ptr(), ds_.data_ptr(), cap,
+                                                nn_.data_ptr(), d_mono.data_ptr(), d_status.data_ptr(), (0, 1000), stream)
+                        t_ev_x[k_].record()
+                    if mode == "one":
+                        vstep()
+                    else:
+                        t_side.wait_event(t_ev_x[k_])
+                        vv.transform_batch_device(ds_.data_ptr(), nn_.data_ptr(), B, cap, 4, v_bi.data_ptr(), v_bv.data_ptr(), v_nb.data_ptr(),
+                                                  v_fn.data_ptr(), v_fo.data_ptr(), v_ff.data_ptr(), v_nf.data_ptr(), t_side.cuda_stream)
+                        t_ev_v.record(t_side)
                     l_u = (lk[:, :, 0] + 3.0).contiguous()
                     t_assign.fill_(-1); t_occ.zero_()
-                    mtrk.SearchByProjection_last_batch_device((d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap),
+                    mtrk.SearchByProjection_last_batch_device((kp_.data_ptr(), ds_.data_ptr(), nn_.data_ptr(), cap),
                                                               (l_valid.data_ptr(), l_u.data_ptr(), l_v.data_ptr(), l_oct.data_ptr(), l_ang.data_ptr(), l_desc.data_ptr(), l_n.data_ptr(), cap),
                                                               B, 15.0, t_assign.data_ptr(), t_occ.data_ptr(), t_nm.data_ptr(), stream,
                                                               bounds=(0.0, 0.0, float(Ww), float(Hh)), scale_factors=sfac)
                     tstep.keep = l_u
-                    ps_t.optimize_batch_device(B, cap, d_kps.data_ptr(), d_n.data_ptr(), t_assign.data_ptr(), l_mp.data_ptr(), cap, t_pose0.data_ptr(), isig_t, cam_t,
+                    ps_t.optimize_batch_device(B, cap, kp_.data_ptr(), nn_.data_ptr(), t_assign.data_ptr(), l_mp.data_ptr(), cap, t_pose0.data_ptr(), isig_t, cam_t,
                                                t_pose.data_ptr(), t_inl.data_ptr(), t_outl.data_ptr(), stream)
-                tstep(); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    tstep()
-                torch.cuda.synchronize()
-                dtt = (time.perf_counter() - t0) / 10
+                    if mode != "one":
+                        cur_s.wait_event(t_ev_v)
+                    t_ev_done[k_].record()
+
+                def time_chain(mode):
+                    tstep(mode); tstep(mode); torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    for _ in range(10):
+                        tstep(mode)
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0_) / 10
+                dtt_one = time_chain("one")
+                dtt_side = time_chain("side")
+                dtt = time_chain("pipe")
+                tstep("one"); torch.cuda.synchronize()          # (the legs below read the first set of arrays and the results of a whole step)
                 t0 = time.perf_counter()
                 for _ in range(10):
                     ps_t.optimize_batch_device(B, cap, d_kps.data_ptr(), d_n.data_ptr(), t_assign.data_ptr(), l_mp.data_ptr(), cap, t_pose0.data_ptr(), isig_t, cam_t,
@@ -621,12 +664,15 @@ def main():
                 torch.cuda.synchronize()
                 dtp_dev = (time.perf_counter() - t0) / 10
                 out["tracking"] = {"metric": "tracking chain frames/s (extract + DBoW2 transform + SearchByProjection(last frame) + PoseOptimization)",
-                                   "value": B / dtt, "unit": "frames/s", "ms_per_batch": 1e3 * dtt,
+                                   "value": B / dtt, "unit": "frames/s", "ms_per_batch": 1e3 * dtt, "ms_per_batch_one_stream": 1e3 * dtt_one,
+                                   "ms_per_batch_transform_beside": 1e3 * dtt_side,
                                    "projection_matches_per_frame": float(t_nm.float().mean().item()),
                                    "pose_inliers_per_frame": float(t_inl.float().mean().item()), "pose_device_entry_ms_per_batch": 1e3 * dtp_dev,
                                    "pose_translation_error_after": float(t_pose[:, 4:].abs().max().item()),
                                    "workload": "%d streams: current frame = last frame moved by 3 px; search and PoseOptimization run on the extractor's device "
-                                               "arrays (edges gathered on the device from the search's assignment), nothing visits the host" % B}
+                                               "arrays (edges gathered on the device from the search's assignment), nothing visits the host. Two batches in flight: the "
+                                               "extraction of batch k+1 runs beside the transform / search / PoseOptimization of batch k (ms_per_batch_one_stream: all four "
+                                               "in a row; ms_per_batch_transform_beside: only the transform on a side stream)" % B}
                 # ---- TrackLocalMap's device work (src/Tracking.cc:3082-3115: SearchLocalPoints -> SearchByProjection(Frame, vpMapPoints, th),
                 # "the dominant matcher call in steady-state tracking", SURVEY M4 -> PoseOptimization): the current frames as the chain above
                 # left them; the local map of a stream = the last frame's points plus as many again seen nearby (the same descriptors at
