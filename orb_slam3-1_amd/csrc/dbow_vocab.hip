@@ -171,20 +171,23 @@ __device__ __forceinline__ int block_rank(const unsigned long long* s, int n, bo
     return total;
 }
 
-__global__ __launch_bounds__(256) void k_vocab_assemble(const int32_t* __restrict__ n_per_frame, int n_fixed, int cap, int n_pow2,
+__global__ __launch_bounds__(256) void k_vocab_assemble(const int32_t* __restrict__ n_per_frame, int n_fixed, int cap, int n_pow2_max,
                                                        const uint32_t* __restrict__ word, const double* __restrict__ weight,
                                                        const uint32_t* __restrict__ node,
                                                        uint32_t* __restrict__ bow_id, double* __restrict__ bow_val, int32_t* __restrict__ n_bow,
                                                        uint32_t* __restrict__ fv_node, int32_t* __restrict__ fv_off, uint32_t* __restrict__ fv_feat,
                                                        int32_t* __restrict__ n_fv)
 {
-    extern __shared__ __align__(16) unsigned long long s_key[];        // n_pow2 keys, then n_pow2 doubles: the BowVector values (for the norm)
-    double* const s_val = (double*)(s_key + n_pow2);
+    extern __shared__ __align__(16) unsigned long long s_key[];        // n_pow2_max keys, then n_pow2_max doubles: the BowVector values (for the norm)
+    double* const s_val = (double*)(s_key + n_pow2_max);
     __shared__ int s_cnt[256];
     __shared__ double s_norm;
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int n = min(n_per_frame ? n_per_frame[frame] : n_fixed, cap);
     const size_t fo = (size_t)frame * cap;
+    int n_pow2 = 2;                             // this frame's own sort size (the launch's LDS is sized for the arrays' capacity)
+    while (n_pow2 < n) n_pow2 <<= 1;
+    n_pow2 = min(n_pow2, n_pow2_max);
     const int per = (n_pow2 + 255) / 256;
 
     // ---------- FeatureVector: keys (node id, feature index), only features whose word is not stopped (w > 0) ----------

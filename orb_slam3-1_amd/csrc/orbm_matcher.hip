@@ -523,13 +523,16 @@ struct ProjArgs {
     int32_t lds_frame;                       // stage the frame (grid, key points, descriptors) in LDS
 };
 
-__global__ __launch_bounds__(256) void k_grid(const ProjArgs* __restrict__ jobs, int n_pow2)
+__global__ __launch_bounds__(256) void k_grid(const ProjArgs* __restrict__ jobs, int n_pow2_max)
 {
     extern __shared__ __align__(16) unsigned long long s_gkey[];
     const ProjFrameDev F = jobs[blockIdx.x].F;
     const int tid = threadIdx.x, n = F.n, ncell = F.cols * F.rows;
     int32_t* cell_off = const_cast<int32_t*>(F.cell_off);
     int32_t* cell_feat = const_cast<int32_t*>(F.cell_feat);
+    int n_pow2 = 2;                             // this frame's own sort size (the launch's LDS is sized for the largest frame / the arrays' capacity)
+    while (n_pow2 < n) n_pow2 <<= 1;
+    n_pow2 = min(n_pow2, n_pow2_max);
     for (int i = tid; i < n_pow2; i += 256) {
         unsigned long long key = ~0ull;
         if (i < n) {

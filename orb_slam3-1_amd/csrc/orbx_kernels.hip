@@ -1090,13 +1090,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(const uint8_t* __restrict_
 }
 
 // median cut of :1086-1100: matches whose SAD is >= 1.5 * 1.4 * median are dropped.  One workgroup per frame.
-__global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nL, int cap, int n_pow2,
+__global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nL, int cap, int n_pow2_max,
                                                       float* __restrict__ u_right, float* __restrict__ depth, const int32_t* __restrict__ sad)
 {
-    extern __shared__ int s_sad[];       // n_pow2
+    extern __shared__ int s_sad[];       // n_pow2_max
     __shared__ int s_cnt;
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int n = min(nL[frame], cap);
+    int n_pow2 = 2;                      // this frame's own sort size (the launch's LDS is sized for the arrays' capacity)
+    while (n_pow2 < n) n_pow2 <<= 1;
+    n_pow2 = min(n_pow2, n_pow2_max);
     const size_t fo = (size_t)frame * cap;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
