@@ -564,13 +564,10 @@ __global__ __launch_bounds__(256) void k_grid(const ProjArgs* __restrict__ jobs,
         __syncthreads();
     }
     for (int i = tid; i < n; i += 256) if (s_gkey[i] != ~0ull) cell_feat[i] = (int32_t)(s_gkey[i] & 0xFFFFFFFFull);
-    // cell_off[c] = number of keys with cell < c = the first sorted position whose cell is >= c: position i writes it for the cells
-    // behind its predecessor's up to its own (the first invalid position, or the virtual one behind the last key, for the rest) --
-    // ncell + 1 stores in all instead of a binary search of ten dependent LDS reads per cell
-    for (int i = tid; i <= n_pow2; i += 256) {
-        const int c = (i < n_pow2 && s_gkey[i] != ~0ull) ? (int)(s_gkey[i] >> 32) : ncell;
-        const int cp = i == 0 ? -1 : (s_gkey[i - 1] != ~0ull ? (int)(s_gkey[i - 1] >> 32) : ncell);
-        for (int cc = cp + 1; cc <= c; cc++) cell_off[cc] = i;
+    for (int c = tid; c <= ncell; c += 256) {            // cell_off[c] = number of keys with cell < c
+        int lo = 0, hi = n_pow2;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((s_gkey[mid] >> 32) < (unsigned long long)c) lo = mid + 1; else hi = mid; }
+        cell_off[c] = lo;
     }
 }
 
