@@ -495,3 +495,27 @@ def test_projection_searches_under_contention(pkg, oracle, sm, seed, targets, no
             m.close()
         assert k1 == k0, n_pts
         np.testing.assert_array_equal(b1, b0); np.testing.assert_array_equal(p1, p0)
+
+
+@pytest.mark.parametrize("n_pts", [1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320])
+def test_projection_searches_at_block_boundaries(pkg, oracle, sm, n_pts):
+    """point counts around the multiples of 64: the search kernel takes the points in blocks of 64 through a three-stage pipeline (resolve
+    block b, walk block b + 1, build block b + 2, loads of block b + 3 in flight) -- the first / last / only block and the blocks whose
+    successors do not exist are the cases its conditions have to get right."""
+    g, dF, aF, sc, last, a, oc = sm.make_last_frame_case(60, n=1000, n_last=n_pts)
+    a0, o0 = a.copy(), oc.copy()
+    n0 = oracle.search_by_projection_last(g, dF, aF, sc, last, 15.0, True, a0, o0)
+    g2, dF2, aF2, sc2, mp, a2, oc2 = sm.make_projection_case(60, n=1000, n_mp=n_pts)
+    b0, p0 = a2.copy(), oc2.copy()
+    k0 = oracle.search_by_projection(g2, dF2, sc2, mp, 4.0, 0.8, b0, p0)
+    m = pkg.Matcher(0.8, True)
+    try:
+        a1, o1 = a.copy(), oc.copy()
+        n1 = m.SearchByProjection_last(g, dF, aF, sc, last, 15.0, a1, o1)
+        b1, p1 = a2.copy(), oc2.copy()
+        k1 = m.SearchByProjection(g2, dF2, sc2, mp, 4.0, b1, p1)
+    finally:
+        m.close()
+    assert (n1, k1) == (n0, k0)
+    np.testing.assert_array_equal(a1, a0); np.testing.assert_array_equal(o1, o0)
+    np.testing.assert_array_equal(b1, b0); np.testing.assert_array_equal(p1, p0)
