@@ -119,6 +119,24 @@ __device__ void bow_node(const BowPairDev& P, int k, int f, float nnratio, int c
 // lanes.  (distance, position) keys make the 16-lane minimum the reference's first best / second best.  The lanes keep
 // the "already consumed" state of the candidates they own in a register bitmask (positions lane, lane+16, ...).
 constexpr int kBowGroup = 16, kBowThreads = 1024;
+// The two smallest keys of a 16-lane group in every lane of it.  A group is one DPP row: four exchanges (lane ^ 1, lane ^ 2 by quad
+// permutes, then the mirror of each half row and of the row -- every step joins two disjoint sets) at VALU speed; the same ladder through
+// ds_bpermute (__shfl_xor) was eight dependent LDS-crossbar round trips per KF feature, most of the loop.  All 16 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ void bow_top2_step(unsigned& k1, unsigned& k2)
+{
+    const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)k1, CTRL, 0xF, 0xF, false);
+    const unsigned o2 = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)k2, CTRL, 0xF, 0xF, false);
+    if (o1 < k1) { k2 = min(k1, o2); k1 = o1; } else k2 = min(k2, o1);
+}
+__device__ __forceinline__ void bow_group_top2(unsigned& k1, unsigned& k2)
+{
+    static_assert(kBowGroup == 16, "a group is a DPP row");
+    bow_top2_step<0xB1>(k1, k2);        // quad_perm [1, 0, 3, 2]
+    bow_top2_step<0x4E>(k1, k2);        // quad_perm [2, 3, 0, 1]
+    bow_top2_step<0x141>(k1, k2);       // row_half_mirror
+    bow_top2_step<0x140>(k1, k2);       // row_mirror
+}
 template <bool KFKF>
 __device__ void bow_node_group(const BowPairDev& P, int k, int f, float nnratio, int check_ori, int* s_hist, int sub)
 {
@@ -138,10 +156,7 @@ __device__ void bow_node_group(const BowPairDev& P, int k, int f, float nnratio,
             const unsigned key = ((unsigned)(__popcll(a0 ^ db[0]) + __popcll(a1 ^ db[1]) + __popcll(a2 ^ db[2]) + __popcll(a3 ^ db[3])) << 16) | (unsigned)c;
             if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
         }
-        for (int o = kBowGroup / 2; o > 0; o >>= 1) {
-            const unsigned o1 = (unsigned)__shfl_xor((int)k1, o), o2 = (unsigned)__shfl_xor((int)k2, o);
-            if (o1 < k1) { k2 = min(k1, o2); k1 = o1; } else k2 = min(k2, o1);
-        }
+        bow_group_top2(k1, k2);
         if (k1 == 0xFFFFFFFFu) continue;
         const int best1 = (int)(k1 >> 16), best2 = (k2 == 0xFFFFFFFFu) ? 256 : (int)(k2 >> 16), cbest = (int)(k1 & 0xFFFFu);
         const bool low = KFKF ? (best1 < TH_LOW) : (best1 <= TH_LOW);       // :848 is strict, :327 is not
@@ -167,18 +182,20 @@ __device__ __forceinline__ unsigned long long shfl16_u64(unsigned long long v, i
     const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src, kBowGroup), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src, kBowGroup);
     return ((unsigned long long)hi << 32) | lo;
 }
-template <bool KFKF>
-__device__ void bow_node_group32(const BowPairDev& P, int k, int f, float nnratio, int check_ori, int* s_hist, int sub)
+// J = candidates per lane: 2 (a node of at most 32 Frame features), 4 (64), 6 (96; 8 spills registers at 1 024 threads).  Real frames through a vocabulary hold a few nodes
+// beyond 32 features; the generic form took 175 us for such a pair where the rest of the pair takes 20.
+template <bool KFKF, int J>
+__device__ void bow_node_group_regs(const BowPairDev& P, int k, int f, float nnratio, int check_ori, int* s_hist, int sub)
 {
-    const int b2 = P.off2[f], n2 = P.off2[f + 1] - b2;         // n2 <= 32
-    int idx2[2] = {0, 0};
-    bool ok2[2];
-    unsigned long long db[2][4];
-    float ang2[2] = {0.f, 0.f};
+    const int b2 = P.off2[f], n2 = P.off2[f + 1] - b2;         // n2 <= 16 J
+    int idx2[J];
+    bool ok2[J];
+    unsigned long long db[J][4];
+    float ang2[J];
 #pragma unroll
-    for (int j = 0; j < 2; j++) { const int c = sub + kBowGroup * j; ok2[j] = c < n2; if (ok2[j]) idx2[j] = (int)P.feat2[b2 + c]; }
+    for (int j = 0; j < J; j++) { const int c = sub + kBowGroup * j; ok2[j] = c < n2; idx2[j] = 0; ang2[j] = 0.f; if (ok2[j]) idx2[j] = (int)P.feat2[b2 + c]; }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < J; j++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) db[j][q] = 0ull;
         if (ok2[j]) {
@@ -212,22 +229,22 @@ __device__ void bow_node_group32(const BowPairDev& P, int k, int f, float nnrati
             const float an1 = __shfl(ang1, i, kBowGroup);
             unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < J; j++) {
                 if (!ok2[j] || ((taken >> j) & 1u)) continue;
                 const unsigned key = ((unsigned)(__popcll(a0 ^ db[j][0]) + __popcll(a1 ^ db[j][1]) + __popcll(a2 ^ db[j][2]) + __popcll(a3 ^ db[j][3])) << 16) | (unsigned)(sub + kBowGroup * j);
                 if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
             }
-            for (int o = kBowGroup / 2; o > 0; o >>= 1) {
-                const unsigned o1 = (unsigned)__shfl_xor((int)k1, o), o2 = (unsigned)__shfl_xor((int)k2, o);
-                if (o1 < k1) { k2 = min(k1, o2); k1 = o1; } else k2 = min(k2, o1);
-            }
+            bow_group_top2(k1, k2);
             if (k1 == 0xFFFFFFFFu) continue;
             const int best1 = (int)(k1 >> 16), best2 = (k2 == 0xFFFFFFFFu) ? 256 : (int)(k2 >> 16), cbest = (int)(k1 & 0xFFFFu);
             const bool low = KFKF ? (best1 < TH_LOW) : (best1 <= TH_LOW);       // :848 is strict, :327 is not
             if (low && (float)best1 < nnratio * (float)best2) {
                 const int jb = cbest / kBowGroup, lb = cbest & (kBowGroup - 1);
-                const int bestIdx = __shfl(jb ? idx2[1] : idx2[0], lb, kBowGroup);
-                const float an2 = __shfl(jb ? ang2[1] : ang2[0], lb, kBowGroup);
+                int sel_i = idx2[0]; float sel_a = ang2[0];
+#pragma unroll
+                for (int j = 1; j < J; j++) if (jb == j) { sel_i = idx2[j]; sel_a = ang2[j]; }
+                const int bestIdx = __shfl(sel_i, lb, kBowGroup);
+                const float an2 = __shfl(sel_a, lb, kBowGroup);
                 if (lb == sub) taken |= 1u << jb;
                 if (sub == 0) {
                     if (KFKF) { P.match[idx1] = bestIdx; P.matched2[bestIdx] = 1; }
@@ -277,7 +294,9 @@ __global__ __launch_bounds__(kBowThreads) void k_bow(const BowPairDev* __restric
                 // a node with more than 512 Frame features does not fit the per-lane bitmask: one lane walks it
                 const int n2 = P.off2[lo + 1] - P.off2[lo];
                 if (n2 > 32 * kBowGroup) { if (sub == 0) bow_node<KFKF>(P, k, lo, nnratio, check_ori, s_hist); }
-                else if (n2 <= 2 * kBowGroup) bow_node_group32<KFKF>(P, k, lo, nnratio, check_ori, s_hist, sub);
+                else if (n2 <= 2 * kBowGroup) bow_node_group_regs<KFKF, 2>(P, k, lo, nnratio, check_ori, s_hist, sub);
+                else if (n2 <= 4 * kBowGroup) bow_node_group_regs<KFKF, 4>(P, k, lo, nnratio, check_ori, s_hist, sub);
+                else if (n2 <= 6 * kBowGroup) bow_node_group_regs<KFKF, 6>(P, k, lo, nnratio, check_ori, s_hist, sub);
                 else bow_node_group<KFKF>(P, k, lo, nnratio, check_ori, s_hist, sub);
             }
         }
