@@ -519,3 +519,37 @@ def test_projection_searches_at_block_boundaries(pkg, oracle, sm, n_pts):
     assert (n1, k1) == (n0, k0)
     np.testing.assert_array_equal(a1, a0); np.testing.assert_array_equal(o1, o0)
     np.testing.assert_array_equal(b1, b0); np.testing.assert_array_equal(p1, p0)
+
+
+@pytest.mark.parametrize("seed,ori", [(0, True), (1, False)])
+def test_search_by_bow_node_sizes(pkg, oracle, synth, seed, ori):
+    """vocabulary nodes of 1 .. 600 Frame features: the kernel keeps the candidates of a node in registers up to 32 / 64 / 96 of them, walks
+    larger nodes from memory with a bitmask per lane up to 512 and leaves the rest to one lane -- every path, and the boundaries between
+    them, against the oracle (real frames through a vocabulary hold a few nodes beyond 32 features; the synthetic match sets none)."""
+    ms = synth.make_match_set(30 + seed, n=2600)
+    n = len(ms["dF"])
+    sizes = [1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 95, 96, 97, 130, 200, 513, 600]
+    node_f = np.zeros(n, np.int64)
+    pos = 0
+    for k_, sz in enumerate(sizes):
+        node_f[pos:pos + sz] = 10 + 3 * k_
+        pos += sz
+    rs = np.random.RandomState(5 + seed)
+    node_f[pos:] = 500 + rs.randint(0, 8, n - pos)          # the rest: a few nodes of ordinary size
+    # a key-frame feature mostly falls into the node of the frame feature it is a copy of; some go astray
+    node_k = node_f[ms["perm"]].copy()
+    astray = rs.uniform(size=n) < 0.1
+    node_k[astray] = rs.choice(np.unique(node_f), int(astray.sum()))
+    fvF, fvK = synth.feature_vector(node_f), synth.feature_vector(node_k)
+    n0, m0 = oracle.search_by_bow(ms["dKF"], ms["validKF"], ms["angKF"], fvK, ms["dF"], ms["angF"], fvF, 0.75, ori)
+    m = pkg.Matcher(0.75, ori)
+    try:
+        n1, m1 = m.SearchByBoW(ms["dKF"], ms["validKF"], ms["angKF"], fvK, ms["dF"], ms["angF"], fvF)
+        k0, q0 = oracle.search_by_bow_kfkf(ms["dKF"], ms["validKF"], ms["angKF"], fvK, ms["dF"], np.ones(n, np.uint8), ms["angF"], fvF, 0.75, ori)
+        k1, q1 = m.SearchByBoW_KFKF(ms["dKF"], ms["validKF"], ms["angKF"], fvK, ms["dF"], np.ones(n, np.uint8), ms["angF"], fvF)
+    finally:
+        m.close()
+    assert n1 == n0 and n0 > 500
+    np.testing.assert_array_equal(m1, m0)
+    assert k1 == k0
+    np.testing.assert_array_equal(q1, q0)
