@@ -221,9 +221,11 @@ __device__ void bow_node_group_regs(const BowPairDev& P, int k, int f, float nnr
             for (int q = 0; q < 4; q++) A[q] = da[q];
             if (check_ori) ang1 = P.a1[(size_t)idx1m * P.a1_stride];
         }
+        // (the validity of the 16 features as a bit mask from one wave ballot: no LDS-crossbar round trip per feature for it)
+        const unsigned vmask = (unsigned)((__ballot(valid != 0) >> (threadIdx.x & 48)) & 0xFFFFull);
         const int cnt = min(kBowGroup, n1 - i0);
         for (int i = 0; i < cnt; i++) {
-            if (!__shfl(valid, i, kBowGroup)) continue;         // uniform over the group
+            if (!((vmask >> i) & 1u)) continue;                 // uniform over the group
             const unsigned long long a0 = shfl16_u64(A[0], i), a1 = shfl16_u64(A[1], i), a2 = shfl16_u64(A[2], i), a3 = shfl16_u64(A[3], i);
             const int idx1 = __shfl(idx1m, i, kBowGroup);
             const float an1 = __shfl(ang1, i, kBowGroup);
@@ -240,13 +242,11 @@ __device__ void bow_node_group_regs(const BowPairDev& P, int k, int f, float nnr
             const bool low = KFKF ? (best1 < TH_LOW) : (best1 <= TH_LOW);       // :848 is strict, :327 is not
             if (low && (float)best1 < nnratio * (float)best2) {
                 const int jb = cbest / kBowGroup, lb = cbest & (kBowGroup - 1);
-                int sel_i = idx2[0]; float sel_a = ang2[0];
+                if (lb == sub) {            // the lane that owns the winner records the match: it holds the winner's index and angle, the key-frame side is uniform
+                    taken |= 1u << jb;
+                    int bestIdx = idx2[0]; float an2 = ang2[0];
 #pragma unroll
-                for (int j = 1; j < J; j++) if (jb == j) { sel_i = idx2[j]; sel_a = ang2[j]; }
-                const int bestIdx = __shfl(sel_i, lb, kBowGroup);
-                const float an2 = __shfl(sel_a, lb, kBowGroup);
-                if (lb == sub) taken |= 1u << jb;
-                if (sub == 0) {
+                    for (int j = 1; j < J; j++) if (jb == j) { bestIdx = idx2[j]; an2 = ang2[j]; }
                     if (KFKF) { P.match[idx1] = bestIdx; P.matched2[bestIdx] = 1; }
                     else P.match[bestIdx] = idx1;
                     if (check_ori) atomicAdd(&s_hist[rot_bin(an1, an2)], 1);
@@ -272,6 +272,8 @@ __global__ __launch_bounds__(kBowThreads) void k_bow(const BowPairDev* __restric
     if (KFKF) for (int i = tid; i < P.n2; i += kBowThreads) P.matched2[i] = 0;
     if (tid < HISTO_LENGTH) s_hist[tid] = 0;
     if (tid == 0) s_count = 0;
+    // (measured and dropped: the Frame's node ids in LDS for the groups' binary search -- no difference, 37 us per 256 pairs either way;
+    // what a node costs is its chain of dependent global reads: offsets -> feature indices -> descriptors, on both sides)
     __threadfence_block();
     __syncthreads();
     if (P.serial) {
